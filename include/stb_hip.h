@@ -1,0 +1,111 @@
+/*
+ * stb_hip.h -- additive C ABI of libstb_amd for device-resident / batched use of the hot path.
+ *
+ * The reference (wbuntine/libstb) has no such interface: its only API is the scalar host one in
+ * stable.h / psample.h, which this library also exports unchanged (see those headers).  The entry
+ * points below expose the same arithmetic -- the table fill of S_remake_part
+ * (reference lib/stable.c:321-388), the S_S gather-sum and restaurant terms of aterms
+ * (lib/samplea.c:46-83) and the lgamma sum of bterms (lib/sampleb.c:33-41) -- for callers that keep
+ * tables and (n,t) groups resident in HBM and evaluate many discounts at once (SURVEY 8b "new,
+ * additive C ABI").  Plain pointers and sizes only; every device pointer is a hipMalloc'd (or
+ * torch-allocated) address on the current device; `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  All functions return 0 on success, non-zero on failure with the
+ * message available from stb_last_error(); nothing here falls back to the CPU.
+ */
+#ifndef STB_HIP_H
+#define STB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- diagnostics ---- */
+const char *stb_last_error(void);
+int stb_device_count(void);                 /* 0 when no usable GPU */
+int stb_device_name(char *buf, int len);    /* name + gcnArch of the current device */
+
+/* ---- memory and stream helpers, so that C / FFI callers need no HIP headers ---- */
+void *stb_device_malloc(size_t bytes);                 /* hipMalloc; NULL on failure */
+void stb_device_free(void *p);
+void *stb_host_malloc(size_t bytes);                   /* pinned (hipHostMalloc); NULL on failure */
+void stb_host_free(void *p);
+int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int stb_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int stb_stream_sync(void *stream);
+
+/* ---- layout of one table slab (see libstb_amd/csrc/stb_layout.h) ---- */
+uint64_t stb_cells(unsigned N, unsigned M);        /* stored values: sum_{n=3..N} min(n-2,M-1) */
+uint64_t stb_elems(unsigned N, unsigned M);        /* doubles to allocate (rows start 16B aligned) */
+uint64_t stb_rowoff(unsigned n, unsigned M);       /* element offset of row n; value (n,m) at +m-2 */
+uint64_t stb_vcells(unsigned N, unsigned M);       /* same three for the V (ratio) table */
+uint64_t stb_velems(unsigned N, unsigned M);
+uint64_t stb_vrowoff(unsigned n, unsigned M);
+
+/* growth policy of the table object (reference lib/stable.c:564-630, S_extend): given current and
+ * maximum bounds and the (n+1, m+1) an accessor asks for, the bounds the table grows to.  Pure
+ * integer function; S_S / S_V use it internally, exported so callers can pre-size. */
+void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned maxM, int N, int M,
+                       unsigned *newN, unsigned *newM);
+
+/* ---- K1/K2: fill D log-Stirling tables (D=1: S_remake; D>1: the batched-discount mode) ----
+ * a_host[D]            discounts (host memory), 0 < a < 1
+ * d_tables             D slabs of stb_elems(N,M) doubles, slab d at d_tables + d*table_stride
+ * d_S1                 D vectors of N doubles (S1[n-1] = log S^n_{1,a}), vector d at + d*s1_stride
+ * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
+ * variant              STB_FILL_SCALED (default) or STB_FILL_LOGDOMAIN
+ */
+#define STB_FILL_SCALED 0    /* recurrence carried as (mantissa, exponent); log taken on output */
+#define STB_FILL_LOGDOMAIN 1 /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
+size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
+int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
+int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
+               uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
+               int variant, void *stream);
+/* V tables (next row 8f-1): V^n_m for 2<=n<=N, 2<=m<=min(n,M); lib/stable.c:451-482 */
+int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
+               uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);
+
+/* ---- lookups with S_S semantics (lib/stable.c:941-974, no growth): out[g] = S_S(n[g], t[g]) ---- */
+int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
+                 const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out, void *stream);
+
+/* ---- K3: sweep.  out[d] = sum over pairs g with n[g]>1 of S_S_d(n[g], t[g])  (samplea.c:68-80) ---- */
+size_t stb_sweep_workspace_bytes(uint64_t G, int D);
+int stb_sweep_S(const double *d_tables, uint64_t table_stride, const double *d_S1,
+                uint64_t s1_stride, int D, unsigned N, unsigned M, const uint32_t *d_n,
+                const uint16_t *d_t, uint64_t G, double *d_out, void *d_ws, size_t ws_bytes,
+                void *stream);
+
+/* ---- K4: per-restaurant terms.
+ * restaurant: out[d] = sum_i T_i*log(x_d) + lgamma(T_i + b_i/x_d) - lgamma(b_i/x_d)  (samplea.c:65-67)
+ * bterms:     out[j] = -Q*x_j + (shape-1)*log(x_j) + sum_i (lgamma(T_i + x_j/apar) - lgamma(x_j/apar))
+ *                                                                            (sampleb.c:33-41)
+ * x_host[D] are host doubles; d_T (uint32) and d_bpar (double) device arrays of I entries. */
+size_t stb_terms_workspace_bytes(uint64_t I, int D);
+int stb_restaurant_terms(const double *x_host, int D, const uint32_t *d_T, const double *d_bpar,
+                         uint64_t I, double *d_out, void *d_ws, size_t ws_bytes, void *stream);
+int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
+               const uint32_t *d_T, uint64_t I, double *d_out, void *d_ws, size_t ws_bytes,
+               void *stream);
+
+/* ---- device-resident group set + grid evaluation (host-friendly wrappers over the above) ----
+ * stb_groups_t owns device copies of the flat (n,t) pairs and the per-restaurant T, bpar, plus
+ * the scratch needed to evaluate aterms on up to Dmax discounts with table bounds (N,M). */
+typedef struct stb_groups stb_groups_t;
+stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
+                                const uint16_t *tflat, const double *bpar, unsigned N, unsigned M,
+                                int Dmax);
+void stb_groups_free(stb_groups_t *g);
+/* out_host[D] = aterms(x_d) for every d: table build + sweep + restaurant terms.  D <= Dmax. */
+int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host);
+/* pieces of the same evaluation, for timing: ms of device time per stage (may be NULL) */
+int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double *out_host,
+                            float *ms_fill, float *ms_sweep, float *ms_terms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,858 @@
+// stb_kernels.hip -- gfx950 kernels and the additive C ABI (include/stb_hip.h) of libstb_amd.
+//
+// What runs here, and the reference code it replaces (paths relative to the reference tree):
+//   K1/K2  k_fill_rows      table fill of S_remake_part, double S branch   lib/stable.c:321-388
+//   K3     k_sweep_partial  the S_S gather-sum inside aterms               lib/samplea.c:68-80
+//   K4     k_terms_partial  restaurant terms of aterms / lgamma sum of bterms
+//                                                       lib/samplea.c:65-67, lib/sampleb.c:33-41
+//          k_lookup         S_S semantics for a list of (n,m)              lib/stable.c:941-974
+//
+// Design notes (DESIGN.md has the long form).  A table row depends only on the row above it, and
+// inside a row information moves one column to the right per row (cell (n,m) reads (n-1,m) and
+// (n-1,m-1)).  So the table is cut into column strips, one 64-lane wavefront per strip, every
+// lane holding C adjacent columns in registers; the only cross-lane traffic is one DPP wave shift
+// per row.  A launch advances every strip by R rows; a strip recomputes an R-column halo on its
+// left instead of synchronising with its neighbour, and the kernel boundary publishes the last
+// row (the "frontier", kept in (mantissa, exponent) form) for the next launch.  Stores go
+// straight from registers to the row-major slab, 16 B per lane, 1 KiB per wave-instruction.
+//
+// No CPU fallback exists in this file: without a device every entry point fails with a message.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "stb_layout.h"
+#include "../../include/stb_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char *stb_last_error(void) { return g_err; }
+
+extern "C" int stb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int stb_device_name(char *buf, int len) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return 0;
+}
+
+extern "C" void *stb_device_malloc(size_t bytes) {
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void stb_device_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+extern "C" void *stb_host_malloc(size_t bytes) {
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void stb_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+extern "C" int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+  HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int stb_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+  HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int stb_stream_sync(void *stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+extern "C" uint64_t stb_cells(unsigned N, unsigned M) { return stb_table_cells(N, M); }
+extern "C" uint64_t stb_elems(unsigned N, unsigned M) { return stb_table_elems(N, M); }
+extern "C" uint64_t stb_rowoff(unsigned n, unsigned M) { return stb_row_offset(n, M); }
+extern "C" uint64_t stb_vcells(unsigned N, unsigned M) { return stb_vtable_cells(N, M); }
+extern "C" uint64_t stb_velems(unsigned N, unsigned M) { return stb_vtable_elems(N, M); }
+extern "C" uint64_t stb_vrowoff(unsigned n, unsigned M) { return stb_vrow_offset(n, M); }
+
+// ------------------------------------------------------------------------------------------------
+// cell arithmetic
+
+// A table value S (not its log) as mant * 2^expo, mant in [0.5,1), or exact zero (mant 0, expo EZ).
+// The recurrence  S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1}  is then one fma plus exponent
+// bookkeeping -- no transcendental on the dependent chain, and every step rounds once at 2^-53
+// relative, which is tighter than the reference's log-domain step (one rounding at ulp(log S)).
+#define STB_EZ (-(1 << 28))
+
+struct cell_t {
+  double m;
+  int e;
+};
+
+__device__ __forceinline__ cell_t cell_zero() { return cell_t{0.0, STB_EZ}; }
+__device__ __forceinline__ cell_t cell_one() { return cell_t{0.5, 1}; }
+
+// coef * up + left
+__device__ __forceinline__ cell_t cell_step(double coef, cell_t up, cell_t left) {
+  int E = max(up.e, left.e);
+  double x = ldexp(up.m, up.e - E);
+  double y = ldexp(left.m, left.e - E);
+  double r = fma(coef, x, y);
+  cell_t o;
+  o.m = __builtin_amdgcn_frexp_mant(r);
+  o.e = E + __builtin_amdgcn_frexp_exp(r);
+  return o;
+}
+
+__device__ __forceinline__ double cell_log(cell_t c) {
+  // log(m 2^e) = e ln2 + log m ; ln2 split so that e*LN2_HI is exact for |e| < 2^20
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  double de = (double)c.e;
+  return fma(de, LN2_HI, fma(de, LN2_LO, log(c.m)));
+}
+
+// log-domain variant: the reference's own cell update, same association order
+// (lib/stable.c:95-103 logadd; :381-386 the two call sites).  rn intrinsics keep hipcc from
+// contracting n - m*a into an fma the reference does not have.
+__device__ __forceinline__ double ld_logadd(double V, double lp) {
+#pragma clang fp contract(off)
+  double hi = V, lo = lp;
+  if (lp > V) {
+    hi = lp;
+    lo = V;
+  }
+  return hi + log(1.0 + exp(lo - hi));
+}
+// lib/stable.c:384-385: logadd(log(N-M*a-1.0) + S[N-1][M], S[N-1][M-1])
+__device__ __forceinline__ double ld_cell(int n, int c, double a, double up, double left) {
+#pragma clang fp contract(off)
+  const double coef = ((double)n - (double)c * a) - 1.0;
+  return ld_logadd(log(coef) + up, left);
+}
+
+// one lane shifted up by one across the whole 64-lane wave (lane l receives lane l-1's value,
+// lane 0 receives `fill`): DPP wave_shr:1, no LDS traffic
+__device__ __forceinline__ int wave_shr1(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double wave_shr1(double v, double fill) {
+  int lo = wave_shr1(__double2loint(v), __double2loint(fill));
+  int hi = wave_shr1(__double2hiint(v), __double2hiint(fill));
+  return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1/K2: fill
+
+struct fill_args {
+  const double *a;    // [D] discounts (device)
+  double *tables;     // D slabs (S or V layout)
+  uint64_t tstride;   // elements between slabs
+  double *S1;         // D vectors of N (S modes only)
+  uint64_t s1stride;
+  double *fm;         // frontier mantissas / plain values: [D][2][W]
+  int *fe;            // frontier exponents (scaled mode):  [D][2][W]
+  unsigned W;         // frontier row pitch (>= M+2)
+  unsigned N, M;
+  int R;              // rows advanced per launch
+  int H;              // halo columns (>= R, multiple of C)
+  int Wv;             // owned columns per strip = 64*C - H
+};
+
+#define STB_MODE_SCALED 0  // S table, (mantissa, exponent) cells
+#define STB_MODE_LOGDOM 1  // S table, log-domain cells in the reference's operation order
+#define STB_MODE_VRATIO 2  // V table, plain doubles in the reference's operation order
+
+// lib/stable.c:475-480: V^n_m = (1 + (m<n ? (n-1-m a) V^{n-1}_m : 0)) / (1/V^{n-1}_{m-1} + (n-1-(m-1)a)).
+// Column 1 is carried as +inf so that 1/V^{n-1}_1 = 0 turns this into the m=2 form of :475.
+__device__ __forceinline__ double v_cell(int n, int c, double a, double up, double left) {
+#pragma clang fp contract(off)
+  const double nm1 = (double)(n - 1);
+  const double num = 1.0 + ((c < n) ? ((nm1 - (double)c * a) * up) : 0.0);
+  const double den = 1.0 / left + (nm1 - (double)(c - 1) * a);
+  return num / den;
+}
+
+// Columns are numbered from 1 (column 1 is S^n_1, the S1 vector; columns <= 0 are identically 0).
+// Strip j owns columns [2 + j*Wv, 2 + (j+1)*Wv); its wave also carries H halo columns to the left,
+// so lane l holds columns cs + l*C .. cs + l*C + C-1 with cs = 2 + j*Wv - H.  For strip 0 the
+// "halo" is columns <= 1, which are exact (zeros and S1), so nothing is ever approximate.
+// Launch k advances rows n0 = 2 + k*R .. n0 + R - 1 from the frontier (row n0 - 1).
+template <int C, int MODE>
+__global__ __launch_bounds__(64) void k_fill_rows(fill_args A, int k) {
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x;
+  const int d = blockIdx.y;
+  const double a = A.a[d];
+  const unsigned N = A.N, M = A.M;
+  const int n0 = 2 + k * A.R;                                      // first row of this launch
+  const int n1 = min((int)N, n0 + A.R - 1);                        // last row
+  const int nf = n0 - 1;                                           // frontier row (already done)
+  const int c0 = 2 + j * A.Wv - A.H + lane * C;                    // lane's first column
+  const bool owned = lane * C >= A.H;                              // lane's columns are stored
+  double *table = A.tables + (uint64_t)d * A.tstride;
+  double *S1 = (MODE == STB_MODE_VRATIO) ? nullptr : A.S1 + (uint64_t)d * A.s1stride;
+  const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+  const double *fm_in = A.fm + fbase + (uint64_t)(k & 1) * A.W;
+  const int *fe_in = A.fe + fbase + (uint64_t)(k & 1) * A.W;
+  double *fm_out = A.fm + fbase + (uint64_t)((k + 1) & 1) * A.W;
+  int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
+
+  // ---- state of row nf for my C columns ----
+  cell_t st[C];
+  const int cmax_f = min(nf, (int)M);  // columns above the diagonal of row nf are zero
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int c = c0 + i;
+    if (MODE == STB_MODE_LOGDOM) {
+      st[i].e = 0;
+      if (k == 0)
+        st[i].m = (c == 1) ? 0.0 : -HUGE_VAL;  // row 1: log S^1_1 = 0
+      else
+        st[i].m = (c >= 1 && c <= cmax_f) ? fm_in[c] : -HUGE_VAL;
+    } else if (MODE == STB_MODE_VRATIO) {
+      st[i].e = 0;
+      if (c == 1)
+        st[i].m = HUGE_VAL;
+      else if (k == 0)
+        st[i].m = 0.0;
+      else
+        st[i].m = (c >= 2 && c <= cmax_f) ? fm_in[c] : 0.0;
+    } else {
+      if (k == 0)
+        st[i] = (c == 1) ? cell_one() : cell_zero();
+      else if (c >= 1 && c <= cmax_f)
+        st[i] = cell_t{fm_in[c], fe_in[c]};
+      else
+        st[i] = cell_zero();
+    }
+  }
+  if (MODE != STB_MODE_VRATIO && k == 0 && j == 0 && lane == 0) S1[0] = 0.0;  // log S^1_1
+
+  for (int n = n0; n <= n1; n++) {
+    // value of my left neighbour's last column in row n-1
+    cell_t left;
+    if (MODE == STB_MODE_SCALED) {
+      left.m = wave_shr1(st[C - 1].m, 0.0);
+      left.e = wave_shr1(st[C - 1].e, STB_EZ);
+    } else {
+      left.m = wave_shr1(st[C - 1].m, (MODE == STB_MODE_LOGDOM) ? -HUGE_VAL : 0.0);
+      left.e = 0;
+    }
+    const double nm1 = (double)(n - 1);
+#pragma unroll
+    for (int i = C - 1; i >= 0; i--) {
+      const int c = c0 + i;
+      const cell_t lf = (i > 0) ? st[i - 1] : left;
+      if (MODE == STB_MODE_LOGDOM) {
+        double v;
+        if (c >= n || c < 1)
+          v = (c == n) ? 0.0 : -HUGE_VAL;  // S^n_n = 1; above the diagonal / left of column 1: 0
+        else
+          // the (M<N-1)?:0 case of the reference is covered: the diagonal state is exactly 0.0
+          v = ld_cell(n, c, a, st[i].m, lf.m);
+        st[i].m = v;
+      } else if (MODE == STB_MODE_VRATIO) {
+        double v;
+        if (c == 1) v = HUGE_VAL;
+        else if (c < 1 || c > n) v = 0.0;
+        else v = v_cell(n, c, a, st[i].m, lf.m);
+        st[i].m = v;
+      } else {
+        st[i] = cell_step(fma(-(double)c, a, nm1), st[i], lf);
+      }
+    }
+    // ---- write row n ----
+    // last stored column of row n: S keeps m<=n-1 (the diagonal is implicit), V keeps m<=n
+    const int cmax = min((MODE == STB_MODE_VRATIO) ? n : n - 1, (int)M);
+    if (owned) {
+      const uint64_t roff = (MODE == STB_MODE_VRATIO) ? stb_vrow_offset((unsigned)n, M)
+                                                      : stb_row_offset((unsigned)n, M);
+      double *row = table + roff - 2;  // row[c] is column c
+      double y[C];
+#pragma unroll
+      for (int i = 0; i < C; i++) y[i] = (MODE == STB_MODE_SCALED) ? cell_log(st[i]) : st[i].m;
+      if (c0 + C - 1 <= cmax) {
+        // whole lane inside the row: 16-byte stores (c0-2 is even and the row base is 16B aligned)
+        if (C == 1) {
+          row[c0] = y[0];
+        } else {
+#pragma unroll
+          for (int i = 0; i < C; i += 2)
+            *reinterpret_cast<double2 *>(row + c0 + i) = make_double2(y[i], y[i + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          if (c0 + i <= cmax) row[c0 + i] = y[i];
+      }
+    } else if (MODE != STB_MODE_VRATIO && j == 0) {
+      // strip 0 only: the lane whose last column is column 1 emits S1[n-1] = log S^n_1
+      if (c0 + C - 1 == 1)
+        S1[n - 1] = (MODE == STB_MODE_SCALED) ? cell_log(st[C - 1]) : st[C - 1].m;
+    }
+  }
+
+  // ---- publish row n1 for the next launch: owned columns, plus column 1 from strip 0 ----
+  if (n1 < (int)N) {
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      const bool mine = owned || (j == 0 && c == 1);
+      if (mine && c >= 1 && c <= (int)M) {
+        fm_out[c] = st[i].m;
+        if (MODE == STB_MODE_SCALED) fe_out[c] = st[i].e;
+      }
+    }
+  }
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static unsigned frontier_pitch(unsigned M) { return (unsigned)align_up((size_t)M + 2, 64); }
+
+extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
+  (void)N;
+  size_t W = frontier_pitch(M);
+  return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) + 256;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  if (!s || !*s) return dflt;
+  return atoi(s);
+}
+
+template <int C>
+static void launch_fill(const fill_args &A, int k, dim3 grid, int mode, hipStream_t st) {
+  if (mode == STB_MODE_LOGDOM)
+    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_LOGDOM>), grid, dim3(64), 0, st, A, k);
+  else if (mode == STB_MODE_VRATIO)
+    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_VRATIO>), grid, dim3(64), 0, st, A, k);
+  else
+    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_SCALED>), grid, dim3(64), 0, st, A, k);
+}
+
+static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
+                       uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
+                       size_t ws_bytes, int mode, hipStream_t st) {
+  const char *who = (mode == STB_MODE_VRATIO) ? "stb_fill_V" : "stb_fill_S";
+  if (D < 1) return fail("%s: D=%d", who, D);
+  if (N < 2 || M < 2) return fail("%s: bounds N=%u M=%u too small", who, N, M);
+  if (!a_host || !d_tables || !d_ws || (mode != STB_MODE_VRATIO && !d_S1))
+    return fail("%s: null pointer", who);
+  if (ws_bytes < stb_fill_workspace_bytes(N, M, D))
+    return fail("%s: workspace %zu < %zu", who, ws_bytes, stb_fill_workspace_bytes(N, M, D));
+  const uint64_t need = (mode == STB_MODE_VRATIO) ? stb_vtable_elems(N, M) : stb_table_elems(N, M);
+  if (D > 1 && (table_stride < need || (mode != STB_MODE_VRATIO && s1_stride < N)))
+    return fail("%s: strides too small", who);
+  if (D > 1 && (table_stride & 1)) return fail("%s: table stride must be even", who);
+  for (int d = 0; d < D; d++)
+    if (!(a_host[d] >= 0.0 && a_host[d] < 1.0))
+      return fail("%s: discount %g outside [0,1)", who, a_host[d]);
+
+  // tunables: columns per lane and rows per launch
+  int C = env_int("STB_FILL_C", 2);
+  int R = env_int("STB_FILL_R", 32);
+  if (C != 1 && C != 2 && C != 4) return fail("STB_FILL_C must be 1, 2 or 4");
+  if (R < 1) R = 1;
+  int H = (R + C - 1) / C * C;
+  if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
+
+  fill_args A;
+  char *ws = (char *)d_ws;
+  A.a = (const double *)ws;
+  ws += align_up((size_t)D * sizeof(double), 256);
+  A.W = frontier_pitch(M);
+  A.fm = (double *)ws;
+  ws += (size_t)D * 2 * A.W * sizeof(double);
+  A.fe = (int *)ws;
+  A.tables = d_tables;
+  A.tstride = table_stride;
+  A.S1 = d_S1;
+  A.s1stride = s1_stride;
+  A.N = N;
+  A.M = M;
+  A.R = R;
+  A.H = H;
+  A.Wv = 64 * C - H;
+  HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+
+  const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  for (int k = 0; k < nlaunch; k++) {
+    int n1 = 2 + (k + 1) * R - 1;
+    if (n1 > (int)N) n1 = (int)N;
+    int ncols = (n1 < (int)M ? n1 : (int)M) - 1;  // owned columns 2..min(n1,M)
+    if (ncols < 1) ncols = 1;
+    int strips = (ncols + A.Wv - 1) / A.Wv;
+    dim3 grid(strips, D);
+    switch (C) {
+      case 1: launch_fill<1>(A, k, grid, mode, st); break;
+      case 2: launch_fill<2>(A, k, grid, mode, st); break;
+      default: launch_fill<4>(A, k, grid, mode, st); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stb_default_variant(void) {
+  return env_int("STB_FILL_VARIANT", STB_FILL_SCALED) == STB_FILL_LOGDOMAIN ? STB_FILL_LOGDOMAIN
+                                                                            : STB_FILL_SCALED;
+}
+
+extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
+                          uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
+                          size_t ws_bytes, int variant, void *stream) {
+  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes,
+                     variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM : STB_MODE_SCALED,
+                     (hipStream_t)stream);
+}
+
+extern "C" int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
+                          uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream) {
+  return fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes,
+                     STB_MODE_VRATIO, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lookups with S_S semantics
+
+__device__ __forceinline__ double dev_S_S(const double *table, const double *S1, unsigned N,
+                                          unsigned M, unsigned n, unsigned m) {
+  // test order of lib/stable.c:941-974 for a table that cannot grow
+  if (n == m) return 0.0;
+  if (m == 1) return (n >= 1 && n <= N) ? S1[n - 1] : -HUGE_VAL;
+  if (n < m || m == 0) return -HUGE_VAL;
+  if (m > M || n > N) return -HUGE_VAL;
+  return table[stb_row_offset(n, M) + (m - 2)];
+}
+
+__global__ void k_lookup(const double *table, const double *S1, unsigned N, unsigned M,
+                         const uint32_t *n, const uint32_t *m, uint64_t G, double *out) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < G; g += step) out[g] = dev_S_S(table, S1, N, M, n[g], m[g]);
+}
+
+extern "C" int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
+                            const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
+                            void *stream) {
+  if (G == 0) return 0;
+  uint64_t blocks = (G + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_lookup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_table,
+                     d_S1, N, M, d_n, d_m, G, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic double-double reductions
+
+struct dd_t {
+  double hi, lo;
+};
+
+__device__ __forceinline__ void dd_add(dd_t &s, double x) {
+  double t = s.hi + x;
+  if (isfinite(t)) {
+    double bb = t - s.hi;
+    s.lo += (s.hi - (t - bb)) + (x - bb);
+  }
+  s.hi = t;
+}
+__device__ __forceinline__ void dd_merge(dd_t &s, dd_t o) {
+  dd_add(s, o.hi);
+  s.lo += o.lo;
+}
+
+// reduce one dd per thread over a 256-thread block in a fixed order; result valid in thread 0
+__device__ __forceinline__ dd_t block_reduce_dd(dd_t v, dd_t *lds /* [4] */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    dd_t o;
+    o.hi = __shfl_down(v.hi, off, 64);
+    o.lo = __shfl_down(v.lo, off, 64);
+    dd_merge(v, o);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) dd_merge(v, lds[w]);
+  }
+  __syncthreads();
+  return v;
+}
+
+// second stage: out[d] = base[d] + sum_b partial[d][b], one block per d, fixed order
+__global__ __launch_bounds__(256) void k_reduce_final(const dd_t *partial, int nb, double *out,
+                                                      const double *base) {
+  __shared__ dd_t lds[4];
+  const int d = blockIdx.x;
+  dd_t v{0.0, 0.0};
+  for (int b = threadIdx.x; b < nb; b += 256) dd_merge(v, partial[(size_t)d * nb + b]);
+  v = block_reduce_dd(v, lds);
+  if (threadIdx.x == 0) {
+    if (base) dd_add(v, base[d]);
+    out[d] = v.hi + v.lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: sweep.  Each block takes a contiguous chunk of pairs and DT discounts; the (n,t) pair is read
+// once per DT tables, the row offset computed once, and DT gathers issued.
+
+#define STB_SWEEP_DT 8
+#define STB_SWEEP_CHUNK 4096
+
+__global__ __launch_bounds__(256) void k_sweep_partial(const double *tables, uint64_t tstride,
+                                                       const double *S1, uint64_t s1stride, int D,
+                                                       unsigned N, unsigned M, const uint32_t *n,
+                                                       const uint16_t *t, uint64_t G, dd_t *partial,
+                                                       int nb) {
+  __shared__ dd_t lds[4];
+  const int d0 = blockIdx.y * STB_SWEEP_DT;
+  const uint64_t g0 = (uint64_t)blockIdx.x * STB_SWEEP_CHUNK;
+  const uint64_t g1 = (g0 + STB_SWEEP_CHUNK < G) ? g0 + STB_SWEEP_CHUNK : G;
+  dd_t acc[STB_SWEEP_DT];
+#pragma unroll
+  for (int q = 0; q < STB_SWEEP_DT; q++) acc[q] = dd_t{0.0, 0.0};
+  for (uint64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+    const unsigned nn = n[g], tt = t[g];
+    if (nn <= 1) continue;  // lib/samplea.c:78: only n>1 contributes
+    // classify once (lib/stable.c:944-949), then the gather differs per table only by base
+    int kind;  // 0: zero, 1: S1, 2: -inf, 3: table
+    uint64_t off = 0;
+    if (nn == tt) kind = 0;
+    else if (tt == 1) kind = (nn <= N) ? 1 : 2;
+    else if (nn < tt || tt == 0) kind = 2;
+    else if (tt > M || nn > N) kind = 2;
+    else {
+      kind = 3;
+      off = stb_row_offset(nn, M) + (tt - 2);
+    }
+#pragma unroll
+    for (int q = 0; q < STB_SWEEP_DT; q++) {
+      const int d = d0 + q;
+      if (d < D) {
+        double v;
+        if (kind == 3) v = tables[(uint64_t)d * tstride + off];
+        else if (kind == 1) v = S1[(uint64_t)d * s1stride + nn - 1];
+        else v = (kind == 0) ? 0.0 : -HUGE_VAL;
+        dd_add(acc[q], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < STB_SWEEP_DT; q++) {
+    dd_t r = block_reduce_dd(acc[q], lds);
+    if (threadIdx.x == 0 && d0 + q < D) partial[(size_t)(d0 + q) * nb + blockIdx.x] = r;
+  }
+}
+
+static int sweep_blocks(uint64_t G) { return (int)((G + STB_SWEEP_CHUNK - 1) / STB_SWEEP_CHUNK); }
+
+extern "C" size_t stb_sweep_workspace_bytes(uint64_t G, int D) {
+  int nb = sweep_blocks(G);
+  if (nb < 1) nb = 1;
+  return (size_t)D * nb * sizeof(dd_t) + 256;
+}
+
+extern "C" int stb_sweep_S(const double *d_tables, uint64_t table_stride, const double *d_S1,
+                           uint64_t s1_stride, int D, unsigned N, unsigned M, const uint32_t *d_n,
+                           const uint16_t *d_t, uint64_t G, double *d_out, void *d_ws,
+                           size_t ws_bytes, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (D < 1) return fail("stb_sweep_S: D=%d", D);
+  if (ws_bytes < stb_sweep_workspace_bytes(G, D)) return fail("stb_sweep_S: workspace too small");
+  int nb = sweep_blocks(G);
+  dd_t *partial = (dd_t *)d_ws;
+  if (nb == 0) {
+    HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * D, st));
+    return 0;
+  }
+  dim3 grid(nb, (D + STB_SWEEP_DT - 1) / STB_SWEEP_DT);
+  hipLaunchKernelGGL(k_sweep_partial, grid, dim3(256), 0, st, d_tables, table_stride, d_S1,
+                     s1_stride, D, N, M, d_n, d_t, G, partial, nb);
+  hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, st, partial, nb, d_out,
+                     (const double *)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-restaurant terms
+
+#define STB_TERMS_CHUNK 2048
+#define STB_TERMS_DMAX 64
+
+struct terms_args {
+  double x[STB_TERMS_DMAX];  // abscissae
+  double p[STB_TERMS_DMAX];  // restaurant: log(x) ; bterms: lgamma(x/apar)
+  double q[STB_TERMS_DMAX];  // bterms: x/apar
+  int D;
+  int mode;  // 0 restaurant (aterms head), 1 bterms
+};
+
+__global__ __launch_bounds__(256) void k_terms_partial(terms_args A, const uint32_t *T,
+                                                       const double *bpar, uint64_t I, dd_t *partial,
+                                                       int nb) {
+  __shared__ dd_t lds[4];
+  const uint64_t i0 = (uint64_t)blockIdx.x * STB_TERMS_CHUNK;
+  const uint64_t i1 = (i0 + STB_TERMS_CHUNK < I) ? i0 + STB_TERMS_CHUNK : I;
+  const int d = blockIdx.y;
+  dd_t acc{0.0, 0.0};
+  if (A.mode == 0) {
+    const double x = A.x[d], lx = A.p[d];
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+#pragma clang fp contract(off)
+      // lib/samplea.c:66-67: T*log(x) + lgamma(T + b/x) - lgamma(b/x), association as written
+      const double Ti = (double)T[i];
+      const double bx = bpar[i] / x;
+      const double term = (Ti * lx + lgamma(Ti + bx)) - lgamma(bx);
+      dd_add(acc, term);
+    }
+  } else {
+    const double lg = A.p[d], xa = A.q[d];
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      // lib/sampleb.c:38-39: lgamma(T + x/a) - lgamma(x/a)
+      dd_add(acc, lgamma((double)T[i] + xa) - lg);
+  }
+  dd_t r = block_reduce_dd(acc, lds);
+  if (threadIdx.x == 0) partial[(size_t)d * nb + blockIdx.x] = r;
+}
+
+static int terms_blocks(uint64_t I) { return (int)((I + STB_TERMS_CHUNK - 1) / STB_TERMS_CHUNK); }
+
+extern "C" size_t stb_terms_workspace_bytes(uint64_t I, int D) {
+  int nb = terms_blocks(I);
+  if (nb < 1) nb = 1;
+  return (size_t)D * nb * sizeof(dd_t) + (size_t)D * sizeof(double) + 512;
+}
+
+static int run_terms(terms_args &A, const double *base_host, const uint32_t *d_T,
+                     const double *d_bpar, uint64_t I, double *d_out, void *d_ws, size_t ws_bytes,
+                     hipStream_t st) {
+  const int D = A.D;
+  if (ws_bytes < stb_terms_workspace_bytes(I, D)) return fail("terms: workspace too small");
+  int nb = terms_blocks(I);
+  double *d_base = (double *)d_ws;
+  dd_t *partial = (dd_t *)((char *)d_ws + align_up((size_t)D * sizeof(double), 256));
+  if (base_host)
+    HIPCHK(hipMemcpyAsync(d_base, base_host, sizeof(double) * D, hipMemcpyHostToDevice, st));
+  if (nb == 0) {
+    if (base_host)
+      HIPCHK(hipMemcpyAsync(d_out, d_base, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+    else
+      HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * D, st));
+    return 0;
+  }
+  hipLaunchKernelGGL(k_terms_partial, dim3(nb, D), dim3(256), 0, st, A, d_T, d_bpar, I, partial, nb);
+  hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, st, partial, nb, d_out,
+                     base_host ? (const double *)d_base : (const double *)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stb_restaurant_terms(const double *x_host, int D, const uint32_t *d_T,
+                                    const double *d_bpar, uint64_t I, double *d_out, void *d_ws,
+                                    size_t ws_bytes, void *stream) {
+  if (D < 1 || D > STB_TERMS_DMAX) return fail("stb_restaurant_terms: D=%d (max %d)", D, STB_TERMS_DMAX);
+  terms_args A;
+  memset(&A, 0, sizeof(A));
+  A.D = D;
+  A.mode = 0;
+  for (int d = 0; d < D; d++) {
+    if (!(x_host[d] > 0)) return fail("stb_restaurant_terms: x=%g", x_host[d]);
+    A.x[d] = x_host[d];
+    A.p[d] = log(x_host[d]);  // host libm: one scalar per abscissa, same call as samplea.c:66
+  }
+  return run_terms(A, nullptr, d_T, d_bpar, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
+                          const uint32_t *d_T, uint64_t I, double *d_out, void *d_ws,
+                          size_t ws_bytes, void *stream) {
+  if (J < 1 || J > STB_TERMS_DMAX) return fail("stb_bterms: J=%d (max %d)", J, STB_TERMS_DMAX);
+  if (!(apar > 0)) return fail("stb_bterms: apar=%g", apar);
+  terms_args A;
+  double base[STB_TERMS_DMAX];
+  memset(&A, 0, sizeof(A));
+  A.D = J;
+  A.mode = 1;
+  for (int j = 0; j < J; j++) {
+    if (!(x_host[j] > 0)) return fail("stb_bterms: x=%g", x_host[j]);
+    A.x[j] = x_host[j];
+    A.q[j] = x_host[j] / apar;
+    A.p[j] = lgamma(A.q[j]);                                   // lib/sampleb.c:36
+    base[j] = -Q * x_host[j] + (shape - 1) * log(x_host[j]);   // lib/sampleb.c:37
+  }
+  return run_terms(A, base, d_T, nullptr, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident group set
+
+struct stb_groups {
+  int I;
+  uint64_t G;
+  unsigned N, M;
+  int Dmax;
+  uint32_t *d_n, *d_T;
+  uint16_t *d_t;
+  double *d_bpar;
+  double *d_tables, *d_S1, *d_out;  // d_out: [2][Dmax]
+  uint64_t tstride;
+  void *d_ws_fill, *d_ws_sweep, *d_ws_terms;
+  size_t ws_fill, ws_sweep, ws_terms;
+  hipStream_t st;
+  hipEvent_t ev[4];
+};
+
+extern "C" void stb_groups_free(stb_groups_t *g) {
+  if (!g) return;
+  void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
+                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto &e : g->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (g->st) (void)hipStreamDestroy(g->st);
+  free(g);
+}
+
+#define GCHK(expr)                                                                            \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);        \
+      stb_groups_free(g);                                                                     \
+      return nullptr;                                                                         \
+    }                                                                                         \
+  } while (0)
+
+extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T,
+                                           const uint32_t *nflat, const uint16_t *tflat,
+                                           const double *bpar, unsigned N, unsigned M, int Dmax) {
+  if (stb_device_count() < 1) {
+    fail("stb_groups_create: no HIP device (libstb_amd has no CPU path)");
+    return nullptr;
+  }
+  if (Dmax < 1 || Dmax > STB_TERMS_DMAX) {
+    fail("stb_groups_create: Dmax=%d (1..%d)", Dmax, STB_TERMS_DMAX);
+    return nullptr;
+  }
+  stb_groups_t *g = (stb_groups_t *)calloc(1, sizeof(*g));
+  if (!g) {
+    fail("stb_groups_create: out of host memory");
+    return nullptr;
+  }
+  uint64_t G = 0;
+  for (int i = 0; i < I; i++) G += (uint64_t)(K[i] > 0 ? K[i] : 0);
+  g->I = I;
+  g->G = G;
+  g->N = N;
+  g->M = M;
+  g->Dmax = Dmax;
+  g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
+  GCHK(hipStreamCreate(&g->st));
+  for (auto &e : g->ev) GCHK(hipEventCreate(&e));
+  GCHK(hipMalloc(&g->d_n, sizeof(uint32_t) * (G ? G : 1)));
+  GCHK(hipMalloc(&g->d_t, sizeof(uint16_t) * (G ? G : 1)));
+  GCHK(hipMalloc(&g->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)));
+  GCHK(hipMalloc(&g->d_bpar, sizeof(double) * (I > 0 ? I : 1)));
+  GCHK(hipMalloc(&g->d_tables, sizeof(double) * g->tstride * Dmax));
+  GCHK(hipMalloc(&g->d_S1, sizeof(double) * (size_t)N * Dmax));
+  GCHK(hipMalloc(&g->d_out, sizeof(double) * 2 * Dmax));
+  g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
+  g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
+  g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
+  GCHK(hipMalloc(&g->d_ws_fill, g->ws_fill));
+  GCHK(hipMalloc(&g->d_ws_sweep, g->ws_sweep));
+  GCHK(hipMalloc(&g->d_ws_terms, g->ws_terms));
+  if (G) {
+    GCHK(hipMemcpy(g->d_n, nflat, sizeof(uint32_t) * G, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(g->d_t, tflat, sizeof(uint16_t) * G, hipMemcpyHostToDevice));
+  }
+  if (I > 0) {
+    GCHK(hipMemcpy(g->d_T, T, sizeof(uint32_t) * I, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(g->d_bpar, bpar, sizeof(double) * I, hipMemcpyHostToDevice));
+  }
+  return g;
+}
+
+extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D,
+                                       double *out_host, float *ms_fill, float *ms_sweep,
+                                       float *ms_terms) {
+  if (!g) return fail("stb_groups_aterms: null group set");
+  if (D < 1 || D > g->Dmax) return fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
+  double h[2 * STB_TERMS_DMAX];
+  HIPCHK(hipEventRecord(g->ev[0], g->st));
+  if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
+                 g->ws_fill, stb_default_variant(), g->st))
+    return 1;
+  HIPCHK(hipEventRecord(g->ev[1], g->st));
+  if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
+                  g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+    return 1;
+  HIPCHK(hipEventRecord(g->ev[2], g->st));
+  if (stb_restaurant_terms(x_host, D, g->d_T, g->d_bpar, (uint64_t)g->I, g->d_out + g->Dmax,
+                           g->d_ws_terms, g->ws_terms, g->st))
+    return 1;
+  HIPCHK(hipEventRecord(g->ev[3], g->st));
+  HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * 2 * g->Dmax, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  for (int d = 0; d < D; d++) out_host[d] = h[g->Dmax + d] + h[d];
+  if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
+  if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));
+  if (ms_terms) HIPCHK(hipEventElapsedTime(ms_terms, g->ev[2], g->ev[3]));
+  return 0;
+}
+
+extern "C" int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host) {
+  return stb_groups_aterms_timed(g, x_host, D, out_host, nullptr, nullptr, nullptr);
+}

@@ -1,0 +1,141 @@
+"""GPU parity: the HIP table fill (K1/K2) through the C ABI against the CPU oracle and the golden
+fixtures dumped from the reference.  Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+fh = float.fromhex
+TOL = 1e-10
+
+
+def test_library_sees_gpu():
+    L = capi.lib()
+    assert L.stb_device_count() >= 1, capi.last_error()
+
+
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN])
+def test_small_tables_batched_vs_golden(golden_dir, variant):
+    """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
+    z = np.load(os.path.join(golden_dir, "stable_200x50.npz"))
+    keys = ["a0.5", "a0.125", "a0.05", "a0.95", "a2_3"]
+    a = np.array([float(z[k + "_a"][0]) for k in keys])
+    T = capi.DeviceTables(200, 50, D=len(keys))
+    T.fill(a, variant)
+    for d, k in enumerate(keys):
+        got = T.packed_host(d)
+        assert got.shape[0] == 8526
+        assert orc.close(got, z[k + "_table"], TOL), (k, orc.max_err(got, z[k + "_table"]))
+        assert orc.close(T.S1[d].cpu().numpy(), z[k + "_S1"], TOL)
+
+
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN])
+@pytest.mark.parametrize("N,M", [(2, 2), (3, 2), (3, 3), (10, 10), (64, 64), (65, 33), (97, 96), (130, 129), (500, 7),
+                                 (1000, 1000), (1500, 260)])
+def test_ragged_shapes_vs_oracle(N, M, variant):
+    """edge shapes: tiny, one strip / several strips, diagonal inside a strip, M << N"""
+    a = np.array([0.31, 0.77])
+    T = capi.DeviceTables(N, M, D=2)
+    T.fill(a, variant)
+    for d in range(2):
+        S1, tab = orc.fill_S(a[d], N, M)
+        got = T.packed_host(d)
+        assert orc.close(got, tab, TOL), (N, M, orc.max_err(got, tab))
+        assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
+
+
+@pytest.mark.parametrize("C,R", [(1, 16), (1, 60), (2, 32), (2, 7), (4, 32), (4, 128)])
+def test_tunings_agree(monkeypatch, C, R):
+    """every (columns-per-lane, rows-per-launch) tuning computes the same table"""
+    monkeypatch.setenv("STB_FILL_C", str(C))
+    monkeypatch.setenv("STB_FILL_R", str(R))
+    T = capi.DeviceTables(700, 650, D=1)
+    T.fill([0.5])
+    S1, tab = orc.fill_S(0.5, 700, 650)
+    assert orc.close(T.packed_host(0), tab, TOL)
+    assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
+
+
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN])
+@pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
+def test_4000_full_table_vs_oracle(golden_dir, a, variant):
+    N = 4000
+    T = capi.DeviceTables(N, N, D=1)
+    T.fill([a], variant)
+    S1, tab = orc.fill_S(a, N, N)
+    got = T.packed_host(0)
+    err = orc.max_err(got, tab)
+    assert err <= TOL, err
+    assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
+    z = np.load(os.path.join(golden_dir, "stable_big.npz"))
+    key = f"N{N}_a{a}"
+    o = orc.row_offset(N, N)
+    assert orc.close(got[o:o + N - 2], z[key + f"_row{N}"], TOL)
+
+
+@pytest.mark.parametrize("a", [0.5, 0.07, 0.93])
+def test_10000_config2_vs_golden(golden_dir, a):
+    """configs[1]: single-discount N=M=10000 -- every row's sum, two full rows, sparse probes."""
+    N = 10000
+    T = capi.DeviceTables(N, N, D=1)
+    T.fill([a])
+    z = np.load(os.path.join(golden_dir, "stable_big.npz"))
+    key = f"N{N}_a{a}"
+    t = T.tables[0].cpu().numpy()
+    rowsum = np.zeros(N + 1)
+    absmax = np.zeros(N + 1)
+    for n in range(3, N + 1):
+        o = T.rowoff(n)
+        r = t[o:o + n - 2]
+        rowsum[n] = np.sum(r)
+        absmax[n] = (n - 2) * max(1.0, np.max(np.abs(r)))
+    want = z[key + "_rowsum"]
+    assert np.all(np.abs(rowsum - want) <= TOL * np.maximum(absmax, 1.0))
+    for n in (N // 3, N):
+        o = T.rowoff(n)
+        assert orc.close(t[o:o + n - 2], z[key + f"_row{n}"], TOL)
+    assert orc.close(T.S1[0].cpu().numpy(), z[key + "_S1"], TOL)
+    with open(os.path.join(golden_dir, "stable_probes.json")) as f:
+        probes = [p for p in json.load(f) if p["N"] == N and fh(p["a"]) == a]
+    assert len(probes) > 40
+    got = T.lookup([p["n"] for p in probes], [p["m"] for p in probes])
+    assert orc.close(got, [fh(p["S"]) for p in probes], TOL)
+
+
+def test_10000_round_trip_property():
+    """size-independent property at full size: the last row satisfies the recurrence
+    S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1} in the log domain, row by row sampled."""
+    N, a = 10000, 0.5
+    T = capi.DeviceTables(N, N, D=1)
+    T.fill([a])
+    t = T.tables[0].cpu().numpy()
+    for n in (4, 57, 1000, 5001, 10000):
+        cur = t[T.rowoff(n):T.rowoff(n) + n - 2]          # m = 2..n-1
+        prv = t[T.rowoff(n - 1):T.rowoff(n - 1) + n - 3]  # m = 2..n-2
+        m = np.arange(3, n - 1)                            # interior columns
+        up = prv[m - 2]
+        left = prv[m - 3]
+        want = np.logaddexp(np.log(n - 1 - m * a) + up, left)
+        assert orc.close(cur[m - 2], want, 1e-12)
+
+
+def test_v_table_bit_exact(golden_dir):
+    """V ratios are plain mul/div in the reference's order: expect equality to the last bit."""
+    z = np.load(os.path.join(golden_dir, "uv_200x50.npz"))
+    T = capi.DeviceVTables(200, 50, D=3)
+    T.fill([0.5, 0.05, 0.95])
+    for d, key in enumerate(("a0.5", "a0.05", "a0.95")):
+        got = T.packed_host(d)
+        assert np.array_equal(got, z[key + "_V"]), orc.max_err(got, z[key + "_V"])
+
+
+def test_v_table_big_vs_oracle():
+    T = capi.DeviceVTables(3000, 1200, D=1)
+    T.fill([0.4])
+    want = orc.fill_V(0.4, 3000, 1200)
+    assert np.array_equal(T.packed_host(0), want)
