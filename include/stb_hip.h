@@ -55,15 +55,22 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
  * d_tables             D slabs of stb_elems(N,M) doubles, slab d at d_tables + d*table_stride
  * d_S1                 D vectors of N doubles (S1[n-1] = log S^n_{1,a}), vector d at + d*s1_stride
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
- * variant              STB_FILL_SCALED (default) or STB_FILL_LOGDOMAIN
+ * variant              STB_FILL_SCALED (default), STB_FILL_LOGDOMAIN or STB_FILL_SCALED_STEP
  */
-#define STB_FILL_SCALED 0    /* recurrence carried as (mantissa, exponent); log taken on output */
-#define STB_FILL_LOGDOMAIN 1 /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
+#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log on output */
+#define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
+#define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
                int variant, void *stream);
+/* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches */
+int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
+/* kernel-only timing of the fills issued by THIS thread between begin and end (the stream must be
+ * synchronised before _end): sum of the per-launch device durations in ms and their count */
+void stb_fill_profile_begin(void);
+int stb_fill_profile_end(double *kernel_ms_total, int *launches);
 /* V tables (next row 8f-1): V^n_m for 2<=n<=N, 2<=m<=min(n,M); lib/stable.c:451-482 */
 int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
                uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstb_amd.so")
 
 # flag bits of include/stable.h
 S_STABLE, S_UVTABLE, S_FLOAT, S_VERBOSE, S_QUITONBOUND, S_THREADS, S_ASYMPT = 1, 2, 4, 8, 16, 32, 64
-FILL_SCALED, FILL_LOGDOMAIN = 0, 1
+FILL_SCALED, FILL_LOGDOMAIN, FILL_SCALED_STEP = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
     sig("stb_fill_workspace_bytes", sz, [u, u, i])
     sig("stb_default_variant", i, [])
     sig("stb_fill_S", i, [c_double_p, i, u, u, vp, u64, vp, u64, vp, sz, i, vp])
+    sig("stb_fill_tuning", i, [u, u, i, c_int_p, c_int_p, c_int_p])
+    sig("stb_fill_profile_begin", None, [])
+    sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
     sig("stb_lookup_S", i, [vp, vp, u, u, vp, vp, u64, vp, vp])
     sig("stb_sweep_workspace_bytes", sz, [u64, i])

@@ -19,6 +19,7 @@
 // No CPU fallback exists in this file: without a device every entry point fails with a message.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -348,6 +349,280 @@ __global__ __launch_bounds__(64) void k_fill_rows(fill_args A, int k) {
   }
 }
 
+// ---- block-floating variant of the scaled fill (the default) --------------------------------
+//
+// Same recurrence in the linear domain, but a cell is (v, ep) with true value v * 2^ep where ep is
+// FROZEN for P consecutive rows: inside a period the update is  v <- (n-1 - c a) v + v_left * s,
+// s = 2^(ep_left - ep) fixed per period, i.e. one add, one multiply and one fma per cell and row.
+// v starts each period at 2^-BFP_BIAS * [0.5,1) and can only grow by the coefficient (< 2N) per
+// row, so P rows never overflow; at the period end every cell is renormalised with frexp.
+// The log that is stored is taken from the bits of v: exponent field + 7 leading mantissa bits
+// index a 128-entry table {1/c, -log(1/c)} held in LDS, then a degree-6 polynomial in
+// r = z/c - 1, |r| < 2^-8 (the construction used by table-driven libm logs).  Absolute error of
+// the log is a few 1e-16, far inside the 1e-10 parity bound.
+#define BFP_BIAS 512
+
+__device__ double2 g_logtab[128];  // {invc, logc}; written by the host once per device
+
+__device__ __forceinline__ double bfp_log(double v, int ep, const double2 *lt) {
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const int hi = __double2hiint(v), lo = __double2loint(v);
+  const int kexp = ((hi >> 20) & 0x7ff) - 1023;
+  const int idx = (hi >> 13) & 127;
+  const double z = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);  // [1,2)
+  const double2 t = lt[idx];
+  const double r = fma(z, t.x, -1.0);
+  double p = fma(r, -1.0 / 6.0, 0.2);
+  p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  const double kf = (double)(kexp + ep);
+  return fma(kf, LN2_HI, fma(kf, LN2_LO, fma(r, p, t.y)));
+}
+
+// keep a value live at this point of the instruction stream (stops hipcc from sinking the log
+// into the divergent store branches, which would serialise it behind the recurrence step)
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
+// emit one finished row: S1 from the lane that holds column 1 of strip 0, table values from owned
+// lanes, 16 bytes per lane when the whole lane lies inside the row
+template <int C>
+__device__ __forceinline__ void bfp_store_row(const double (&y)[C], double *row, double *S1, int n,
+                                              int c0, int cmax, bool owned, bool s1lane) {
+  if (owned) {
+    if (c0 + C - 1 <= cmax) {
+      if (C == 1) {
+        row[c0] = y[0];
+      } else {
+#pragma unroll
+        for (int i = 0; i < C; i += 2)
+          *reinterpret_cast<double2 *>(row + c0 + i) = make_double2(y[i], y[i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if (c0 + i <= cmax) row[c0 + i] = y[i];
+    }
+  } else if (s1lane) {
+    S1[n - 1] = y[C - 1];
+  }
+}
+
+// U consecutive rows for this lane's C columns.  The U recurrence steps are a short dependent
+// chain (DPP shift, multiply, fma).  The U*C logs that follow are written stage-major -- all table
+// reads, then stage 1 of every polynomial, then stage 2, ... -- so that the in-order wave always has
+// an independent instruction to issue while a previous fma or LDS read is still in flight (there
+// are only one or two waves per SIMD when few tables are being filled, so instruction-level
+// parallelism is what hides latency here, not occupancy).
+template <int C, int U>
+__device__ __forceinline__ void bfp_rows(double (&v)[C], const double (&ca)[C], const double (&s)[C],
+                                         const int (&ep)[C], int n, const double2 *lt, double *table,
+                                         uint64_t &roff, double *S1, unsigned M, int c0, int clast,
+                                         bool owned, bool s1lane) {
+  constexpr int Q = U * C;
+  double x[Q];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const double lfv = wave_shr1(v[C - 1], 0.0);
+    const double nm1 = (double)(n + u - 1);
+#pragma unroll
+    for (int i = C - 1; i >= 0; i--) {
+      const double lf = (i > 0) ? v[i - 1] : lfv;
+      v[i] = fma(nm1 - ca[i], v[i], lf * s[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < C; i++) x[u * C + i] = v[i];
+  }
+  // ---- y = log(x 2^ep): exponent field + 7 mantissa bits -> table, degree-6 polynomial in r ----
+  double2 t[Q];
+  double z[Q], kf[Q], r[Q], pl[Q], y[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) t[q] = lt[(__double2hiint(x[q]) >> 13) & 127];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int hi = __double2hiint(x[q]);
+    z[q] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[q]));
+    kf[q] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + ep[q % C]);
+  }
+#pragma unroll
+  for (int q = 0; q < Q; q++) r[q] = fma(z[q], t[q].x, -1.0);
+#pragma unroll
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], -1.0 / 6.0, 0.2);
+#pragma unroll
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], -0.25);
+#pragma unroll
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], 1.0 / 3.0);
+#pragma unroll
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], -0.5);
+#pragma unroll
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], 1.0);
+#pragma unroll
+  for (int q = 0; q < Q; q++) y[q] = fma(kf[q], 0.693147180559945309417, fma(r[q], pl[q], t[q].y));
+#pragma unroll
+  for (int q = 0; q < Q; q++) pin(y[q]);
+
+  // ---- emit the U rows ----
+  if (clast <= min(n - 1, (int)M)) {
+    // every owned column of this wave is inside all U rows (the common case): no per-row tests
+    if (owned) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        double *row = table + roff - 2;
+        if (C == 1) {
+          row[c0] = y[u];
+        } else {
+#pragma unroll
+          for (int i = 0; i < C; i += 2)
+            *reinterpret_cast<double2 *>(row + c0 + i) = make_double2(y[u * C + i], y[u * C + i + 1]);
+        }
+        roff += (stb_row_len((unsigned)(n + u), M) + 1) & ~1u;
+      }
+    } else {
+      if (s1lane) {
+#pragma unroll
+        for (int u = 0; u < U; u++) S1[n + u - 1] = y[u * C + C - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) roff += (stb_row_len((unsigned)(n + u), M) + 1) & ~1u;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int rr = n + u;
+      double yy[C];
+#pragma unroll
+      for (int i = 0; i < C; i++) yy[i] = y[u * C + i];
+      bfp_store_row<C>(yy, table + roff - 2, S1, rr, c0, min(rr - 1, (int)M), owned, s1lane);
+      roff += (stb_row_len((unsigned)rr, M) + 1) & ~1u;
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_fill_bfp(fill_args A, int k, int P) {
+  __shared__ double2 lt[128];
+  const int lane = threadIdx.x;
+  lt[lane] = g_logtab[lane];
+  lt[lane + 64] = g_logtab[lane + 64];
+  __syncthreads();
+
+  const int j = blockIdx.x;
+  const int d = blockIdx.y;
+  const double a = A.a[d];
+  const unsigned N = A.N, M = A.M;
+  const int n0 = 2 + k * A.R;
+  const int n1 = min((int)N, n0 + A.R - 1);
+  const int nf = n0 - 1;
+  const int c0 = 2 + j * A.Wv - A.H + lane * C;
+  const bool owned = lane * C >= A.H;
+  const bool s1lane = (j == 0) && (c0 + C - 1 == 1);
+  const int clast = 2 + j * A.Wv - A.H + 64 * C - 1;  // last column carried by this wave
+  double *table = A.tables + (uint64_t)d * A.tstride;
+  double *S1 = A.S1 + (uint64_t)d * A.s1stride;
+  const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+  const double *fm_in = A.fm + fbase + (uint64_t)(k & 1) * A.W;
+  const int *fe_in = A.fe + fbase + (uint64_t)(k & 1) * A.W;
+  double *fm_out = A.fm + fbase + (uint64_t)((k + 1) & 1) * A.W;
+  int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
+
+  // ---- row nf: (mantissa, exponent) from the frontier -> (v, ep) ----
+  double v[C], ca[C];
+  int ep[C];
+  const int cmax_f = min(nf, (int)M);
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int c = c0 + i;
+    double m = 0.0;
+    int e = 1;
+    if (k == 0) {
+      if (c == 1) m = 0.5;  // S^1_1 = 1 = 0.5 * 2^1
+    } else if (c >= 1 && c <= cmax_f) {
+      m = fm_in[c];
+      e = fe_in[c];
+    }
+    v[i] = ldexp(m, -BFP_BIAS);
+    ep[i] = e + BFP_BIAS;
+    ca[i] = (double)c * a;
+  }
+  if (k == 0 && j == 0 && lane == 0) S1[0] = 0.0;  // log S^1_1
+
+  uint64_t roff = stb_row_offset((unsigned)n0, M);  // element offset of the next row to emit
+
+  for (int nb = n0; nb <= n1; nb += P) {
+    const int ne = min(n1, nb + P - 1);
+    // ---- period set-up: freeze exponents, derive the per-cell scale of the left input ----
+    double s[C];
+    {
+      // a cell far below its left neighbour (or an exact zero) adopts the neighbour's exponent so
+      // that s stays <= 2^64
+      int epl = wave_shr1(ep[C - 1], ep[0]);
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int el = (i > 0) ? ep[i - 1] : epl;
+        const int mine = ep[i];
+        if (el > mine + 64 || v[i] == 0.0) {
+          v[i] = ldexp(v[i], mine - el);
+          ep[i] = el;
+        }
+      }
+      epl = wave_shr1(ep[C - 1], ep[0]);
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int el = (i > 0) ? ep[i - 1] : epl;
+        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 500));
+      }
+    }
+    // ---- the rows of this period, four at a time ----
+    int n = nb;
+    for (; n + 3 <= ne; n += 4)
+      bfp_rows<C, 4>(v, ca, s, ep, n, lt, table, roff, S1, M, c0, clast, owned, s1lane);
+    for (; n <= ne; n++)
+      bfp_rows<C, 1>(v, ca, s, ep, n, lt, table, roff, S1, M, c0, clast, owned, s1lane);
+    // ---- renormalise ----
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int kx = __builtin_amdgcn_frexp_exp(v[i]);
+      const double m = __builtin_amdgcn_frexp_mant(v[i]);
+      if (v[i] != 0.0) {
+        v[i] = ldexp(m, -BFP_BIAS);
+        ep[i] += kx + BFP_BIAS;
+      }
+    }
+  }
+
+  if (n1 < (int)N) {
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      const bool mine = owned || (j == 0 && c == 1);
+      if (mine && c >= 1 && c <= (int)M) {
+        // back to (mantissa in [0.5,1), exponent): v = m 2^-BIAS, value = v 2^ep
+        fm_out[c] = ldexp(v[i], BFP_BIAS);
+        fe_out[c] = (v[i] != 0.0) ? ep[i] - BFP_BIAS : STB_EZ;
+      }
+    }
+  }
+}
+
+static int ensure_logtab() {
+  static bool done[64] = {false};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail("device index %d out of range", dev);
+  if (done[dev]) return 0;
+  double2 h[128];
+  for (int i = 0; i < 128; i++) {
+    const long double c = 1.0L + ((long double)i + 0.5L) / 128.0L;
+    const double invc = (double)(1.0L / c);
+    h[i].x = invc;
+    h[i].y = (double)(-logl((long double)invc));
+  }
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_logtab), h, sizeof(h)));
+  done[dev] = true;
+  return 0;
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static unsigned frontier_pitch(unsigned M) { return (unsigned)align_up((size_t)M + 2, 64); }
@@ -364,14 +639,81 @@ static int env_int(const char *name, int dflt) {
   return atoi(s);
 }
 
+#define STB_MODE_BFP 3  // S table, block-floating cells + table log (default)
+
+// optional per-launch timing: when armed, every fill kernel is launched with a begin/end event pair
+// (hipExtLaunchKernelGGL stamps them with the dispatch's own start/stop, i.e. what a kernel trace
+// reports), so a caller can obtain the kernel-only time of a fill without a profiler attached.
+struct fill_prof {
+  bool armed = false;
+  int used = 0;
+  hipEvent_t ev[2 * 4096];
+  int made = 0;
+};
+static thread_local fill_prof g_prof;
+
 template <int C>
-static void launch_fill(const fill_args &A, int k, dim3 grid, int mode, hipStream_t st) {
+static void launch_fill(const fill_args &A, int k, dim3 grid, int mode, int P, hipStream_t st) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+    while (g_prof.made < g_prof.used + 2) {
+      if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+      g_prof.made++;
+    }
+    if (g_prof.made >= g_prof.used + 2) {
+      e0 = g_prof.ev[g_prof.used];
+      e1 = g_prof.ev[g_prof.used + 1];
+      g_prof.used += 2;
+    }
+  }
+#define STB_LAUNCH(KERN, ...)                                                          \
+  do {                                                                                  \
+    if (e0)                                                                             \
+      hipExtLaunchKernelGGL(KERN, grid, dim3(64), 0, st, e0, e1, 0, __VA_ARGS__);       \
+    else                                                                                \
+      hipLaunchKernelGGL(KERN, grid, dim3(64), 0, st, __VA_ARGS__);                     \
+  } while (0)
   if (mode == STB_MODE_LOGDOM)
-    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_LOGDOM>), grid, dim3(64), 0, st, A, k);
+    STB_LAUNCH((k_fill_rows<C, STB_MODE_LOGDOM>), A, k);
   else if (mode == STB_MODE_VRATIO)
-    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_VRATIO>), grid, dim3(64), 0, st, A, k);
+    STB_LAUNCH((k_fill_rows<C, STB_MODE_VRATIO>), A, k);
+  else if (mode == STB_MODE_SCALED)
+    STB_LAUNCH((k_fill_rows<C, STB_MODE_SCALED>), A, k);
   else
-    hipLaunchKernelGGL((k_fill_rows<C, STB_MODE_SCALED>), grid, dim3(64), 0, st, A, k);
+    STB_LAUNCH((k_fill_bfp<C>), A, k, P);
+#undef STB_LAUNCH
+}
+
+extern "C" void stb_fill_profile_begin(void) {
+  g_prof.armed = true;
+  g_prof.used = 0;
+}
+
+extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
+  // caller must have synchronised the stream(s) the fills ran on
+  g_prof.armed = false;
+  double tot = 0.0;
+  const int n = g_prof.used / 2;
+  for (int i = 0; i < n; i++) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (kernel_ms_total) *kernel_ms_total = tot;
+  if (launches) *launches = n;
+  g_prof.used = 0;
+  return 0;
+}
+
+extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
+  const bool few = (uint64_t)D * M < 40000;
+  int C = env_int("STB_FILL_C", few ? 1 : 2);
+  int R = env_int("STB_FILL_R", few ? 48 : 64);
+  if (R < 1) R = 1;
+  if (C_out) *C_out = C;
+  if (R_out) *R_out = R;
+  if (launches) *launches = ((int)N - 1 + R - 1) / R;
+  return 0;
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -392,13 +734,28 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     if (!(a_host[d] >= 0.0 && a_host[d] < 1.0))
       return fail("%s: discount %g outside [0,1)", who, a_host[d]);
 
-  // tunables: columns per lane and rows per launch
-  int C = env_int("STB_FILL_C", 2);
-  int R = env_int("STB_FILL_R", 32);
+  // tunables: columns per lane and rows per launch.  Few tables in flight -> the fill is bound by
+  // the latency of one row step, so narrow lanes (C=1); many tables -> throughput, wider lanes.
+  const bool few = (uint64_t)D * M < 40000;
+  int C = env_int("STB_FILL_C", few ? 1 : 2);
+  int R = env_int("STB_FILL_R", few ? 48 : 64);
   if (C != 1 && C != 2 && C != 4) return fail("STB_FILL_C must be 1, 2 or 4");
   if (R < 1) R = 1;
   int H = (R + C - 1) / C * C;
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
+  // rows per renormalisation period: a value grows by < 2N per row; keep P*log2(2N) under ~440 bits
+  int P = 1;
+  if (mode == STB_MODE_BFP) {
+    if (ensure_logtab()) return 1;
+    int bits = 2;
+    while ((1ull << bits) < 2ull * N) bits++;
+    P = 440 / bits;
+    int Penv = env_int("STB_FILL_P", 0);
+    if (Penv > 0 && Penv < P) P = Penv;
+    if (P < 1) P = 1;
+    if (P >= R) P = R;
+    else P = (R + (R + P - 1) / P - 1) / ((R + P - 1) / P);  // equal-length periods inside a launch
+  }
 
   fill_args A;
   char *ws = (char *)d_ws;
@@ -428,9 +785,9 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     int strips = (ncols + A.Wv - 1) / A.Wv;
     dim3 grid(strips, D);
     switch (C) {
-      case 1: launch_fill<1>(A, k, grid, mode, st); break;
-      case 2: launch_fill<2>(A, k, grid, mode, st); break;
-      default: launch_fill<4>(A, k, grid, mode, st); break;
+      case 1: launch_fill<1>(A, k, grid, mode, P, st); break;
+      case 2: launch_fill<2>(A, k, grid, mode, P, st); break;
+      default: launch_fill<4>(A, k, grid, mode, P, st); break;
     }
   }
   HIPCHK(hipGetLastError());
@@ -438,15 +795,17 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 }
 
 extern "C" int stb_default_variant(void) {
-  return env_int("STB_FILL_VARIANT", STB_FILL_SCALED) == STB_FILL_LOGDOMAIN ? STB_FILL_LOGDOMAIN
-                                                                            : STB_FILL_SCALED;
+  const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
+  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP) ? v : STB_FILL_SCALED;
 }
 
 extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                           uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
                           size_t ws_bytes, int variant, void *stream) {
-  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes,
-                     variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM : STB_MODE_SCALED,
+  const int mode = variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM
+                   : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
+                                                     : STB_MODE_BFP;
+  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
 }
 
