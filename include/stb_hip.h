@@ -112,6 +112,17 @@ int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_
 int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double *out_host,
                             float *ms_fill, float *ms_sweep, float *ms_terms);
 
+/* ---- diagnostics of the host samplers (include/psample.h) ----
+ * the log-posterior evaluations of the most recent samplea()/sampleb() call on this process:
+ * how many, ARMS' return code (ignored by the samplers themselves, as in the reference), and the
+ * i-th (abscissa, value) pair */
+int stb_sampler_trace_count(void);
+int stb_sampler_trace_code(void);
+int stb_sampler_trace_get(int i, double *x, double *y);
+/* entry i of the ziggurat tables the Gaussian generator rebuilt (which: 0 heights, 1 widths,
+ * 2 integer thresholds); for tests */
+double stb_zig_table(int which, int i);
+
 #ifdef __cplusplus
 }
 #endif

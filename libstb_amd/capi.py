@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
         ("stb_sampler_trace_count", i, []),
         ("stb_sampler_trace_get", i, [i, c_double_p, c_double_p]),
         ("stb_sampler_trace_code", i, []),
+        ("stb_zig_table", d, [i, i]),
     ):
         if hasattr(L, name):
             sig(name, res, args)
