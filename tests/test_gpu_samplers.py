@@ -1,0 +1,134 @@
+"""GPU parity of samplea / sampleb (include/psample.h) against the reference's end-to-end runs
+under the same libc streams (srand(777), srand48(12345)).
+
+The host control code is bit-identical to the reference (tests/test_host_logic.py); what can
+differ is the log-posterior value handed to ARMS: the reference accumulates 10^3..10^6 terms
+left to right in one double (its own rounding noise is ~1e-13 relative, i.e. up to ~1e-3 absolute
+at |y| ~ 1e10), the device sums in double-double.  ARMS only looks at DIFFERENCES of these values,
+so the abscissae it visits agree to many digits but not to the last bit; the integer outputs
+(number of evaluations, return code) and the bracket are exact.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+fh = float.fromhex
+
+SETS = {"small_wide": (20, 30, 300, "wide"), "small_real": (20, 30, 300, "realistic"),
+        "mid_wide": (100, 100, 1000, "wide"), "big_wide": (1000, 1000, 4000, "wide"),
+        "big_real": (1000, 1000, 4000, "realistic")}
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def ragged(g):
+    """n[i][k], t[i][k] pointer vectors over the flat arrays, as the reference's callers pass them"""
+    NP = C.POINTER(C.c_uint32) * g.I
+    TP = C.POINTER(C.c_uint16) * g.I
+    n, t = NP(), TP()
+    off = 0
+    for i in range(g.I):
+        n[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+        t[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
+        off += int(g.K[i])
+    return n, t
+
+
+def trace(L):
+    xs, ys = [], []
+    for i in range(L.stb_sampler_trace_count()):
+        x, y = C.c_double(), C.c_double()
+        L.stb_sampler_trace_get(i, C.byref(x), C.byref(y))
+        xs.append(x.value)
+        ys.append(y.value)
+    return np.array(xs), np.array(ys), L.stb_sampler_trace_code()
+
+
+@pytest.mark.parametrize("rec_index", range(11))
+def test_samplea_vs_reference(golden_dir, rec_index):
+    L = capi.lib()
+    rec = load(golden_dir, "samplers.json")["samplea"][rec_index]
+    g = synth.groups(*SETS[rec["set"]])
+    n, t = ragged(g)
+    orc.seed_libc(777, 12345)
+    got = L.samplea(fh(rec["a_in"]), g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, 1, 0)
+    xs, ys, code = trace(L)
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    assert code == rec["trace"]["code"]
+    assert len(xs) == rec["trace"]["count"], (len(xs), rec["trace"]["count"])   # same number of aterms calls
+    assert np.array_equal(xs[:3], want_x[:3])                    # the three starting abscissae are exact
+    assert orc.close(ys[:3], want_y[:3], 1e-10)                  # log-posterior parity where x is identical
+    relx = np.max(np.abs(xs - want_x) / np.abs(want_x))
+    print(f"{rec['set']}: {len(xs)} evals, max rel dx {relx:.2e}, da {abs(got - fh(rec['a_out'])):.2e}")
+    assert relx <= 1e-4                                          # adaptive abscissae: see module docstring
+    assert orc.close(ys, want_y, 1e-7)                           # y at (slightly) different x
+    assert abs(got - fh(rec["a_out"])) <= 1e-6 * abs(fh(rec["a_out"]))
+
+
+def test_samplea_getval_callback_equals_arrays():
+    L = capi.lib()
+    g = synth.groups(20, 30, 300, "wide")
+    n, t = ragged(g)
+    orc.seed_libc(777, 12345)
+    a1 = L.samplea(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, 1, 0)
+    offs = np.concatenate([[0], np.cumsum(g.K)])
+
+    @capi.GETVAL
+    def getval(pn, pt, i, k):
+        pn[0] = int(g.n[offs[i] + k])
+        pt[0] = int(g.t[offs[i] + k])
+
+    orc.seed_libc(777, 12345)
+    a2 = L.samplea(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), None, None, getval, orc.dp(g.bpar), None, 1, 0)
+    assert a1 == a2
+
+
+@pytest.mark.parametrize("rec_index", range(20))
+def test_sampleb_vs_reference(golden_dir, rec_index):
+    L = capi.lib()
+    rec = load(golden_dir, "samplers.json")["sampleb"][rec_index]
+    g = synth.groups(*SETS[rec["set"]])
+    orc.seed_libc(777, 12345)
+    got = L.sampleb(fh(rec["b_in"]), g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), fh(rec["apar"]),
+                    None, 1, 0)
+    want = fh(rec["b_out"])
+    if fh(rec["apar"]) == 0.0:
+        assert got == want          # Gamma/Gaussian draw only: host RNG path, exact
+        return
+    xs, ys, code = trace(L)
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    assert code == rec["trace"]["code"]
+    assert len(xs) == rec["trace"]["count"]
+    assert np.array_equal(xs[:3], want_x[:3])
+    assert orc.close(ys[:3], want_y[:3], 1e-10)
+    relx = np.max(np.abs(xs - want_x) / np.abs(want_x))
+    print(f"{rec['set']}: {len(xs)} evals, max rel dx {relx:.2e}, db {abs(got - want):.2e}")
+    assert relx <= 1e-4
+    assert orc.close(ys, want_y, 1e-7)
+    assert abs(got - want) <= 1e-6 * abs(want)
+
+
+def test_slice_variant_runs_on_device(monkeypatch):
+    """STB_SAMPLER=slice routes samplea/sampleb through SliceSimple (lib/sslice.c path)"""
+    L = capi.lib()
+    monkeypatch.setenv("STB_SAMPLER", "slice")
+    g = synth.groups(20, 30, 300, "realistic")
+    n, t = ragged(g)
+    orc.seed_libc(777, 12345)
+    a = L.samplea(0.3, g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, 2, 0)
+    assert 0.01 <= a <= 0.98 and L.stb_sampler_trace_count() >= 4
+    orc.seed_libc(777, 12345)
+    b = L.sampleb(10.0, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), 0.5, None, 2, 0)
+    assert 0.01 <= b <= 2000
