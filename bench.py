@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from libstb_amd import capi, synth
+from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
@@ -98,7 +98,7 @@ def main():
     Dg = Dl * world
     # configs[1] is the single discount a=0.5; any larger job shards the (0.05,0.95) grid
     grid = np.array([0.5]) if Dg == 1 else synth.discount_grid(Dg)
-    mine = np.ascontiguousarray(grid[rank * Dl:(rank + 1) * Dl])
+    mine = np.ascontiguousarray(grid[shard.my_slice(Dg, rank, world)])
     T = capi.DeviceTables(N, M, D=Dl, device=dev)
     cells_rank = T.cells * Dl
     probe_idx = torch.tensor([T.rowoff(N) + max(M // 2, 2) - 2], device=dev)
@@ -107,10 +107,7 @@ def main():
     def step():
         T.fill(mine, args.variant)
         probes = T.tables.index_select(1, probe_idx).reshape(-1)  # log S^N_{M/2} per discount
-        if dist is not None:
-            dist.all_gather_into_tensor(gathered, probes)
-        else:
-            gathered.copy_(probes)
+        gathered.copy_(shard.gather_scalars(probes, Dg, dist))
 
     def fence():
         torch.cuda.synchronize()
@@ -138,10 +135,7 @@ def main():
     kms, kn = C.c_double(0.0), C.c_int(0)
     capi.check(L.stb_fill_profile_end(C.byref(kms), C.byref(kn)))
 
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = shard.max_over_ranks(dt, dev, dist)
     total_cells = cells_rank * world * args.steps
     value = total_cells / dt
 

@@ -1,0 +1,52 @@
+"""Discount-axis sharding for multi-GPU runs: tables for different discounts are
+independent, so rank r owns a contiguous block of the sorted grid, fills and sweeps it locally, and
+the only exchange is an all-gather of one scalar per discount (RCCL on GPUs, gloo in CPU tests)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def my_slice(D_total: int, rank: int, world: int) -> slice:
+    """contiguous block of the D_total grid points owned by `rank` (remainder spread over the
+    first ranks, so any D_total works, not only multiples of world)"""
+    base, extra = divmod(D_total, world)
+    lo = rank * base + min(rank, extra)
+    return slice(lo, lo + base + (1 if rank < extra else 0))
+
+
+def counts(D_total: int, world: int):
+    return [my_slice(D_total, r, world).stop - my_slice(D_total, r, world).start for r in range(world)]
+
+
+def gather_scalars(local, D_total: int, dist=None, group=None):
+    """all ranks end up with the D_total per-discount scalars in grid order.
+
+    `local` is a 1-D torch tensor with this rank's values.  Equal shares use
+    all_gather_into_tensor (one collective, 8 bytes per discount); ragged shares pad to the
+    largest share first."""
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local.clone()
+    world = dist.get_world_size(group)
+    cnt = counts(D_total, world)
+    if len(set(cnt)) == 1:
+        out = torch.empty(D_total, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    width = max(cnt)
+    padded = torch.zeros(width, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    buf = torch.empty(world * width, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    return torch.cat([buf[r * width: r * width + cnt[r]] for r in range(world)])
+
+
+def max_over_ranks(seconds: float, device, dist=None) -> float:
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,73 @@
+"""Where the real reference is compiled (oracle/_ref, build container only): the CPU oracle must
+reproduce it bit for bit on fresh random inputs, not only on the committed fixtures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import synth
+
+pytestmark = pytest.mark.ref
+
+
+def test_fill_random_shapes_bitwise():
+    R = orc.ref()
+    rng = np.random.default_rng(3)
+    buf = np.zeros(2048)
+    for _ in range(12):
+        M = int(rng.integers(10, 300))
+        N = int(rng.integers(M, 900))
+        a = float(rng.uniform(0.01, 0.98))
+        sp = R.S_make(N, M, N, M, a, 1)
+        S1, tab = orc.fill_S(a, N, M)
+        for n in range(3, N + 1):
+            k = R.ref_copy_S_row(sp, n, orc.dp(buf))
+            o = orc.row_offset(n, M)
+            assert np.array_equal(buf[:k], tab[o:o + k]), (N, M, a, n)
+        r1 = np.zeros(N)
+        R.ref_copy_S1(sp, orc.dp(r1), N)
+        assert np.array_equal(r1, S1)
+        R.S_free(sp)
+
+
+def test_v_fill_bitwise():
+    R = orc.ref()
+    buf = np.zeros(512)
+    for (N, M, a) in ((300, 60, 0.3), (120, 120, 0.9), (500, 11, 0.05)):
+        sp = R.S_make(N, M, N, M, a, 2)
+        v = orc.fill_V(a, N, M)
+        L = orc.oracle()
+        for n in range(2, N + 1):
+            k = R.ref_copy_V_row(sp, n, orc.dp(buf))
+            o = int(L.orc_vrow_offset(n, M))
+            assert np.array_equal(buf[:k], v[o:o + k]), (N, M, n)
+        R.S_free(sp)
+
+
+def test_aterms_bterms_bitwise():
+    R, L = orc.ref(), orc.oracle()
+    g = synth.groups(37, 23, 500, "wide", seed=99)
+    h = R.ref_aterms_open(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar))
+    mn, mt = R.ref_aterms_maxn(h), R.ref_aterms_maxt(h)
+    M = max(mt, 10)
+    N = max(mn, M)
+    scratch = np.zeros(synth.cells(N, M) + N)
+    for x in (0.07, 0.33, 0.71, 0.97):
+        want = R.ref_aterms_eval(h, x)
+        got = L.orc_aterms(x, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
+                           N, M, orc.dp(scratch))
+        assert got == want
+    R.ref_aterms_close(h)
+    for x in (0.02, 3.0, 777.0):
+        assert L.orc_bterms(x, 1.3, 1.1, g.I, orc.u32p(g.T), 0.4) == \
+            R.ref_bterms_eval(x, 1.3, 1.1, g.I, orc.u32p(g.T), 0.4)
+
+
+def test_asympt_and_policy_bitwise():
+    R, L = orc.ref(), orc.oracle()
+    for a in (0.0, 0.2, 0.77):
+        sp = R.S_make(20, 10, 20, 10, a, 1 | 64)
+        for (n, m) in ((30, 3), (10 ** 6, 40), (2 * 10 ** 9, 7)):
+            assert L.orc_S_asympt(a, n, m) == R.S_asympt(sp, n, m)
+        R.S_free(sp)
