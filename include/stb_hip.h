@@ -60,6 +60,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
 #define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log on output */
 #define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
 #define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
+#define STB_FILL_SPLIT 3       /* STB_FILL_SCALED with recurrence and log in separate kernels/streams */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,

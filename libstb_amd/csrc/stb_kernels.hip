@@ -177,6 +177,12 @@ __device__ __forceinline__ double ld_cell(int n, int c, double a, double up, dou
 __device__ __forceinline__ int wave_shr1(int v, int fill) {
   return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
 }
+// same with 0 shifted into lane 0 (bound_ctrl: no register has to be preset with the fill value)
+__device__ __forceinline__ double wave_shr1_zero(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_shr1(double v, double fill) {
   int lo = wave_shr1(__double2loint(v), __double2loint(fill));
   int hi = wave_shr1(__double2hiint(v), __double2hiint(fill));
@@ -462,40 +468,24 @@ __device__ __forceinline__ void bfp_rows(double (&v)[C], const double (&ca)[C], 
 #pragma unroll
   for (int q = 0; q < Q; q++) pin(y[q]);
 
-  // ---- emit the U rows ----
-  if (clast <= min(n - 1, (int)M)) {
-    // every owned column of this wave is inside all U rows (the common case): no per-row tests
+  // ---- emit the U rows: no column tests, the row slack of the slab layout (stb_layout.h) absorbs
+  // whatever a wave holds beyond the diagonal or beyond column M ----
+  (void)clast;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
     if (owned) {
+      double *row = table + roff - 2;
+      if (C == 1) {
+        row[c0] = y[u];
+      } else {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        double *row = table + roff - 2;
-        if (C == 1) {
-          row[c0] = y[u];
-        } else {
-#pragma unroll
-          for (int i = 0; i < C; i += 2)
-            *reinterpret_cast<double2 *>(row + c0 + i) = make_double2(y[u * C + i], y[u * C + i + 1]);
-        }
-        roff += (stb_row_len((unsigned)(n + u), M) + 1) & ~1u;
+        for (int i = 0; i < C; i += 2)
+          *reinterpret_cast<double2 *>(row + c0 + i) = make_double2(y[u * C + i], y[u * C + i + 1]);
       }
-    } else {
-      if (s1lane) {
-#pragma unroll
-        for (int u = 0; u < U; u++) S1[n + u - 1] = y[u * C + C - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) roff += (stb_row_len((unsigned)(n + u), M) + 1) & ~1u;
+    } else if (s1lane) {
+      S1[n + u - 1] = y[u * C + C - 1];
     }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int rr = n + u;
-      double yy[C];
-#pragma unroll
-      for (int i = 0; i < C; i++) yy[i] = y[u * C + i];
-      bfp_store_row<C>(yy, table + roff - 2, S1, rr, c0, min(rr - 1, (int)M), owned, s1lane);
-      roff += (stb_row_len((unsigned)rr, M) + 1) & ~1u;
-    }
+    roff += stb_row_pitch((unsigned)(n + u), M);
   }
 }
 
@@ -518,6 +508,7 @@ __global__ __launch_bounds__(64) void k_fill_bfp(fill_args A, int k, int P) {
   const bool owned = lane * C >= A.H;
   const bool s1lane = (j == 0) && (c0 + C - 1 == 1);
   const int clast = 2 + j * A.Wv - A.H + 64 * C - 1;  // last column carried by this wave
+  const int cmin = 2 + j * A.Wv - A.H;                // first column carried by this wave
   double *table = A.tables + (uint64_t)d * A.tstride;
   double *S1 = A.S1 + (uint64_t)d * A.s1stride;
   const uint64_t fbase = ((uint64_t)d * 2) * A.W;
@@ -573,8 +564,21 @@ __global__ __launch_bounds__(64) void k_fill_bfp(fill_args A, int k, int P) {
         s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 500));
       }
     }
-    // ---- the rows of this period, four at a time ----
-    int n = nb;
+    // ---- the rows of this period, four at a time.  Rows above this wave's first column are
+    // identically zero (and row 2 stores nothing): skip them, which also keeps every store inside
+    // its own row's slack ----
+    int n = max(nb, max(cmin, 3));
+    if (nb == 2 && cmin < 3) {
+      // row 2 of strip 0: advance the state, emit only S1
+      const double lfv = wave_shr1(v[C - 1], 0.0);
+#pragma unroll
+      for (int i = C - 1; i >= 0; i--) {
+        const double lf = (i > 0) ? v[i - 1] : lfv;
+        v[i] = fma(1.0 - ca[i], v[i], lf * s[i]);
+      }
+      if (s1lane) S1[1] = bfp_log(v[C - 1], ep[C - 1], lt);
+    }
+    roff = stb_row_offset((unsigned)n, M);
     for (; n + 3 <= ne; n += 4)
       bfp_rows<C, 4>(v, ca, s, ep, n, lt, table, roff, S1, M, c0, clast, owned, s1lane);
     for (; n <= ne; n++)
@@ -605,6 +609,221 @@ __global__ __launch_bounds__(64) void k_fill_bfp(fill_args A, int k, int P) {
   }
 }
 
+// ---- split form of the block-floating fill -----------------------------------------------------
+//
+// With one or a few tables per GPU the fused kernel above is bound by the length of one row's
+// dependent chain (shift, fma, LDS lookup, nine fmas, store) times N rows.  Here the chain is cut:
+// k_rec carries ONLY the recurrence (per cell and row: one add, one multiply, one fma) and stores
+// the raw block-floating significand v where the log will eventually live, plus one exponent per
+// cell and renormalisation period in a small ring; k_logconv then turns v into log(v 2^e) in place,
+// one thread per two cells, on other CUs and on another stream while the recurrence moves on.
+// The serial part per row is three dependent fp64 operations; the logs are embarrassingly parallel.
+#define STB_EP_RING 32  // row-blocks of exponents kept alive for the conversion kernels
+
+struct split_args {
+  int *epbuf;      // [D][STB_EP_RING][PPL][W] exponents frozen per period
+  int PPL;         // periods per launch
+  int P;           // rows per period
+};
+
+template <int C>
+__global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x;
+  const int d = blockIdx.y;
+  const double a = A.a[d];
+  const unsigned N = A.N, M = A.M;
+  const int P = X.P;
+  const int n0 = 2 + k * A.R;
+  const int n1 = min((int)N, n0 + A.R - 1);
+  const int nf = n0 - 1;
+  const int c0 = 2 + j * A.Wv - A.H + lane * C;
+  const bool owned = lane * C >= A.H;
+  const int cmin = 2 + j * A.Wv - A.H;  // first column carried by this wave
+  double *table = A.tables + (uint64_t)d * A.tstride;
+  const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+  const double *fm_in = A.fm + fbase + (uint64_t)(k & 1) * A.W;
+  const int *fe_in = A.fe + fbase + (uint64_t)(k & 1) * A.W;
+  double *fm_out = A.fm + fbase + (uint64_t)((k + 1) & 1) * A.W;
+  int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
+  int *epslot = X.epbuf + ((uint64_t)d * STB_EP_RING + (uint64_t)(k % STB_EP_RING)) * X.PPL * A.W;
+
+  double v[C], ca[C];
+  int ep[C];
+  const int cmax_f = min(nf, (int)M);
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int c = c0 + i;
+    double m = 0.0;
+    int e = 1;
+    if (k == 0) {
+      if (c == 1) m = 0.5;
+    } else if (c >= 1 && c <= cmax_f) {
+      m = fm_in[c];
+      e = fe_in[c];
+    }
+    v[i] = ldexp(m, -BFP_BIAS);
+    ep[i] = e + BFP_BIAS;
+    ca[i] = (double)c * a;
+  }
+
+  int pidx = 0;
+  for (int nb = n0; nb <= n1; nb += P, pidx++) {
+    const int ne = min(n1, nb + P - 1);
+    double s[C];
+    {
+      int epl = wave_shr1(ep[C - 1], ep[0]);
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int el = (i > 0) ? ep[i - 1] : epl;
+        const int mine = ep[i];
+        if (el > mine + 64 || v[i] == 0.0) {
+          v[i] = ldexp(v[i], mine - el);
+          ep[i] = el;
+        }
+      }
+      epl = wave_shr1(ep[C - 1], ep[0]);
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int el = (i > 0) ? ep[i - 1] : epl;
+        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 500));
+      }
+      // exponents of this period, for the conversion kernel
+      int *epp = epslot + (uint64_t)pidx * A.W;
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int c = c0 + i;
+        if (owned && c <= (int)M) epp[c] = ep[i];
+      }
+    }
+    // A lone wave issues roughly one instruction per 5 cycles whatever its kind, and a launch
+    // lasts as long as its slowest wave, so the row loop is kept to the bare recurrence: shift,
+    // C x (multiply, fma, add), one store, one pointer bump.  No column tests: the slab's row
+    // slack (stb_layout.h) absorbs what the wave holds beyond the diagonal or beyond column M.
+    // Rows above this wave's first column are identically zero and row 2 stores nothing: start at
+    // ns (this also keeps every store inside its own row's slack).
+    const int ns = max(nb, max(cmin, 3));
+    if (nb == 2 && cmin < 3) {
+      double t[C];
+      t[0] = wave_shr1_zero(v[C - 1]) * s[0];
+#pragma unroll
+      for (int i = 1; i < C; i++) t[i] = v[i - 1] * s[i];
+#pragma unroll
+      for (int i = 0; i < C; i++) v[i] = fma(1.0 - ca[i], v[i], t[i]);
+    }
+    double coef[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) coef[i] = (double)(ns - 1) - ca[i];
+    double *rowp = table + stb_row_offset((unsigned)ns, M) - 2 + c0;  // my first column in row ns
+    const unsigned pitch = stb_row_pitch((unsigned)ns, M);
+    if (ns > ne) {
+      // nothing to do in this period
+    } else if (stb_row_pitch((unsigned)ne, M) == pitch) {
+      for (int n = ns; n <= ne; n++) {
+        double t[C];
+        t[0] = wave_shr1_zero(v[C - 1]) * s[0];
+#pragma unroll
+        for (int i = 1; i < C; i++) t[i] = v[i - 1] * s[i];
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          v[i] = fma(coef[i], v[i], t[i]);
+          coef[i] += 1.0;
+        }
+        if (owned) {
+          if (C == 1) {
+            rowp[0] = v[0];
+          } else {
+#pragma unroll
+            for (int i = 0; i < C; i += 2)
+              *reinterpret_cast<double2 *>(rowp + i) = make_double2(v[i], v[i + 1]);
+          }
+        }
+        rowp += pitch;
+      }
+    } else {
+      // the row pitch steps up inside this period (once per 64 rows in the triangular part)
+      for (int n = ns; n <= ne; n++) {
+        double t[C];
+        t[0] = wave_shr1_zero(v[C - 1]) * s[0];
+#pragma unroll
+        for (int i = 1; i < C; i++) t[i] = v[i - 1] * s[i];
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          v[i] = fma(coef[i], v[i], t[i]);
+          coef[i] += 1.0;
+        }
+        if (owned) {
+          if (C == 1) {
+            rowp[0] = v[0];
+          } else {
+#pragma unroll
+            for (int i = 0; i < C; i += 2)
+              *reinterpret_cast<double2 *>(rowp + i) = make_double2(v[i], v[i + 1]);
+          }
+        }
+        rowp += stb_row_pitch((unsigned)n, M);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int kx = __builtin_amdgcn_frexp_exp(v[i]);
+      const double m = __builtin_amdgcn_frexp_mant(v[i]);
+      if (v[i] != 0.0) {
+        v[i] = ldexp(m, -BFP_BIAS);
+        ep[i] += kx + BFP_BIAS;
+      }
+    }
+  }
+
+  if (n1 < (int)N) {
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      const bool mine = owned || (j == 0 && c == 1);
+      if (mine && c >= 1 && c <= (int)M) {
+        fm_out[c] = ldexp(v[i], BFP_BIAS);
+        fe_out[c] = (v[i] != 0.0) ? ep[i] - BFP_BIAS : STB_EZ;
+      }
+    }
+  }
+}
+
+// rows [ra, rb] of every table: raw significands -> logs, in place.  grid = (column chunks of 512,
+// rb-ra+1 rows, D tables); a thread converts two adjacent columns (one 16-byte load and store).
+__global__ __launch_bounds__(256) void k_logconv(fill_args A, split_args X, int ra, int rb) {
+  __shared__ double2 lt[128];
+  if (threadIdx.x < 128) lt[threadIdx.x] = g_logtab[threadIdx.x];
+  __syncthreads();
+  const int n = ra + blockIdx.y;
+  const int d = blockIdx.z;
+  if (n > rb) return;
+  const unsigned M = A.M;
+  const int k = (n - 2) / A.R;
+  const int pidx = ((n - 2) % A.R) / X.P;
+  const int *epp = X.epbuf + (((uint64_t)d * STB_EP_RING + (uint64_t)(k % STB_EP_RING)) * X.PPL + pidx) * A.W;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // log S^n_1 = log Gamma(n-a)/Gamma(1-a) in closed form (the recurrence kernel carries column 1
+    // only as input to column 2); row 1 is written here too when the group starts at row 2
+    double *S1 = A.S1 + (uint64_t)d * A.s1stride;
+    const double a = A.a[d];
+    S1[n - 1] = lgamma((double)n - a) - lgamma(1.0 - a);
+    if (n == 2) S1[0] = 0.0;
+  }
+  const int cmax = min(n - 1, (int)M);
+  const int c = 2 + 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (c > cmax) return;
+  double *row = A.tables + (uint64_t)d * A.tstride + stb_row_offset((unsigned)n, M) - 2;
+  if (c + 1 <= cmax) {
+    double2 x = *reinterpret_cast<double2 *>(row + c);
+    const int2 e = *reinterpret_cast<const int2 *>(epp + c);
+    x.x = bfp_log(x.x, e.x, lt);
+    x.y = bfp_log(x.y, e.y, lt);
+    *reinterpret_cast<double2 *>(row + c) = x;
+  } else {
+    row[c] = bfp_log(row[c], epp[c], lt);
+  }
+}
+
 static int ensure_logtab() {
   static bool done[64] = {false};
   int dev = 0;
@@ -627,10 +846,14 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static unsigned frontier_pitch(unsigned M) { return (unsigned)align_up((size_t)M + 2, 64); }
 
+// periods of a launch never exceed this (R <= 252, P >= 1 ... in practice 2-4)
+#define STB_PPL_MAX 8
+
 extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
   (void)N;
   size_t W = frontier_pitch(M);
-  return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) + 256;
+  return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) +
+         (size_t)D * STB_EP_RING * STB_PPL_MAX * W * sizeof(int) + 512;
 }
 
 static int env_int(const char *name, int dflt) {
@@ -639,7 +862,26 @@ static int env_int(const char *name, int dflt) {
   return atoi(s);
 }
 
-#define STB_MODE_BFP 3  // S table, block-floating cells + table log (default)
+#define STB_MODE_BFP 3    // S table, block-floating cells + table log (default)
+#define STB_MODE_SPLIT 4  // same arithmetic, recurrence and log in separate kernels / streams
+
+// auxiliary streams and an event pool for the split variant (per host thread and device)
+struct split_ctx {
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[1024];
+  int made = 0;
+};
+static thread_local split_ctx g_split[16];
+
+static int split_event(split_ctx &c, int i, hipEvent_t *out) {
+  if (i >= 1024) return fail("split fill: too many row groups");
+  while (c.made <= i) {
+    HIPCHK(hipEventCreateWithFlags(&c.ev[c.made], hipEventDisableTiming));
+    c.made++;
+  }
+  *out = c.ev[i];
+  return 0;
+}
 
 // optional per-launch timing: when armed, every fill kernel is launched with a begin/end event pair
 // (hipExtLaunchKernelGGL stamps them with the dispatch's own start/stop, i.e. what a kernel trace
@@ -705,10 +947,11 @@ extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
   return 0;
 }
 
+extern "C" int stb_default_variant(void);
 extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
   const bool few = (uint64_t)D * M < 40000;
-  int C = env_int("STB_FILL_C", few ? 1 : 2);
-  int R = env_int("STB_FILL_R", few ? 48 : 64);
+  int C = env_int("STB_FILL_C", stb_default_variant() == STB_FILL_SPLIT ? 2 : (few ? 1 : 2));
+  int R = env_int("STB_FILL_R", stb_default_variant() == STB_FILL_SPLIT ? 64 : (few ? 48 : 64));
   if (R < 1) R = 1;
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
@@ -737,15 +980,15 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   // tunables: columns per lane and rows per launch.  Few tables in flight -> the fill is bound by
   // the latency of one row step, so narrow lanes (C=1); many tables -> throughput, wider lanes.
   const bool few = (uint64_t)D * M < 40000;
-  int C = env_int("STB_FILL_C", few ? 1 : 2);
-  int R = env_int("STB_FILL_R", few ? 48 : 64);
+  int C = env_int("STB_FILL_C", mode == STB_MODE_SPLIT ? 2 : (few ? 1 : 2));
+  int R = env_int("STB_FILL_R", mode == STB_MODE_SPLIT ? 64 : (few ? 48 : 64));
   if (C != 1 && C != 2 && C != 4) return fail("STB_FILL_C must be 1, 2 or 4");
   if (R < 1) R = 1;
   int H = (R + C - 1) / C * C;
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
   // rows per renormalisation period: a value grows by < 2N per row; keep P*log2(2N) under ~440 bits
   int P = 1;
-  if (mode == STB_MODE_BFP) {
+  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT) {
     if (ensure_logtab()) return 1;
     int bits = 2;
     while ((1ull << bits) < 2ull * N) bits++;
@@ -777,6 +1020,63 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
   const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  if (mode == STB_MODE_SPLIT) {
+    split_args X;
+    X.P = P;
+    X.PPL = (R + P - 1) / P;
+    if (X.PPL > STB_PPL_MAX) return fail("%s: %d renormalisation periods per launch (max %d); lower STB_FILL_R", who, X.PPL, STB_PPL_MAX);
+    X.epbuf = (int *)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int));
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail("device index %d out of range", dev);
+    split_ctx &cx = g_split[dev];
+    for (auto &q : cx.aux)
+      if (!q) HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    const int G = env_int("STB_SPLIT_GROUP", 4) < STB_EP_RING / 2 ? (env_int("STB_SPLIT_GROUP", 4) > 0 ? env_int("STB_SPLIT_GROUP", 4) : 1)
+                                                                  : STB_EP_RING / 2;
+    const int ngroups = (nlaunch + G - 1) / G;
+    // events: [g] = recurrence of group g done (on st), [ngroups+g] = conversion of group g done
+    for (int k = 0; k < nlaunch; k++) {
+      const int g = k / G;
+      if (k % G == 0 && g >= 2) {
+        // the exponent slots about to be reused belong to group g-2: its conversion must be over
+        hipEvent_t e;
+        if (split_event(cx, ngroups + g - 2, &e)) return 1;
+        HIPCHK(hipStreamWaitEvent(st, e, 0));
+      }
+      int n1 = 2 + (k + 1) * R - 1;
+      if (n1 > (int)N) n1 = (int)N;
+      int ncols = (n1 < (int)M ? n1 : (int)M) - 1;
+      if (ncols < 1) ncols = 1;
+      dim3 grid((ncols + A.Wv - 1) / A.Wv, D);
+      switch (C) {
+        case 1: hipLaunchKernelGGL((k_rec<1>), grid, dim3(64), 0, st, A, X, k); break;
+        case 2: hipLaunchKernelGGL((k_rec<2>), grid, dim3(64), 0, st, A, X, k); break;
+        default: hipLaunchKernelGGL((k_rec<4>), grid, dim3(64), 0, st, A, X, k); break;
+      }
+      if (k % G == G - 1 || k == nlaunch - 1) {
+        hipEvent_t ea, eb;
+        if (split_event(cx, g, &ea) || split_event(cx, ngroups + g, &eb)) return 1;
+        hipStream_t q = cx.aux[g % 3];
+        HIPCHK(hipEventRecord(ea, st));
+        HIPCHK(hipStreamWaitEvent(q, ea, 0));
+        const int ra = 2 + g * G * R;
+        const int rb = n1;
+        const int cm = (rb < (int)M ? rb : (int)M) - 1;  // columns 2..min(rb,M)
+        dim3 cg((unsigned)((cm > 0 ? cm : 1) + 511) / 512, (unsigned)(rb - ra + 1), (unsigned)D);
+        hipLaunchKernelGGL(k_logconv, cg, dim3(256), 0, q, A, X, ra, rb);
+        HIPCHK(hipEventRecord(eb, q));
+      }
+    }
+    // the caller's stream continues only after every conversion has finished
+    for (int g = (ngroups > 3 ? ngroups - 3 : 0); g < ngroups; g++) {
+      hipEvent_t e;
+      if (split_event(cx, ngroups + g, &e)) return 1;
+      HIPCHK(hipStreamWaitEvent(st, e, 0));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   for (int k = 0; k < nlaunch; k++) {
     int n1 = 2 + (k + 1) * R - 1;
     if (n1 > (int)N) n1 = (int)N;
@@ -796,7 +1096,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 
 extern "C" int stb_default_variant(void) {
   const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
-  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP) ? v : STB_FILL_SCALED;
+  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT) ? v : STB_FILL_SCALED;
 }
 
 extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -804,7 +1104,8 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
                           size_t ws_bytes, int variant, void *stream) {
   const int mode = variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM
                    : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
-                                                     : STB_MODE_BFP;
+                   : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
+                                               : STB_MODE_BFP;
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
 }

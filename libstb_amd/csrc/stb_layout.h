@@ -3,9 +3,8 @@
  *
  * The reference keeps `double **S` with S[n-3][m-2] = log S^n_{m,a} for 3<=n<=usedN,
  * 2<=m<=min(n-1,usedM), one malloc per row (reference lib/stable.h:77, lib/stable.c:207-231).
- * Here a table is ONE slab: rows back to back, row n holding min(n-2, M-1) values, each row's
- * start rounded to an even element so that every row base is 16-byte aligned and a lane that
- * owns two adjacent columns can store them with one 16-byte access.  The host mirror is a
+ * Here a table is ONE slab: rows back to back, row n holding min(n-2, M-1) values followed by
+ * alignment padding and a fixed slack (see below).  The host mirror is a
  * byte-for-byte copy of the device slab (one hipMemcpy), and the row-pointer vector the
  * reference's struct exposes simply points into it.
  *
@@ -22,23 +21,37 @@
 #define STB_HD static inline
 #endif
 
-/* stored values in row n of an S table with column bound M: m = 2..min(n-1,M) */
+/* Row geometry.  Row n of an S table stores m = 2..min(n-1,M): len(n) = min(n-2, M-1) values.
+ * In the slab each row occupies pitch(n) = roundup(len(n), STB_ROW_ALIGN) + STB_ROW_SLACK elements:
+ *  - every row base is 512-byte aligned, so a wave's 512 B / 1 KiB store never straddles lines;
+ *  - at least STB_ROW_SLACK elements after the last stored value belong to the same row and are
+ *    never read.  The fill kernels rely on this: a wavefront that straddles the diagonal (or column
+ *    M) stores all of its 64*C columns unconditionally, the excess lands in the slack (C <= 4).
+ * N = M = 10000: 52.9 M elements (423 MB) for 49 985 001 stored values. */
+#define STB_ROW_ALIGN 64u
+#define STB_ROW_SLACK 256u
+
 STB_HD unsigned stb_row_len(unsigned n, unsigned M) {
   if (n < 3) return 0;
   return (n - 2 < M - 1) ? n - 2 : M - 1;
 }
 
-/* sum_{L=1..k} roundup2(L) */
+STB_HD unsigned stb_row_pitch(unsigned n, unsigned M) {
+  if (n < 3) return 0;
+  return ((stb_row_len(n, M) + STB_ROW_ALIGN - 1) & ~(STB_ROW_ALIGN - 1)) + STB_ROW_SLACK;
+}
+
+/* sum_{L=1..k} (roundup(L, ALIGN) + SLACK) */
 STB_HD uint64_t stb_tri_padded(uint64_t k) {
-  uint64_t h = (k + 1) >> 1, g = k >> 1;
-  return h * (h + 1) + g * (g + 1);
+  const uint64_t q = k / STB_ROW_ALIGN, r = k % STB_ROW_ALIGN;
+  return STB_ROW_ALIGN * (STB_ROW_ALIGN * (q * (q + 1) / 2) + r * (q + 1)) + k * STB_ROW_SLACK;
 }
 
 /* element offset of row n (3<=n) inside the slab */
 STB_HD uint64_t stb_row_offset(unsigned n, unsigned M) {
   if (n <= 3) return 0;
   if (n <= M + 1) return stb_tri_padded((uint64_t)n - 3);
-  return stb_tri_padded((uint64_t)M - 1) + (uint64_t)(n - M - 2) * (((uint64_t)M - 1 + 1) & ~1ull);
+  return stb_tri_padded((uint64_t)M - 1) + (uint64_t)(n - M - 2) * stb_row_pitch(M + 1, M);
 }
 
 /* slab size in elements for bounds (N,M) */
@@ -60,10 +73,14 @@ STB_HD unsigned stb_vrow_len(unsigned n, unsigned M) {
   if (n < 2) return 0;
   return (n - 1 < M - 1) ? n - 1 : M - 1;
 }
+STB_HD unsigned stb_vrow_pitch(unsigned n, unsigned M) {
+  if (n < 2) return 0;
+  return ((stb_vrow_len(n, M) + STB_ROW_ALIGN - 1) & ~(STB_ROW_ALIGN - 1)) + STB_ROW_SLACK;
+}
 STB_HD uint64_t stb_vrow_offset(unsigned n, unsigned M) {
   if (n <= 2) return 0;
   if (n <= M) return stb_tri_padded((uint64_t)n - 2);
-  return stb_tri_padded((uint64_t)M - 1) + (uint64_t)(n - M - 1) * (((uint64_t)M - 1 + 1) & ~1ull);
+  return stb_tri_padded((uint64_t)M - 1) + (uint64_t)(n - M - 1) * stb_vrow_pitch(M, M);
 }
 STB_HD uint64_t stb_vtable_elems(unsigned N, unsigned M) { return stb_vrow_offset(N + 1, M); }
 STB_HD uint64_t stb_vtable_cells(unsigned N, unsigned M) {

@@ -50,12 +50,13 @@ def test_layout_queries_are_pure():
     assert L.stb_cells(4000, 4000) == 7994001
     assert L.stb_cells(10000, 10000) == 49985001
     assert L.stb_elems(10000, 10000) >= 49985001
-    assert L.stb_rowoff(3, 50) == 0 and L.stb_rowoff(4, 50) == 2 and L.stb_rowoff(5, 50) == 4
-    # rows start on even elements (16-byte aligned)
-    for (N, M) in ((200, 50), (77, 76), (1000, 13)):
+    assert L.stb_rowoff(3, 50) == 0 and L.stb_rowoff(4, 50) == 320 and L.stb_rowoff(5, 50) == 640
+    # rows start 512-byte aligned and keep >= 256 elements of slack after the last stored value
+    for (N, M) in ((200, 50), (77, 76), (1000, 13), (300, 300)):
         for n in range(3, N + 1):
-            assert L.stb_rowoff(n, M) % 2 == 0
-            assert L.stb_rowoff(n + 1, M) - L.stb_rowoff(n, M) >= min(n - 2, M - 1)
+            assert L.stb_rowoff(n, M) % 64 == 0
+            assert L.stb_rowoff(n + 1, M) - L.stb_rowoff(n, M) >= min(n - 2, M - 1) + 256
+        assert L.stb_elems(N, M) == L.stb_rowoff(N + 1, M)
 
 
 @pytest.mark.skipif(capi.lib().stb_device_count() > 0, reason="a GPU is present")

@@ -8,6 +8,6 @@ N = int(sys.argv[1]); D = int(sys.argv[2]); reps = int(sys.argv[3])
 T = capi.DeviceTables(N, N, D=D)
 a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
 for _ in range(reps):
-    T.fill(a)
+    T.fill(a, int(os.environ.get('VARIANT', '0')))
 torch.cuda.synchronize()
 print("done")
