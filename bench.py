@@ -141,7 +141,11 @@ def main():
 
     if rank == 0:
         Cc, Rr, nl = C.c_int(), C.c_int(), C.c_int()
-        L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
+        split = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
+        if args.variant == capi.FILL_SPLIT:
+            split = 1
+        elif args.variant != capi.FILL_SCALED:
+            split = 0
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches
         bytes_per_launch = 8.0 * cells_rank * args.steps / launches  # 8 B per stored cell
@@ -172,7 +176,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_fill_bfp" if args.variant == capi.FILL_SCALED else "k_fill_rows",
+                "kernel": ("k_rec (recurrence; logs follow in k_logconv on a second stream)" if split
+                           else "k_fill_bfp" if args.variant in (capi.FILL_SCALED, capi.FILL_FUSED) else "k_fill_rows"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -182,7 +187,7 @@ def main():
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_per_step": kms.value / args.steps,
-                "note": "fp64 VALU/latency-bound at one table per GPU; see DESIGN.md",
+                "note": "one table per GPU is bound by N serial row steps of one lone wavefront per strip, not by HBM; see DESIGN.md",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -57,16 +57,18 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
  * variant              STB_FILL_SCALED (default), STB_FILL_LOGDOMAIN or STB_FILL_SCALED_STEP
  */
-#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log on output */
+#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks FUSED or SPLIT */
 #define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
 #define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
-#define STB_FILL_SPLIT 3       /* STB_FILL_SCALED with recurrence and log in separate kernels/streams */
+#define STB_FILL_SPLIT 3       /* recurrence kernel + in-place log conversion kernel on auxiliary streams */
+#define STB_FILL_FUSED 4       /* recurrence and log in one kernel (8 B of HBM traffic per cell) */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
                int variant, void *stream);
-/* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches */
+/* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches;
+ * returns 1 when the split form is chosen, 0 for the fused form */
 int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
 /* kernel-only timing of the fills issued by THIS thread between begin and end (the stream must be
  * synchronised before _end): sum of the per-launch device durations in ms and their count */

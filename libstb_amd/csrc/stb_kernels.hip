@@ -360,13 +360,14 @@ __global__ __launch_bounds__(64) void k_fill_rows(fill_args A, int k) {
 // Same recurrence in the linear domain, but a cell is (v, ep) with true value v * 2^ep where ep is
 // FROZEN for P consecutive rows: inside a period the update is  v <- (n-1 - c a) v + v_left * s,
 // s = 2^(ep_left - ep) fixed per period, i.e. one add, one multiply and one fma per cell and row.
-// v starts each period at 2^-BFP_BIAS * [0.5,1) and can only grow by the coefficient (< 2N) per
-// row, so P rows never overflow; at the period end every cell is renormalised with frexp.
+// v starts each period at 2^-BFP_BIAS * [0.5,1) and grows by at most N^2 per row (the left
+// neighbour can be that much larger next to the diagonal), so P rows with P * (2 log2 N + 1) <= 1700
+// bits of the ~1900 available never overflow; at the period end every cell is renormalised.
 // The log that is stored is taken from the bits of v: exponent field + 7 leading mantissa bits
-// index a 128-entry table {1/c, -log(1/c)} held in LDS, then a degree-6 polynomial in
+// index a 128-entry table {1/c, -log(1/c)} held in LDS, then a degree-5 polynomial in
 // r = z/c - 1, |r| < 2^-8 (the construction used by table-driven libm logs).  Absolute error of
 // the log is a few 1e-16, far inside the 1e-10 parity bound.
-#define BFP_BIAS 512
+#define BFP_BIAS 900
 
 __device__ double2 g_logtab[128];  // {invc, logc}; written by the host once per device
 
@@ -378,8 +379,7 @@ __device__ __forceinline__ double bfp_log(double v, int ep, const double2 *lt) {
   const double z = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);  // [1,2)
   const double2 t = lt[idx];
   const double r = fma(z, t.x, -1.0);
-  double p = fma(r, -1.0 / 6.0, 0.2);
-  p = fma(r, p, -0.25);
+  double p = fma(r, 0.2, -0.25);  // r^6/6 <= 2^-48/6 = 6e-16 is dropped
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r, p, 1.0);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void bfp_rows(double (&v)[C], const double (&ca)[C], 
 #pragma unroll
     for (int i = 0; i < C; i++) x[u * C + i] = v[i];
   }
-  // ---- y = log(x 2^ep): exponent field + 7 mantissa bits -> table, degree-6 polynomial in r ----
+  // ---- y = log(x 2^ep): exponent field + 7 mantissa bits -> table, degree-5 polynomial in r ----
   double2 t[Q];
   double z[Q], kf[Q], r[Q], pl[Q], y[Q];
 #pragma unroll
@@ -454,9 +454,7 @@ __device__ __forceinline__ void bfp_rows(double (&v)[C], const double (&ca)[C], 
 #pragma unroll
   for (int q = 0; q < Q; q++) r[q] = fma(z[q], t[q].x, -1.0);
 #pragma unroll
-  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], -1.0 / 6.0, 0.2);
-#pragma unroll
-  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], -0.25);
+  for (int q = 0; q < Q; q++) pl[q] = fma(r[q], 0.2, -0.25);  // r^6/6 <= 6e-16 is dropped
 #pragma unroll
   for (int q = 0; q < Q; q++) pl[q] = fma(r[q], pl[q], 1.0 / 3.0);
 #pragma unroll
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(64) void k_fill_bfp(fill_args A, int k, int P) {
 #pragma unroll
       for (int i = 0; i < C; i++) {
         const int el = (i > 0) ? ep[i - 1] : epl;
-        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 500));
+        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 100));
       }
     }
     // ---- the rows of this period, four at a time.  Rows above this wave's first column are
@@ -624,7 +622,21 @@ struct split_args {
   int *epbuf;      // [D][STB_EP_RING][PPL][W] exponents frozen per period
   int PPL;         // periods per launch
   int P;           // rows per period
+#ifdef STB_STAMPS
+  unsigned long long *stamps;  // diagnostic build only: [launch][strip][8] s_memtime stamps
+  int stamp_strips;
+#endif
 };
+
+#ifdef STB_STAMPS
+#define STAMP(slot)                                                                              \
+  do {                                                                                           \
+    if (X.stamps && lane == 0 && d == 0 && j < X.stamp_strips)                                   \
+      X.stamps[((size_t)k * X.stamp_strips + j) * 8 + (slot)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 template <int C>
 __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
@@ -648,6 +660,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
   int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
   int *epslot = X.epbuf + ((uint64_t)d * STB_EP_RING + (uint64_t)(k % STB_EP_RING)) * X.PPL * A.W;
 
+  STAMP(0);
   double v[C], ca[C];
   int ep[C];
   const int cmax_f = min(nf, (int)M);
@@ -666,6 +679,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
     ep[i] = e + BFP_BIAS;
     ca[i] = (double)c * a;
   }
+  STAMP(1);
 
   int pidx = 0;
   for (int nb = n0; nb <= n1; nb += P, pidx++) {
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
 #pragma unroll
       for (int i = 0; i < C; i++) {
         const int el = (i > 0) ? ep[i - 1] : epl;
-        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 500));
+        s[i] = ldexp(1.0, min(max(el - ep[i], -1100), 100));
       }
       // exponents of this period, for the conversion kernel
       int *epp = epslot + (uint64_t)pidx * A.W;
@@ -700,6 +714,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
     // lasts as long as its slowest wave, so the row loop is kept to the bare recurrence: shift,
     // C x (multiply, fma, add), one store, one pointer bump.  No column tests: the slab's row
     // slack (stb_layout.h) absorbs what the wave holds beyond the diagonal or beyond column M.
+    STAMP(2);
     // Rows above this wave's first column are identically zero and row 2 stores nothing: start at
     // ns (this also keeps every store inside its own row's slack).
     const int ns = max(nb, max(cmin, 3));
@@ -764,6 +779,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
         rowp += stb_row_pitch((unsigned)n, M);
       }
     }
+    STAMP(3);
 #pragma unroll
     for (int i = 0; i < C; i++) {
       const int kx = __builtin_amdgcn_frexp_exp(v[i]);
@@ -786,6 +802,7 @@ __global__ __launch_bounds__(64) void k_rec(fill_args A, split_args X, int k) {
       }
     }
   }
+  STAMP(4);
 }
 
 // rows [ra, rb] of every table: raw significands -> logs, in place.  grid = (column chunks of 512,
@@ -950,13 +967,15 @@ extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
 extern "C" int stb_default_variant(void);
 extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
   const bool few = (uint64_t)D * M < 40000;
-  int C = env_int("STB_FILL_C", stb_default_variant() == STB_FILL_SPLIT ? 2 : (few ? 1 : 2));
-  int R = env_int("STB_FILL_R", stb_default_variant() == STB_FILL_SPLIT ? 64 : (few ? 48 : 64));
+  const int v = stb_default_variant();
+  const bool split = v == STB_FILL_SPLIT || (v == STB_FILL_SCALED && few);
+  int C = env_int("STB_FILL_C", split ? 2 : (few ? 1 : 2));
+  int R = env_int("STB_FILL_R", split ? 96 : (few ? 48 : 64));
   if (R < 1) R = 1;
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
   if (launches) *launches = ((int)N - 1 + R - 1) / R;
-  return 0;
+  return split ? 1 : 0;  /* 1: split form (k_rec + k_logconv), 0: fused form (k_fill_bfp) */
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -981,18 +1000,22 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   // the latency of one row step, so narrow lanes (C=1); many tables -> throughput, wider lanes.
   const bool few = (uint64_t)D * M < 40000;
   int C = env_int("STB_FILL_C", mode == STB_MODE_SPLIT ? 2 : (few ? 1 : 2));
-  int R = env_int("STB_FILL_R", mode == STB_MODE_SPLIT ? 64 : (few ? 48 : 64));
+  int R = env_int("STB_FILL_R", mode == STB_MODE_SPLIT ? 96 : (few ? 48 : 64));
   if (C != 1 && C != 2 && C != 4) return fail("STB_FILL_C must be 1, 2 or 4");
   if (R < 1) R = 1;
   int H = (R + C - 1) / C * C;
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
-  // rows per renormalisation period: a value grows by < 2N per row; keep P*log2(2N) under ~440 bits
+  // rows per renormalisation period
   int P = 1;
   if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT) {
     if (ensure_logtab()) return 1;
-    int bits = 2;
-    while ((1ull << bits) < 2ull * N) bits++;
-    P = 440 / bits;
+    // A cell grows per row by U^n_m = n - m a + S^n_{m-1}/S^n_m, and the last term reaches n(n-1)/2
+    // next to the diagonal, so the bound is N^2 per row, not N.  v starts at 2^-BFP_BIAS and the
+    // scale factor s is capped at 2^100: 1700 bits of head-room.
+    int bits = 1;
+    while ((1ull << bits) < (unsigned long long)N) bits++;
+    bits = 2 * bits + 1;
+    P = 1700 / bits;
     int Penv = env_int("STB_FILL_P", 0);
     if (Penv > 0 && Penv < P) P = Penv;
     if (P < 1) P = 1;
@@ -1026,14 +1049,25 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     X.PPL = (R + P - 1) / P;
     if (X.PPL > STB_PPL_MAX) return fail("%s: %d renormalisation periods per launch (max %d); lower STB_FILL_R", who, X.PPL, STB_PPL_MAX);
     X.epbuf = (int *)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int));
+#ifdef STB_STAMPS
+    X.stamps = nullptr;
+    X.stamp_strips = 512;
+    static unsigned long long *g_stamps = nullptr;
+    if (getenv("STB_STAMP_FILE")) {
+      if (!g_stamps) HIPCHK(hipMalloc(&g_stamps, sizeof(unsigned long long) * 8 * 512 * 2048));
+      HIPCHK(hipMemsetAsync(g_stamps, 0, sizeof(unsigned long long) * 8 * 512 * 2048, st));
+      X.stamps = g_stamps;
+    }
+#endif
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail("device index %d out of range", dev);
     split_ctx &cx = g_split[dev];
     for (auto &q : cx.aux)
       if (!q) HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    const int G = env_int("STB_SPLIT_GROUP", 4) < STB_EP_RING / 2 ? (env_int("STB_SPLIT_GROUP", 4) > 0 ? env_int("STB_SPLIT_GROUP", 4) : 1)
-                                                                  : STB_EP_RING / 2;
+    int G = env_int("STB_SPLIT_GROUP", 8);  // row-blocks converted per k_logconv launch
+    if (G < 1) G = 1;
+    if (G > STB_EP_RING / 2) G = STB_EP_RING / 2;
     const int ngroups = (nlaunch + G - 1) / G;
     // events: [g] = recurrence of group g done (on st), [ngroups+g] = conversion of group g done
     for (int k = 0; k < nlaunch; k++) {
@@ -1049,11 +1083,31 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       int ncols = (n1 < (int)M ? n1 : (int)M) - 1;
       if (ncols < 1) ncols = 1;
       dim3 grid((ncols + A.Wv - 1) / A.Wv, D);
-      switch (C) {
-        case 1: hipLaunchKernelGGL((k_rec<1>), grid, dim3(64), 0, st, A, X, k); break;
-        case 2: hipLaunchKernelGGL((k_rec<2>), grid, dim3(64), 0, st, A, X, k); break;
-        default: hipLaunchKernelGGL((k_rec<4>), grid, dim3(64), 0, st, A, X, k); break;
+      hipEvent_t p0 = nullptr, p1 = nullptr;
+      if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+        while (g_prof.made < g_prof.used + 2) {
+          if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+          g_prof.made++;
+        }
+        if (g_prof.made >= g_prof.used + 2) {
+          p0 = g_prof.ev[g_prof.used];
+          p1 = g_prof.ev[g_prof.used + 1];
+          g_prof.used += 2;
+        }
       }
+#define STB_LAUNCH_REC(CC)                                                               \
+  do {                                                                                   \
+    if (p0)                                                                              \
+      hipExtLaunchKernelGGL((k_rec<CC>), grid, dim3(64), 0, st, p0, p1, 0, A, X, k);     \
+    else                                                                                 \
+      hipLaunchKernelGGL((k_rec<CC>), grid, dim3(64), 0, st, A, X, k);                   \
+  } while (0)
+      switch (C) {
+        case 1: STB_LAUNCH_REC(1); break;
+        case 2: STB_LAUNCH_REC(2); break;
+        default: STB_LAUNCH_REC(4); break;
+      }
+#undef STB_LAUNCH_REC
       if (k % G == G - 1 || k == nlaunch - 1) {
         hipEvent_t ea, eb;
         if (split_event(cx, g, &ea) || split_event(cx, ngroups + g, &eb)) return 1;
@@ -1075,6 +1129,22 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       HIPCHK(hipStreamWaitEvent(st, e, 0));
     }
     HIPCHK(hipGetLastError());
+#ifdef STB_STAMPS
+    if (X.stamps) {
+      HIPCHK(hipStreamSynchronize(st));
+      size_t cnt = (size_t)8 * 512 * nlaunch;
+      unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+      HIPCHK(hipMemcpy(h, X.stamps, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("STB_STAMP_FILE"), "w");
+      for (int k = 0; k < nlaunch; k++)
+        for (int jj = 0; jj < 512; jj++) {
+          unsigned long long *q = h + ((size_t)k * 512 + jj) * 8;
+          if (q[0]) fprintf(f, "%d %d %llu %llu %llu %llu %llu\n", k, jj, q[0], q[1], q[2], q[3], q[4]);
+        }
+      fclose(f);
+      free(h);
+    }
+#endif
     return 0;
   }
   for (int k = 0; k < nlaunch; k++) {
@@ -1096,16 +1166,23 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 
 extern "C" int stb_default_variant(void) {
   const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
-  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT) ? v : STB_FILL_SCALED;
+  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED)
+             ? v
+             : STB_FILL_SCALED;
 }
 
 extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                           uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
                           size_t ws_bytes, int variant, void *stream) {
+  // STB_FILL_SCALED picks the form by how many tables are in flight: with few, the fill is bound by
+  // the serial row chain and the split form (short chain + parallel logs) wins; with many, the GPU
+  // is full either way and the fused form moves 8 B per cell instead of 24
+  const bool few = (uint64_t)D * M < 40000;
   const int mode = variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM
                    : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
                    : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
-                                               : STB_MODE_BFP;
+                   : variant == STB_FILL_FUSED ? STB_MODE_BFP
+                   : (few ? STB_MODE_SPLIT : STB_MODE_BFP);
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
 }
