@@ -152,6 +152,18 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         name = bytearray(128)
         L.stb_device_name((C.c_char * 128).from_buffer(name), 128)
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+        # (tools/pmc_traffic.py: WRITE_SIZE + 2*FETCH_SIZE, separate passes, KiB -> bytes)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            db = json.load(open(tpath))
+            key = f"N{N}_M{M}_D{Dl}_{'split' if split else 'fused'}"
+            want = "k_rec" if split else "k_fill_bfp"
+            for kname, rec in db.get(key, {}).items():
+                if kname.startswith(want):
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/r01_hbm_traffic.json[{key}][{kname}]"
         out = {
             "metric": "S-table cells/s",
             "value": value,
@@ -182,7 +194,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches_per_step": launches / args.steps,
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
