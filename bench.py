@@ -67,6 +67,46 @@ def cpu_baseline(N: int, M: int, a: float):
             "seconds": best, "host_cpus": os.cpu_count()}
 
 
+def sweep_extra(dev):
+    """Second half of the BASELINE metric ("sampler grid-evals/s"), reported beside `value`:
+    configs[3]/[4] shape on ONE GPU -- 10^6 synthetic (n,t) pairs (I=1000 x K=1000, n<4000, wide t)
+    against N=M=4000 tables; one grid-eval = one (discount, pair) term of the log-posterior.
+    D=1 is one aterms() evaluation as samplea's ARMS makes them; D=64 is the batched grid."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    L = capi.lib()
+    g = synth.groups(1000, 1000, 4000, "wide")
+    M = max(int(g.t.max()) + 1, 10)
+    N = max(int(g.n.max()) + 1, M)
+    out = {"pairs": g.pairs, "N": N, "M": M}
+    h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
+                            g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p),
+                            capi.dp(g.bpar), N, M, 64)
+    if not h:
+        return {"error": capi.last_error()}
+    try:
+        for D in (1, 64):
+            x = np.ascontiguousarray(synth.discount_grid(64)[:D] if D > 1 else np.array([0.45]))
+            res = np.zeros(D)
+            mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
+            best = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(res), C.byref(mf), C.byref(ms), C.byref(mt)))
+                wall = time.perf_counter() - t0
+                if best is None or wall < best[0]:
+                    best = (wall, mf.value, ms.value, mt.value)
+            wall, f_ms, s_ms, t_ms = best
+            ge = D * g.pairs
+            out[f"D{D}"] = {"grid_evals": ge, "fill_ms": f_ms, "sweep_ms": s_ms, "terms_ms": t_ms, "wall_ms": wall * 1e3,
+                            "grid_evals_per_s_sweep_only": ge / (s_ms * 1e-3),
+                            "grid_evals_per_s_end_to_end": ge / wall,
+                            "sweep_algorithmic_GBs": ge * (8 + 6.0 / D) / (s_ms * 1e-3) / 1e9}
+    finally:
+        L.stb_groups_free(h)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +117,7 @@ def main():
     ap.add_argument("--discounts-per-gpu", type=int, default=1)
     ap.add_argument("--variant", type=int, default=capi.FILL_SCALED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sweep (grid-evals/s) section")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,6 +246,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, float(mine[0]))
+        if world == 1 and not args.no_extra:
+            del T
+            torch.cuda.empty_cache()
+            out["extra"] = {"sampler_sweep": sweep_extra(dev)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
