@@ -53,7 +53,24 @@ static int fail(const char *fmt, ...) {
 
 extern "C" const char *stb_last_error(void) { return g_err; }
 
+// The HIP runtime draws from libc's rand() while it initialises (first stream, first module load:
+// observed on ROCm 7.2), which would shift the rand() stream the caller's ARMS sampler is about to
+// consume (reference lib/arms.c:913-918) and make samplea/sampleb depend on whether the GPU had
+// been touched before.  Every entry point that can reach the runtime therefore runs with rand()'s
+// state swapped to a private buffer (glibc: rand() and random() share the state that
+// initstate/setstate switch) and restores the caller's state on exit.
+struct rand_guard {
+  char buf[128];
+  char *old;
+  rand_guard() { old = initstate(0x5eedu, buf, sizeof buf); }
+  ~rand_guard() { setstate(old); }
+  rand_guard(const rand_guard &) = delete;
+  rand_guard &operator=(const rand_guard &) = delete;
+};
+#define STB_ENTRY rand_guard stb_rand_guard_
+
 extern "C" int stb_device_count(void) {
+  STB_ENTRY;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
     (void)hipGetLastError();
@@ -63,6 +80,7 @@ extern "C" int stb_device_count(void) {
 }
 
 extern "C" int stb_device_name(char *buf, int len) {
+  STB_ENTRY;
   hipDeviceProp_t p;
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
@@ -72,6 +90,7 @@ extern "C" int stb_device_name(char *buf, int len) {
 }
 
 extern "C" void *stb_device_malloc(size_t bytes) {
+  STB_ENTRY;
   void *p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) {
@@ -82,9 +101,11 @@ extern "C" void *stb_device_malloc(size_t bytes) {
   return p;
 }
 extern "C" void stb_device_free(void *p) {
+  STB_ENTRY;
   if (p) (void)hipFree(p);
 }
 extern "C" void *stb_host_malloc(size_t bytes) {
+  STB_ENTRY;
   void *p = nullptr;
   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -95,17 +116,21 @@ extern "C" void *stb_host_malloc(size_t bytes) {
   return p;
 }
 extern "C" void stb_host_free(void *p) {
+  STB_ENTRY;
   if (p) (void)hipHostFree(p);
 }
 extern "C" int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+  STB_ENTRY;
   HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   return 0;
 }
 extern "C" int stb_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+  STB_ENTRY;
   HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return 0;
 }
 extern "C" int stb_stream_sync(void *stream) {
+  STB_ENTRY;
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
@@ -949,6 +974,7 @@ extern "C" void stb_fill_profile_begin(void) {
 }
 
 extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
+  STB_ENTRY;
   // caller must have synchronised the stream(s) the fills ran on
   g_prof.armed = false;
   double tot = 0.0;
@@ -1174,6 +1200,7 @@ extern "C" int stb_default_variant(void) {
 extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                           uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
                           size_t ws_bytes, int variant, void *stream) {
+  STB_ENTRY;
   // STB_FILL_SCALED picks the form by how many tables are in flight: with few, the fill is bound by
   // the serial row chain and the split form (short chain + parallel logs) wins; with many, the GPU
   // is full either way and the fused form moves 8 B per cell instead of 24
@@ -1189,6 +1216,7 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
 
 extern "C" int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
                           uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream) {
+  STB_ENTRY;
   return fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes,
                      STB_MODE_VRATIO, (hipStream_t)stream);
 }
@@ -1216,6 +1244,7 @@ __global__ void k_lookup(const double *table, const double *S1, unsigned N, unsi
 extern "C" int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
                             const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
                             void *stream) {
+  STB_ENTRY;
   if (G == 0) return 0;
   uint64_t blocks = (G + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -1343,6 +1372,7 @@ extern "C" int stb_sweep_S(const double *d_tables, uint64_t table_stride, const 
                            uint64_t s1_stride, int D, unsigned N, unsigned M, const uint32_t *d_n,
                            const uint16_t *d_t, uint64_t G, double *d_out, void *d_ws,
                            size_t ws_bytes, void *stream) {
+  STB_ENTRY;
   hipStream_t st = (hipStream_t)stream;
   if (D < 1) return fail("stb_sweep_S: D=%d", D);
   if (ws_bytes < stb_sweep_workspace_bytes(G, D)) return fail("stb_sweep_S: workspace too small");
@@ -1438,6 +1468,7 @@ static int run_terms(terms_args &A, const double *base_host, const uint32_t *d_T
 extern "C" int stb_restaurant_terms(const double *x_host, int D, const uint32_t *d_T,
                                     const double *d_bpar, uint64_t I, double *d_out, void *d_ws,
                                     size_t ws_bytes, void *stream) {
+  STB_ENTRY;
   if (D < 1 || D > STB_TERMS_DMAX) return fail("stb_restaurant_terms: D=%d (max %d)", D, STB_TERMS_DMAX);
   terms_args A;
   memset(&A, 0, sizeof(A));
@@ -1454,6 +1485,7 @@ extern "C" int stb_restaurant_terms(const double *x_host, int D, const uint32_t 
 extern "C" int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
                           const uint32_t *d_T, uint64_t I, double *d_out, void *d_ws,
                           size_t ws_bytes, void *stream) {
+  STB_ENTRY;
   if (J < 1 || J > STB_TERMS_DMAX) return fail("stb_bterms: J=%d (max %d)", J, STB_TERMS_DMAX);
   if (!(apar > 0)) return fail("stb_bterms: apar=%g", apar);
   terms_args A;
@@ -1491,6 +1523,7 @@ struct stb_groups {
 };
 
 extern "C" void stb_groups_free(stb_groups_t *g) {
+  STB_ENTRY;
   if (!g) return;
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms};
@@ -1515,6 +1548,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
 extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T,
                                            const uint32_t *nflat, const uint16_t *tflat,
                                            const double *bpar, unsigned N, unsigned M, int Dmax) {
+  STB_ENTRY;
   if (stb_device_count() < 1) {
     fail("stb_groups_create: no HIP device (libstb_amd has no CPU path)");
     return nullptr;
@@ -1565,6 +1599,7 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
 extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D,
                                        double *out_host, float *ms_fill, float *ms_sweep,
                                        float *ms_terms) {
+  STB_ENTRY;
   if (!g) return fail("stb_groups_aterms: null group set");
   if (D < 1 || D > g->Dmax) return fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
   double h[2 * STB_TERMS_DMAX];

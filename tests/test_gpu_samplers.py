@@ -132,3 +132,24 @@ def test_slice_variant_runs_on_device(monkeypatch):
     orc.seed_libc(777, 12345)
     b = L.sampleb(10.0, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), 0.5, None, 2, 0)
     assert 0.01 <= b <= 2000
+
+
+def test_rand_stream_is_not_disturbed_by_the_runtime():
+    """the HIP runtime draws from rand() while initialising; entry points must shield the caller's
+    stream (ARMS consumes it, lib/arms.c:913-918)"""
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    L = capi.lib()
+    g = synth.groups(3, 20, 30, "wide")
+    libc.srand(1)
+    want = [libc.rand() for _ in range(3)]
+    libc.srand(1)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
+                            40, 40, 1)
+    got = [libc.rand()]
+    x, out = np.array([0.4]), np.zeros(1)
+    L.stb_groups_aterms(h, capi.dp(x), 1, capi.dp(out))
+    got.append(libc.rand())
+    L.stb_groups_free(h)
+    got.append(libc.rand())
+    assert got == want
