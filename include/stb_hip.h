@@ -78,6 +78,10 @@ int stb_fill_profile_end(double *kernel_ms_total, int *launches);
 int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
                uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);
 
+/* narrow a table slab to float, element for element (S_FLOAT storage, reference lib/stable.h:31-33:
+ * "keep final table values in float, but all intermediate calcs done in double") */
+int stb_table_to_float(const double *d_src, float *d_dst, uint64_t elems, void *stream);
+
 /* ---- lookups with S_S semantics (lib/stable.c:941-974, no growth): out[g] = S_S(n[g], t[g]) ---- */
 int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
                  const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out, void *stream);

@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
     sig("stb_fill_profile_begin", None, [])
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
+    sig("stb_table_to_float", i, [vp, vp, u64, vp])
     sig("stb_lookup_S", i, [vp, vp, u, u, vp, vp, u64, vp, vp])
     sig("stb_sweep_workspace_bytes", sz, [u64, i])
     sig("stb_sweep_S", i, [vp, u64, vp, u64, i, u, u, vp, vp, u64, vp, vp, sz, vp])

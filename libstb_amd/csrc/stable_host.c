@@ -17,6 +17,12 @@
  *    :856-857 would zero valid S1 entries).
  *  - S_make with neither table flag frees the struct it allocated (:131-132 leaks it).
  *  - m < 2 in S_V returns 0 instead of indexing before the row.
+ *  - when one growth step is capped short of the requested column (new usedM <= old usedN,
+ *    lib/stable.c:626-628) the reference reads past the end of the row; here growth repeats until
+ *    the request is covered, so usedM can end up larger than the reference's in that case only.
+ *  - S_FLOAT: the SfrontN/SfrontM/VfrontN/VfrontM double frontiers stay NULL; they exist in the
+ *    reference only so that incremental extension loses no precision (lib/stable.c:389-449), and
+ *    growth here recomputes from scratch in double.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -43,12 +49,12 @@ typedef struct mirror_gen {
 typedef struct stb_impl {
   /* device */
   double *d_S, *d_V, *d_S1;
+  float *d_Sf, *d_Vf; /* S_FLOAT: narrowed copies of the double slabs, same element offsets */
   void *d_ws;
   size_t ws_bytes;
-  uint64_t d_S_elems, d_V_elems, d_S1_elems;
-  /* host mirrors (current generation) */
-  double *h_S, *h_V;
-  float *h_Sf, *h_Vf;
+  uint64_t d_S_elems, d_V_elems, d_S1_elems, d_Sf_elems, d_Vf_elems;
+  /* host mirrors (current generation); elements are double, or float under S_FLOAT */
+  void *h_S, *h_V;
   int h_S_pinned, h_V_pinned;
   uint64_t h_S_elems, h_V_elems;
   mirror_gen *retired;
@@ -102,11 +108,26 @@ static void retire(stable_t *sp, void *slab, int pinned, void *rows) {
 
 /* host-side storage prepared for new bounds but not yet visible through the public struct */
 typedef struct pending {
-  double *hS, *hV;
+  void *hS, *hV;
   int hS_pinned, hV_pinned, hS_new, hV_new;
   uint64_t hS_elems, hV_elems;
-  double **rowsS, **rowsV;
+  void **rowsS, **rowsV; /* double** or float** */
 } pending;
+
+/* bytes per stored table value: the reference's S_FLOAT keeps tables as float (lib/stable.h:31-33) */
+static size_t esz(const stable_t *sp) { return (sp->flags & S_FLOAT) ? sizeof(float) : sizeof(double); }
+
+static int devf_grow(stb_impl *im, float **slot, uint64_t *have, uint64_t want) {
+  if (want <= *have) return 0;
+  stb_device_free(*slot);
+  im->bytes_dev -= *have * sizeof(float);
+  *have = 0;
+  *slot = stb_device_malloc(sizeof(float) * want);
+  if (!*slot) return 1;
+  *have = want;
+  im->bytes_dev += want * sizeof(float);
+  return 0;
+}
 
 static int dev_grow(stb_impl *im, double **slot, uint64_t *have, uint64_t want) {
   if (want <= *have) return 0;
@@ -151,8 +172,9 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
     uint64_t el = stb_table_elems(N, M);
     if (el < 2) el = 2;
     if (dev_grow(im, &im->d_S, &im->d_S_elems, el)) return 1;
+    if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Sf, &im->d_Sf_elems, el)) return 1;
     if (growing || el > im->h_S_elems) {
-      p->hS = host_slab(sizeof(double) * el, &p->hS_pinned);
+      p->hS = host_slab(esz(sp) * el, &p->hS_pinned);
       if (!p->hS) return 1;
       p->hS_new = 1;
       p->hS_elems = el;
@@ -161,9 +183,9 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
       p->hS_pinned = im->h_S_pinned;
       p->hS_elems = im->h_S_elems;
     }
-    p->rowsS = malloc(sizeof(double *) * (N > 3 ? N : 3));
+    p->rowsS = malloc(sizeof(void *) * (N > 3 ? N : 3));
     if (!p->rowsS) return 1;
-    for (n = 3; n <= N; n++) p->rowsS[n - 3] = p->hS + stb_row_offset(n, M);
+    for (n = 3; n <= N; n++) p->rowsS[n - 3] = (char *)p->hS + esz(sp) * stb_row_offset(n, M);
   }
   if (sp->flags & S_UVTABLE) {
     uint64_t el = stb_vtable_elems(N, M);
@@ -171,8 +193,9 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
     if (!(sp->flags & S_STABLE) && dev_grow(im, &im->d_S, &im->d_S_elems, stb_table_elems(N, 2) + 2))
       return 1; /* scratch for the S1-only fill */
     if (dev_grow(im, &im->d_V, &im->d_V_elems, el)) return 1;
+    if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Vf, &im->d_Vf_elems, el)) return 1;
     if (growing || el > im->h_V_elems) {
-      p->hV = host_slab(sizeof(double) * el, &p->hV_pinned);
+      p->hV = host_slab(esz(sp) * el, &p->hV_pinned);
       if (!p->hV) return 1;
       p->hV_new = 1;
       p->hV_elems = el;
@@ -181,26 +204,36 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
       p->hV_pinned = im->h_V_pinned;
       p->hV_elems = im->h_V_elems;
     }
-    p->rowsV = malloc(sizeof(double *) * (N > 2 ? N : 2));
+    p->rowsV = malloc(sizeof(void *) * (N > 2 ? N : 2));
     if (!p->rowsV) return 1;
-    for (n = 2; n <= N; n++) p->rowsV[n - 2] = p->hV + stb_vrow_offset(n, M);
+    for (n = 2; n <= N; n++) p->rowsV[n - 2] = (char *)p->hV + esz(sp) * stb_vrow_offset(n, M);
   }
   return 0;
 }
 
 /* device fill for discount a at bounds (N,M), copied into the given mirrors; S1[0..N) refreshed */
-static int build(stable_t *sp, double a, unsigned N, unsigned M, double *hS, double *hV) {
+static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void *hV) {
   stb_impl *im = sp->impl;
   if (sp->flags & S_STABLE) {
     if (stb_fill_S(&a, 1, N, M, im->d_S, im->d_S_elems, im->d_S1, N, im->d_ws, im->ws_bytes,
                    stb_default_variant(), NULL))
       return 1;
-    if (stb_memcpy_d2h(hS, im->d_S, sizeof(double) * stb_table_elems(N, M), NULL)) return 1;
+    if (sp->flags & S_FLOAT) {
+      /* all arithmetic was done in double (as lib/stable.c:389-449 does through its frontier
+       * vectors); only the stored values are narrowed, on the device, so the copy is half as big */
+      if (stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
+      if (stb_memcpy_d2h(hS, im->d_Sf, sizeof(float) * stb_table_elems(N, M), NULL)) return 1;
+    } else if (stb_memcpy_d2h(hS, im->d_S, sizeof(double) * stb_table_elems(N, M), NULL))
+      return 1;
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
   }
   if (sp->flags & S_UVTABLE) {
     if (stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL)) return 1;
-    if (stb_memcpy_d2h(hV, im->d_V, sizeof(double) * stb_vtable_elems(N, M), NULL)) return 1;
+    if (sp->flags & S_FLOAT) {
+      if (stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
+      if (stb_memcpy_d2h(hV, im->d_Vf, sizeof(float) * stb_vtable_elems(N, M), NULL)) return 1;
+    } else if (stb_memcpy_d2h(hV, im->d_V, sizeof(double) * stb_vtable_elems(N, M), NULL))
+      return 1;
   }
   if (!(sp->flags & S_STABLE)) {
     /* U/V-only tables still keep S1 (lib/stable.c:155, :337-348): take it from a width-2 S fill
@@ -218,24 +251,36 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M, double *hS, dou
 static void publish(stable_t *sp, pending *p, unsigned N, unsigned M) {
   stb_impl *im = sp->impl;
   if (sp->flags & S_STABLE) {
-    double **oldrows = sp->S;
-    sp->S = p->rowsS;
+    void *oldrows;
+    if (sp->flags & S_FLOAT) {
+      oldrows = sp->Sf;
+      sp->Sf = (float **)p->rowsS;
+    } else {
+      oldrows = sp->S;
+      sp->S = (double **)p->rowsS;
+    }
     retire(sp, NULL, 0, oldrows);
     if (p->hS_new) {
       retire(sp, im->h_S, im->h_S_pinned, NULL);
-      im->bytes_host += (p->hS_elems - im->h_S_elems) * sizeof(double);
+      im->bytes_host += (p->hS_elems - im->h_S_elems) * esz(sp);
       im->h_S = p->hS;
       im->h_S_pinned = p->hS_pinned;
       im->h_S_elems = p->hS_elems;
     }
   }
   if (sp->flags & S_UVTABLE) {
-    double **oldrows = sp->V;
-    sp->V = p->rowsV;
+    void *oldrows;
+    if (sp->flags & S_FLOAT) {
+      oldrows = sp->Vf;
+      sp->Vf = (float **)p->rowsV;
+    } else {
+      oldrows = sp->V;
+      sp->V = (double **)p->rowsV;
+    }
     retire(sp, NULL, 0, oldrows);
     if (p->hV_new) {
       retire(sp, im->h_V, im->h_V_pinned, NULL);
-      im->bytes_host += (p->hV_elems - im->h_V_elems) * sizeof(double);
+      im->bytes_host += (p->hV_elems - im->h_V_elems) * esz(sp);
       im->h_V = p->hV;
       im->h_V_pinned = p->hV_pinned;
       im->h_V_elems = p->hV_elems;
@@ -260,10 +305,6 @@ stable_t *S_make(unsigned initN, unsigned initM, unsigned maxN, unsigned maxM, d
   if (initN < initM) initM = initN; /* the quirk above can leave initN<initM: unusable, clamp */
 
   if ((flags & S_STABLE) == 0 && (flags & S_UVTABLE) == 0) return NULL; /* lib/stable.c:131-132 */
-  if (flags & S_FLOAT) {
-    yaps_message("S_make: S_FLOAT storage is not available in libstb_amd yet\n");
-    return NULL;
-  }
   if (!(a >= 0.0 && a < 1.0)) {
     yaps_message("S_make: discount %lf outside [0,1)\n", a);
     return NULL;
@@ -488,11 +529,19 @@ double S_V(stable_t *sp, unsigned n, unsigned m) {
       }
       return 0;
     }
-    if (extend(sp, n + 1, m + 1)) yaps_quit("S_extend() out of memory\n");
+    {
+      /* one step as the reference does (lib/stable.c:924); more only while the request is still
+       * outside the table (see S_S) */
+      int tries;
+      if (extend(sp, n + 1, m + 1)) yaps_quit("S_extend() out of memory\n");
+      for (tries = 0; tries < 3 && (m > sp->usedM || n > sp->usedN); tries++)
+        if (extend(sp, n + 1, m + 1)) yaps_quit("S_extend() out of memory\n");
+    }
   }
   if (m < 2) return 0;
   if (n < m) return 0;
   if (n > sp->usedN || m > sp->usedM) return 0; /* growth was capped by the max bounds */
+  if (sp->flags & S_FLOAT) return sp->Vf[n - 2][m - 2];
   return sp->V[n - 2][m - 2];
 }
 
@@ -513,8 +562,17 @@ double S_S(stable_t *sp, unsigned N, unsigned T) {
       }
       return -HUGE_VAL;
     }
-    if (extend(sp, N + 1, T + 1)) yaps_quit("S_extend() out of memory\n");
+    {
+      /* one growth step can stop short of T: the policy caps the new usedM at the OLD usedN
+       * (lib/stable.c:626-628), after which the reference indexes past the end of the row.  Here
+       * growth is repeated until the request is covered (the second step always suffices). */
+      int tries;
+      for (tries = 0; tries < 4 && (T > sp->usedM || N > sp->usedN); tries++)
+        if (extend(sp, N + 1, T + 1)) yaps_quit("S_extend() out of memory\n");
+      if (T > sp->usedM || N > sp->usedN) return -HUGE_VAL;
+    }
   }
+  if (sp->flags & S_FLOAT) return sp->Sf[N - 3][T - 2];
   return sp->S[N - 3][T - 2];
 }
 
@@ -526,6 +584,8 @@ void S_free(stable_t *sp) {
   free(sp->S1);
   free(sp->S);
   free(sp->V);
+  free(sp->Sf);
+  free(sp->Vf);
   if (im) {
     mirror_gen *g = im->retired;
     while (g) {
@@ -539,6 +599,8 @@ void S_free(stable_t *sp) {
     host_slab_free(im->h_V, im->h_V_pinned);
     stb_device_free(im->d_S);
     stb_device_free(im->d_V);
+    stb_device_free(im->d_Sf);
+    stb_device_free(im->d_Vf);
     stb_device_free(im->d_S1);
     stb_device_free(im->d_ws);
     free(im);

@@ -1222,6 +1222,31 @@ extern "C" int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, d
 }
 
 // ------------------------------------------------------------------------------------------------
+// S_FLOAT storage: narrow a slab
+
+__global__ __launch_bounds__(256) void k_to_float(const double *src, float *dst, uint64_t n2) {
+  // two elements per thread: one 16-byte load, one 8-byte store
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n2; i += step) {
+    const double2 v = reinterpret_cast<const double2 *>(src)[i];
+    reinterpret_cast<float2 *>(dst)[i] = make_float2((float)v.x, (float)v.y);
+  }
+}
+
+extern "C" int stb_table_to_float(const double *d_src, float *d_dst, uint64_t elems, void *stream) {
+  STB_ENTRY;
+  if (elems == 0) return 0;
+  if (elems & 1) return fail("stb_table_to_float: element count must be even (slabs are)");
+  const uint64_t n2 = elems / 2;
+  uint64_t blocks = (n2 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_to_float, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, n2);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // lookups with S_S semantics
 
 __device__ __forceinline__ double dev_S_S(const double *table, const double *S1, unsigned N,
