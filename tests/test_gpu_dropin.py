@@ -48,3 +48,20 @@ def test_demo_gibbs_run_prints_the_same(args):
     assert len(a) == len(b) > 20
     bad = [(x, y) for x, y in zip(a, b) if x != y]
     assert not bad, bad[:5]
+
+
+def test_own_end_to_end_driver():
+    """examples/pyp_resample.c (this repo's harness for the whole path: S_make + S_V Gibbs sweeps +
+    sampleb/samplea/S_remake + one batched 64-discount grid evaluation)"""
+    exe = os.path.join(ROOT, "examples", "bin", "pyp_resample")
+    if not os.path.exists(exe):
+        pytest.skip("examples/bin/pyp_resample not built (make -C libstb_amd/csrc)")
+    p = subprocess.run([exe, "-J", "3", "-n", "2000", "-a", "0.4", "-b", "15", "-c", "45", "-g", "64", "-s", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    m = re.search(r"posterior means after 45 sweeps: a=([0-9.]+) b=([0-9.]+)", p.stdout)
+    g = re.search(r"posterior mode at a=([0-9.]+)", p.stdout)
+    assert m and g, p.stdout
+    a, b, amode = float(m.group(1)), float(m.group(2)), float(g.group(1))
+    assert 0.01 <= a <= 0.98 and 0.01 <= b <= 2000
+    assert abs(a - amode) < 0.15  # sampled discount and batched-grid mode describe the same posterior
