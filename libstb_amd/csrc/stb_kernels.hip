@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "stb_layout.h"
 #include "../../include/stb_hip.h"
 
@@ -1547,6 +1549,60 @@ struct stb_groups {
   hipEvent_t ev[4];
 };
 
+// The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
+// random 8-byte gather moves a whole 64-byte sector.  Sorting the pairs once by (n,t) (they are reused
+// for every evaluation of a samplea call and for all D tables of a grid) makes neighbouring threads
+// read neighbouring addresses.  The sum is order-independent up to rounding and stays deterministic.
+__global__ void k_pack_pairs(const uint32_t *n, const uint16_t *t, uint64_t G, uint64_t *key) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) key[g] = ((uint64_t)n[g] << 16) | t[g];
+}
+__global__ void k_unpack_pairs(const uint64_t *key, uint64_t G, uint32_t *n, uint16_t *t) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) {
+    n[g] = (uint32_t)(key[g] >> 16);
+    t[g] = (uint16_t)(key[g] & 0xffff);
+  }
+}
+
+static int sort_pairs(uint32_t *d_n, uint16_t *d_t, uint64_t G, hipStream_t st) {
+  if (G < 2) return 0;
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = 1;
+  do {
+    if (hipMalloc(&k0, sizeof(uint64_t) * G) != hipSuccess || hipMalloc(&k1, sizeof(uint64_t) * G) != hipSuccess) {
+      fail("sort_pairs: out of device memory");
+      break;
+    }
+    const unsigned blocks = (unsigned)((G + 255) / 256);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(256), 0, st, d_n, d_t, G, k0);
+    if (rocprim::radix_sort_keys(nullptr, tmp_bytes, k0, k1, (size_t)G, 0, 48, st) != hipSuccess) {
+      fail("sort_pairs: radix_sort_keys (size query) failed");
+      break;
+    }
+    if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
+      fail("sort_pairs: out of device memory");
+      break;
+    }
+    if (rocprim::radix_sort_keys(tmp, tmp_bytes, k0, k1, (size_t)G, 0, 48, st) != hipSuccess) {
+      fail("sort_pairs: radix_sort_keys failed");
+      break;
+    }
+    hipLaunchKernelGGL(k_unpack_pairs, dim3(blocks), dim3(256), 0, st, k1, G, d_n, d_t);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+      fail("sort_pairs: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    rc = 0;
+  } while (0);
+  if (k0) (void)hipFree(k0);
+  if (k1) (void)hipFree(k1);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}
+
 extern "C" void stb_groups_free(stb_groups_t *g) {
   STB_ENTRY;
   if (!g) return;
@@ -1617,6 +1673,10 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
   if (I > 0) {
     GCHK(hipMemcpy(g->d_T, T, sizeof(uint32_t) * I, hipMemcpyHostToDevice));
     GCHK(hipMemcpy(g->d_bpar, bpar, sizeof(double) * I, hipMemcpyHostToDevice));
+  }
+  if (env_int("STB_SORT_PAIRS", 1) && sort_pairs(g->d_n, g->d_t, G, g->st)) {
+    stb_groups_free(g);
+    return nullptr;
   }
   return g;
 }
