@@ -125,6 +125,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    # STB_BENCH_SHARE_GPU=1 is a rehearsal mode for boxes with one GPU: every rank uses cuda:0 and
+    # the scalars travel over gloo.  The driver's multi-GPU runs use one GPU per rank over RCCL.
+    share = os.environ.get("STB_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -132,7 +137,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     L = capi.lib()
     N, M, Dl = args.n, args.m, args.discounts_per_gpu
@@ -153,7 +161,10 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            if share:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

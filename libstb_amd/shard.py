@@ -30,6 +30,10 @@ def gather_scalars(local, D_total: int, dist=None, group=None):
         return local.clone()
     world = dist.get_world_size(group)
     cnt = counts(D_total, world)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal mode (several ranks sharing one GPU, no RCCL): stage the 8-byte scalars through
+        # the host; the production path below hands device tensors to RCCL directly
+        return gather_scalars(local.cpu(), D_total, dist, group).to(local.device)
     if len(set(cnt)) == 1:
         out = torch.empty(D_total, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -47,6 +51,8 @@ def max_over_ranks(seconds: float, device, dist=None) -> float:
 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
