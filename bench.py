@@ -104,6 +104,44 @@ def sweep_extra(dev):
                             "sweep_algorithmic_GBs": ge * (8 + 6.0 / D) / (s_ms * 1e-3) / 1e9}
     finally:
         L.stb_groups_free(h)
+    # one whole samplea() / sampleb() call (host ARMS + device posteriors) on the same groups, and
+    # the reference's own samplea on this box's host CPU when oracle/_ref is present
+    try:
+        import orc
+
+        NP = C.POINTER(C.c_uint32) * g.I
+        TP = C.POINTER(C.c_uint16) * g.I
+        nn, tt = NP(), TP()
+        off = 0
+        for i in range(g.I):
+            nn[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+            tt[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
+            off += int(g.K[i])
+        orc.seed_libc(777, 12345)
+        t0 = time.perf_counter()
+        a_new = L.samplea(0.5, g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p), nn, tt, None,
+                          capi.dp(g.bpar), None, 1, 0)
+        ta = time.perf_counter() - t0
+        evals = L.stb_sampler_trace_count()
+        orc.seed_libc(777, 12345)
+        t0 = time.perf_counter()
+        b_new = L.sampleb(10.0, g.I, g.shape, g.scale, g.N.ctypes.data_as(capi.c_u32_p), g.T.ctypes.data_as(capi.c_u32_p),
+                          0.5, None, 1, 0)
+        tb = time.perf_counter() - t0
+        out["samplea"] = {"seconds": ta, "aterms_evaluations": evals, "a": a_new,
+                          "grid_evals_per_s": evals * g.pairs / ta}
+        out["sampleb"] = {"seconds": tb, "bterms_evaluations": L.stb_sampler_trace_count(), "b": b_new}
+        if orc.have_ref():
+            R = orc.ref()
+            orc.seed_libc(777, 12345)
+            t0 = time.perf_counter()
+            a_ref = R.ref_samplea_flat(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
+                                       orc.dp(g.bpar), 1, 0)
+            tr = time.perf_counter() - t0
+            out["samplea"]["cpu_reference"] = {"seconds": tr, "cores": 1, "a": a_ref,
+                                               "aterms_evaluations": R.ref_trace_count()}
+    except Exception as e:  # the timing section must never take the contract line down
+        out["samplea_error"] = repr(e)
     return out
 
 
