@@ -62,6 +62,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
 #define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
 #define STB_FILL_SPLIT 3       /* recurrence kernel + in-place log conversion kernel on auxiliary streams */
 #define STB_FILL_FUSED 4       /* recurrence and log in one kernel (8 B of HBM traffic per cell) */
+#define STB_FILL_PC 5          /* one producer wave (recurrence) + consumer waves (logs) per column block, via LDS */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,

@@ -868,6 +868,261 @@ __global__ __launch_bounds__(256) void k_logconv(fill_args A, split_args X, int 
   }
 }
 
+// ---- producer/consumer form of the block-floating fill ---------------------------------------
+//
+// One workgroup = one column block of 256 columns = 1 producer wave + NCW consumer waves.
+//  * The producer (wave 0) carries ONLY the recurrence, four columns per lane, and hands the raw
+//    significands of its owned columns (the right-most 64*NCW; the rest is halo) to LDS.
+//  * Each consumer wave turns 64 of them per row into logs and stores them -- 512 contiguous bytes
+//    per row and wave -- so the log work (17 of ~25 instructions per cell) is spread over NCW other
+//    SIMDs of the same CU, costs nothing on halo columns, and the table still moves 8 B per cell.
+// Producer and consumers run U=4 rows apart through a two-slot LDS ring, one barrier per 4 rows;
+// the 4 logs a consumer lane owns per trip are evaluated stage-major for ILP.
+// log S^n_1 (the S1 vector) is not produced here: k_s1 evaluates lgamma(n-a) - lgamma(1-a).
+#define PC_U 8
+#define PC_BIAS 700  // per-lane shared exponent: leave room below for the smallest cell of a lane
+#ifdef STB_STAMPS
+__device__ unsigned long long *g_dbg;  // diagnostic build: [launch][block<512][wave<4][4]
+#endif
+
+#ifdef STB_STAMPS
+#define PC_DUMP()                                                                           \
+  do {                                                                                      \
+    if (g_dbg && lane == 0 && d == 0 && j < 512) {                                          \
+      unsigned long long *q_ = g_dbg + (((size_t)k * 512 + j) * 4 + wave) * 4;              \
+      q_[0] = t_work;                                                                       \
+      q_[1] = __builtin_amdgcn_s_memtime() - t_begin;                                       \
+      q_[2] = n_trips;                                                                      \
+    }                                                                                       \
+  } while (0)
+#endif
+// LDS-only barrier: waits for this wave's LDS traffic, NOT for its global stores (a __syncthreads()
+// would add s_waitcnt vmcnt(0) and stall every consumer on its stores' round trip once per trip)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NCW>
+__global__ __launch_bounds__(64 * (1 + NCW)) void k_fill_pc(fill_args A, int k, int P) {
+  constexpr int C = 4;
+  constexpr int OW = 64 * NCW;      // owned (stored) columns per block
+  constexpr int H = 256 - OW;       // halo columns recomputed per block
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(32))) double vbuf[2][PC_U][OW];
+  __shared__ int ebuf[2][OW];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 128) lt[tid] = g_logtab[tid];
+
+  const int j = blockIdx.x;
+  const int d = blockIdx.y;
+  const unsigned N = A.N, M = A.M;
+  const int n0 = 2 + k * A.R;
+  const int n1 = min((int)N, n0 + A.R - 1);
+  const int nf = n0 - 1;
+  const int cmin = 2 + j * OW - H;  // first column of the block (halo included)
+  double *table = A.tables + (uint64_t)d * A.tstride;
+
+  // ---- producer state: four columns per lane sharing ONE exponent, so that inside a lane the
+  // left-neighbour term needs no rescaling (value of cell i = v[i] * 2^ep) ----
+  double v[C], ca[C], s = 1.0;
+  int ep = 1 + PC_BIAS;
+  const int c0 = cmin + lane * C;
+  const bool owned = lane * C >= H;
+  if (wave == 0) {
+    const double a = A.a[d];
+    const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+    const double *fm_in = A.fm + fbase + (uint64_t)(k & 1) * A.W;
+    const int *fe_in = A.fe + fbase + (uint64_t)(k & 1) * A.W;
+    const int cmax_f = min(nf, (int)M);
+    double m[C];
+    int e[C], E = STB_EZ;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      m[i] = 0.0;
+      e[i] = STB_EZ;
+      if (k == 0) {
+        if (c == 1) {
+          m[i] = 0.5;
+          e[i] = 1;
+        }
+      } else if (c >= 1 && c <= cmax_f) {
+        m[i] = fm_in[c];
+        e[i] = fe_in[c];
+      }
+      if (m[i] != 0.0) E = max(E, e[i]);
+      ca[i] = (double)c * a;
+    }
+    if (E == STB_EZ) E = 1;  // an all-zero lane: exponent of the 1 the diagonal will bring
+#pragma unroll
+    for (int i = 0; i < C; i++) v[i] = (m[i] != 0.0) ? ldexp(m[i], max(e[i] - E, -1000) - PC_BIAS) : 0.0;
+    ep = E + PC_BIAS;
+  }
+  // ---- consumer state ----
+  const int ridx = (wave - 1) * 64 + lane;     // my slot in vbuf / ebuf (consumers only)
+  const int cc = 2 + j * OW + ridx;            // my column
+
+#ifdef STB_STAMPS
+  unsigned long long t_work = 0, t_begin = __builtin_amdgcn_s_memtime(), t_mark = 0;
+  int n_trips = 0;
+#define PC_MARK() (t_mark = __builtin_amdgcn_s_memtime())
+#define PC_ACC() (t_work += __builtin_amdgcn_s_memtime() - t_mark, n_trips++)
+#else
+#define PC_MARK() do {} while (0)
+#define PC_ACC() do {} while (0)
+#endif
+  int pidx = 0;
+  for (int nb = n0; nb <= n1; nb += P, pidx++) {
+    const int ne = min(n1, nb + P - 1);
+    const int ns = max(nb, max(cmin, 3));  // rows above the block's first column are all zero
+    if (wave == 0) {
+      // period set-up: freeze the scale of the cross-lane input, s = 2^(ep_left - ep).  Adjacent
+      // lanes (4 columns apart) differ by at most (N^2)^4, i.e. 8 log2 N <= 216 bits for N < 2^27,
+      // and v_left <= 2^(-700 + 1450), so v_left * s stays below 2^970: no exponent adoption needed.
+      const int epl = wave_shr1(ep, ep);
+      s = ldexp(1.0, min(max(epl - ep, -1100), 220));
+      if (owned) {
+#pragma unroll
+        for (int i = 0; i < C; i++) ebuf[pidx & 1][lane * C - H + i] = ep;
+      }
+      if (nb == 2 && cmin < 3) {  // row 2 (nothing is stored for it)
+        const double t0 = wave_shr1_zero(v[3]) * s;
+        v[3] = fma(1.0 - ca[3], v[3], v[2]);
+        v[2] = fma(1.0 - ca[2], v[2], v[1]);
+        v[1] = fma(1.0 - ca[1], v[1], v[0]);
+        v[0] = fma(1.0 - ca[0], v[0], t0);
+      }
+    }
+    __syncthreads();  // exponents (and, first time, the log table) visible to the consumers
+    int myep = 0;
+    if (wave > 0) myep = ebuf[pidx & 1][ridx];
+
+    if (ns <= ne) {
+      double coef[C];
+      if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < C; i++) coef[i] = (double)(ns - 1) - ca[i];
+      }
+      // consumers address row r as rowbase(r)[coff]: a wave-uniform row base advanced by the row
+      // pitch, plus a per-lane constant column offset
+      double *rowbase = table + stb_row_offset((unsigned)ns, M);
+      const int coff = cc - 2;
+      const int trips = (ne - ns + 1 + PC_U - 1) / PC_U;
+      // trip q: the producer computes rows ns+U*q.., the consumers emit the rows of trip q-1
+      for (int q = 0; q <= trips; q++) {
+        PC_MARK();
+        if (wave == 0) {
+          if (q < trips) {
+            const int r0 = ns + q * PC_U;
+            const int cnt = min(PC_U, ne - r0 + 1);
+            for (int u = 0; u < cnt; u++) {
+              const double t0 = wave_shr1_zero(v[3]) * s;
+              v[3] = fma(coef[3], v[3], v[2]);
+              v[2] = fma(coef[2], v[2], v[1]);
+              v[1] = fma(coef[1], v[1], v[0]);
+              v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+              for (int i = 0; i < C; i++) coef[i] += 1.0;
+              if (owned) {
+                double2 *dst = reinterpret_cast<double2 *>(&vbuf[q & 1][u][lane * C - H]);
+                dst[0] = make_double2(v[0], v[1]);
+                dst[1] = make_double2(v[2], v[3]);
+              }
+            }
+          }
+        } else if (q > 0) {
+          const int r0 = ns + (q - 1) * PC_U;
+          const int cnt = min(PC_U, ne - r0 + 1);
+          if (cnt == PC_U) {
+            // U rows of my column, stage-major
+            double x[PC_U], z[PC_U], kf[PC_U], r[PC_U], pl[PC_U];
+            double2 t[PC_U];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) x[u] = vbuf[(q - 1) & 1][u][ridx];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) {
+              const int hi = __double2hiint(x[u]);
+              z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+              kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+            }
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) r[u] = fma(z[u], t[u].x, -1.0);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0);
+            const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+            if (stb_row_pitch((unsigned)(r0 + PC_U - 1), M) == pitch) {
+#pragma unroll
+              for (int u = 0; u < PC_U; u++)
+                rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+              rowbase += (size_t)PC_U * pitch;
+            } else {
+#pragma unroll
+              for (int u = 0; u < PC_U; u++) {
+                rowbase[coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                rowbase += stb_row_pitch((unsigned)(r0 + u), M);
+              }
+            }
+          } else {
+            for (int u = 0; u < cnt; u++) {
+              rowbase[coff] = bfp_log(vbuf[(q - 1) & 1][u][ridx], myep, lt);
+              rowbase += stb_row_pitch((unsigned)(r0 + u), M);
+            }
+          }
+        }
+        PC_ACC();
+        lds_barrier();
+      }
+    }
+    if (wave == 0) {
+      // renormalise the lane: the largest of the four significands back to 2^-PC_BIAS * [0.5,1)
+      int kmax = -4000;
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+      if (kmax > -4000) {
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+        ep += kmax + PC_BIAS;
+      }
+    }
+  }
+
+  if (wave == 0 && n1 < (int)N) {
+    const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+    double *fm_out = A.fm + fbase + (uint64_t)((k + 1) & 1) * A.W;
+    int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      const bool mine = owned || (j == 0 && c == 1);
+      if (mine && c >= 1 && c <= (int)M) {
+        fm_out[c] = __builtin_amdgcn_frexp_mant(v[i]);
+        fe_out[c] = (v[i] != 0.0) ? ep + __builtin_amdgcn_frexp_exp(v[i]) : STB_EZ;
+      }
+    }
+  }
+#ifdef STB_STAMPS
+  PC_DUMP();
+#endif
+}
+
+// S1[n-1] = log S^n_1 = log Gamma(n-a)/Gamma(1-a) for n = 1..N, all tables
+__global__ __launch_bounds__(256) void k_s1(const double *a, double *S1, uint64_t s1stride, unsigned N) {
+  const int d = blockIdx.y;
+  const double ad = a[d];
+  const double lg1 = lgamma(1.0 - ad);
+  for (unsigned n = 1 + blockIdx.x * blockDim.x + threadIdx.x; n <= N; n += gridDim.x * blockDim.x)
+    S1[(uint64_t)d * s1stride + n - 1] = (n == 1) ? 0.0 : lgamma((double)n - ad) - lg1;
+}
+
 static int ensure_logtab() {
   static bool done[64] = {false};
   int dev = 0;
@@ -908,6 +1163,7 @@ static int env_int(const char *name, int dflt) {
 
 #define STB_MODE_BFP 3    // S table, block-floating cells + table log (default)
 #define STB_MODE_SPLIT 4  // same arithmetic, recurrence and log in separate kernels / streams
+#define STB_MODE_PC 5     // same arithmetic, producer wave + consumer waves through LDS
 
 // auxiliary streams and an event pool for the split variant (per host thread and device)
 struct split_ctx {
@@ -1035,7 +1291,17 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
   // rows per renormalisation period
   int P = 1;
-  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT) {
+  if (mode == STB_MODE_PC && N >= (1u << 27)) mode = STB_MODE_BFP;  // see the scale bound in k_fill_pc
+  if (mode == STB_MODE_PC) {
+    // geometry is fixed by the block shape: 256 columns per block, NCW consumer waves
+    C = 4;
+    const int ncw = env_int("STB_PC_CONSUMERS", 2) == 3 ? 3 : 2;
+    H = 256 - 64 * ncw;
+    R = env_int("STB_FILL_R", H);
+    if (R > H) R = H;
+    if (R < 1) R = 1;
+  }
+  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT || mode == STB_MODE_PC) {
     if (ensure_logtab()) return 1;
     // A cell grows per row by U^n_m = n - m a + S^n_{m-1}/S^n_m, and the last term reaches n(n-1)/2
     // next to the diagonal, so the bound is N^2 per row, not N.  v starts at 2^-BFP_BIAS and the
@@ -1043,7 +1309,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     int bits = 1;
     while ((1ull << bits) < (unsigned long long)N) bits++;
     bits = 2 * bits + 1;
-    P = 1700 / bits;
+    P = (mode == STB_MODE_PC ? 1450 : 1700) / bits;  // the producer/consumer form starts at 2^-700
     int Penv = env_int("STB_FILL_P", 0);
     if (Penv > 0 && Penv < P) P = Penv;
     if (P < 1) P = 1;
@@ -1071,6 +1337,68 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
   const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  if (mode == STB_MODE_PC) {
+    const int ncw = (256 - H) / 64;
+    const int OW = 64 * ncw;
+    hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
+#ifdef STB_STAMPS
+    static unsigned long long *h_dbg = nullptr;
+    {
+      unsigned long long *z = nullptr;
+      if (getenv("STB_STAMP_FILE")) {
+        if (!h_dbg) HIPCHK(hipMalloc(&h_dbg, sizeof(unsigned long long) * 16 * 512 * 1024));
+        HIPCHK(hipMemsetAsync(h_dbg, 0, sizeof(unsigned long long) * 16 * 512 * 1024, st));
+        z = h_dbg;
+      }
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dbg), &z, sizeof(z), 0, hipMemcpyHostToDevice, st));
+    }
+#endif
+    for (int k = 0; k < nlaunch; k++) {
+      int n1 = 2 + (k + 1) * R - 1;
+      if (n1 > (int)N) n1 = (int)N;
+      int ncols = (n1 < (int)M ? n1 : (int)M) - 1;
+      if (ncols < 1) ncols = 1;
+      dim3 grid((ncols + OW - 1) / OW, D);
+      hipEvent_t p0 = nullptr, p1 = nullptr;
+      if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+        while (g_prof.made < g_prof.used + 2) {
+          if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+          g_prof.made++;
+        }
+        if (g_prof.made >= g_prof.used + 2) {
+          p0 = g_prof.ev[g_prof.used];
+          p1 = g_prof.ev[g_prof.used + 1];
+          g_prof.used += 2;
+        }
+      }
+      if (ncw == 3) {
+        if (p0) hipExtLaunchKernelGGL((k_fill_pc<3>), grid, dim3(256), 0, st, p0, p1, 0, A, k, P);
+        else hipLaunchKernelGGL((k_fill_pc<3>), grid, dim3(256), 0, st, A, k, P);
+      } else {
+        if (p0) hipExtLaunchKernelGGL((k_fill_pc<2>), grid, dim3(192), 0, st, p0, p1, 0, A, k, P);
+        else hipLaunchKernelGGL((k_fill_pc<2>), grid, dim3(192), 0, st, A, k, P);
+      }
+    }
+    HIPCHK(hipGetLastError());
+#ifdef STB_STAMPS
+    if (getenv("STB_STAMP_FILE") && h_dbg) {
+      HIPCHK(hipStreamSynchronize(st));
+      size_t cnt = (size_t)16 * 512 * nlaunch;
+      unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+      HIPCHK(hipMemcpy(h, h_dbg, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("STB_STAMP_FILE"), "w");
+      for (int k = 0; k < nlaunch; k++)
+        for (int jj = 0; jj < 512; jj++)
+          for (int w = 0; w < 4; w++) {
+            unsigned long long *q = h + (((size_t)k * 512 + jj) * 4 + w) * 4;
+            if (q[1]) fprintf(f, "%d %d %d %llu %llu %llu\n", k, jj, w, q[0], q[1], q[2]);
+          }
+      fclose(f);
+      free(h);
+    }
+#endif
+    return 0;
+  }
   if (mode == STB_MODE_SPLIT) {
     split_args X;
     X.P = P;
@@ -1194,7 +1522,8 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 
 extern "C" int stb_default_variant(void) {
   const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
-  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED)
+  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
+          v == STB_FILL_PC)
              ? v
              : STB_FILL_SCALED;
 }
@@ -1211,6 +1540,7 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
                    : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
                    : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
                    : variant == STB_FILL_FUSED ? STB_MODE_BFP
+                   : variant == STB_FILL_PC ? STB_MODE_PC
                    : (few ? STB_MODE_SPLIT : STB_MODE_BFP);
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);

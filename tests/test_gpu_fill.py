@@ -19,7 +19,7 @@ def test_library_sees_gpu():
     assert L.stb_device_count() >= 1, capi.last_error()
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC])
 def test_small_tables_batched_vs_golden(golden_dir, variant):
     """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
     z = np.load(os.path.join(golden_dir, "stable_200x50.npz"))
@@ -34,7 +34,7 @@ def test_small_tables_batched_vs_golden(golden_dir, variant):
         assert orc.close(T.S1[d].cpu().numpy(), z[k + "_S1"], TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC])
 @pytest.mark.parametrize("N,M", [(2, 2), (3, 2), (3, 3), (10, 10), (64, 64), (65, 33), (97, 96), (130, 129), (500, 7),
                                  (1000, 1000), (1500, 260)])
 def test_ragged_shapes_vs_oracle(N, M, variant):
@@ -61,7 +61,7 @@ def test_tunings_agree(monkeypatch, C, R):
     assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC])
 @pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
 def test_4000_full_table_vs_oracle(golden_dir, a, variant):
     N = 4000
@@ -141,7 +141,7 @@ def test_v_table_big_vs_oracle():
     assert np.array_equal(T.packed_host(0), want)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SPLIT, capi.FILL_FUSED])
+@pytest.mark.parametrize("variant", [capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC])
 @pytest.mark.parametrize("a", [0.0, 0.01, 0.07, 0.5, 0.98])
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the
