@@ -231,11 +231,9 @@ def main():
 
     if rank == 0:
         Cc, Rr, nl = C.c_int(), C.c_int(), C.c_int()
-        split = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
-        if args.variant == capi.FILL_SPLIT:
-            split = 1
-        elif args.variant != capi.FILL_SCALED:
-            split = 0
+        form = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
+        form = {capi.FILL_SPLIT: 1, capi.FILL_PC: 2, capi.FILL_FUSED: 0, capi.FILL_SCALED: form}.get(args.variant, 3)
+        split = form == 1
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches
         bytes_per_launch = 8.0 * cells_rank * args.steps / launches  # 8 B per stored cell
@@ -248,8 +246,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tpath):
             db = json.load(open(tpath))
-            key = f"N{N}_M{M}_D{Dl}_{'split' if split else 'fused'}"
-            want = "k_rec" if split else "k_fill_bfp"
+            key = f"N{N}_M{M}_D{Dl}_{['fused', 'split', 'pc', 'other'][form]}"
+            want = ["k_fill_bfp", "k_rec", "k_fill_pc", "k_fill_rows"][form]
             for kname, rec in db.get(key, {}).items():
                 if kname.startswith(want):
                     traffic = rec["hbm_bytes_per_launch"]
@@ -278,8 +276,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_rec (recurrence; logs follow in k_logconv on a second stream)" if split
-                           else "k_fill_bfp" if args.variant in (capi.FILL_SCALED, capi.FILL_FUSED) else "k_fill_rows"),
+                "kernel": ["k_fill_bfp", "k_rec (recurrence; logs follow in k_logconv on a second stream)",
+                           "k_fill_pc (producer wave + consumer waves per column block)", "k_fill_rows"][form],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -57,7 +57,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
  * variant              STB_FILL_SCALED (default), STB_FILL_LOGDOMAIN or STB_FILL_SCALED_STEP
  */
-#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks FUSED or SPLIT */
+#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks SPLIT or PC */
 #define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
 #define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
 #define STB_FILL_SPLIT 3       /* recurrence kernel + in-place log conversion kernel on auxiliary streams */
@@ -69,7 +69,7 @@ int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_ta
                uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
                int variant, void *stream);
 /* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches;
- * returns 1 when the split form is chosen, 0 for the fused form */
+ * returns the form: 0 fused, 1 split, 2 producer/consumer */
 int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
 /* kernel-only timing of the fills issued by THIS thread between begin and end (the stream must be
  * synchronised before _end): sum of the per-launch device durations in ms and their count */

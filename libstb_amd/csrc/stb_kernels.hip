@@ -1250,16 +1250,17 @@ extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
 
 extern "C" int stb_default_variant(void);
 extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
-  const bool few = (uint64_t)D * M < 40000;
+  const bool few = (uint64_t)D * M < 25000;
   const int v = stb_default_variant();
-  const bool split = v == STB_FILL_SPLIT || (v == STB_FILL_SCALED && few);
-  int C = env_int("STB_FILL_C", split ? 2 : (few ? 1 : 2));
-  int R = env_int("STB_FILL_R", split ? 96 : (few ? 48 : 64));
+  const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : (few ? 1 : 2);
+  int C = env_int("STB_FILL_C", form == 2 ? 4 : 2);
+  int R = env_int("STB_FILL_R", form == 2 ? 128 : form == 1 ? 96 : 64);
+  if (form == 2 && R > 128) R = 128;
   if (R < 1) R = 1;
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
   if (launches) *launches = ((int)N - 1 + R - 1) / R;
-  return split ? 1 : 0;  /* 1: split form (k_rec + k_logconv), 0: fused form (k_fill_bfp) */
+  return form; /* 0 fused (k_fill_bfp), 1 split (k_rec + k_logconv), 2 producer/consumer (k_fill_pc) */
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -1532,16 +1533,17 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
                           uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
                           size_t ws_bytes, int variant, void *stream) {
   STB_ENTRY;
-  // STB_FILL_SCALED picks the form by how many tables are in flight: with few, the fill is bound by
-  // the serial row chain and the split form (short chain + parallel logs) wins; with many, the GPU
-  // is full either way and the fused form moves 8 B per cell instead of 24
-  const bool few = (uint64_t)D * M < 40000;
+  // STB_FILL_SCALED picks the form by how many tables are in flight: with one or two, the fill is
+  // bound by the serial row chain and the split form (shortest chain, logs on other CUs) wins; from
+  // three 10^4-column tables on, the producer/consumer form (8 B per cell instead of 24, logs on the
+  // other SIMDs of the same CU) is faster and keeps gaining up to HBM-bound batches
+  const bool few = (uint64_t)D * M < 25000;
   const int mode = variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM
                    : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
                    : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
                    : variant == STB_FILL_FUSED ? STB_MODE_BFP
                    : variant == STB_FILL_PC ? STB_MODE_PC
-                   : (few ? STB_MODE_SPLIT : STB_MODE_BFP);
+                   : (few ? STB_MODE_SPLIT : STB_MODE_PC);
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
 }
