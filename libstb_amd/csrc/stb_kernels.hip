@@ -876,8 +876,8 @@ __global__ __launch_bounds__(256) void k_logconv(fill_args A, split_args X, int 
 //  * Each consumer wave turns 64 of them per row into logs and stores them -- 512 contiguous bytes
 //    per row and wave -- so the log work (17 of ~25 instructions per cell) is spread over NCW other
 //    SIMDs of the same CU, costs nothing on halo columns, and the table still moves 8 B per cell.
-// Producer and consumers run U=4 rows apart through a two-slot LDS ring, one barrier per 4 rows;
-// the 4 logs a consumer lane owns per trip are evaluated stage-major for ILP.
+// Producer and consumers run PC_U rows apart through a two-slot LDS ring, one barrier per PC_U rows;
+// the PC_U logs a consumer lane owns per trip are evaluated stage-major for ILP.
 // log S^n_1 (the S1 vector) is not produced here: k_s1 evaluates lgamma(n-a) - lgamma(1-a).
 #define PC_U 8
 #define PC_BIAS 700  // per-lane shared exponent: leave room below for the smallest cell of a lane
