@@ -63,14 +63,19 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
 #define STB_FILL_SPLIT 3       /* recurrence kernel + in-place log conversion kernel on auxiliary streams */
 #define STB_FILL_FUSED 4       /* recurrence and log in one kernel (8 B of HBM traffic per cell) */
 #define STB_FILL_PC 5          /* one producer wave (recurrence) + consumer waves (logs) per column block, via LDS */
+#define STB_FILL_CHAIN 6       /* one launch: column blocks keep their columns for all rows, edges handed on in HBM */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
                uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
                int variant, void *stream);
 /* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches;
- * returns the form: 0 fused, 1 split, 2 producer/consumer */
+ * returns the form: 0 fused, 1 split, 2 producer/consumer, 3 chain */
 int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
+/* Completion status of the last chain-form fill issued by THIS thread (waits for it): 0, or non-zero
+ * with stb_last_error() set when a column block gave up waiting for its neighbour (the fill's
+ * polls are bounded; STB_CHAIN_TIMEOUT_MS, default 2000).  The other forms cannot fail on the device. */
+int stb_fill_status(void);
 /* kernel-only timing of the fills issued by THIS thread between begin and end (the stream must be
  * synchronised before _end): sum of the per-launch device durations in ms and their count */
 void stb_fill_profile_begin(void);

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstb_amd.so")
 
 # flag bits of include/stable.h
 S_STABLE, S_UVTABLE, S_FLOAT, S_VERBOSE, S_QUITONBOUND, S_THREADS, S_ASYMPT = 1, 2, 4, 8, 16, 32, 64
-FILL_SCALED, FILL_LOGDOMAIN, FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_PC = 0, 1, 2, 3, 4, 5
+FILL_SCALED, FILL_LOGDOMAIN, FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_PC, FILL_CHAIN = 0, 1, 2, 3, 4, 5, 6
 
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
     sig("stb_default_variant", i, [])
     sig("stb_fill_S", i, [c_double_p, i, u, u, vp, u64, vp, u64, vp, sz, i, vp])
     sig("stb_fill_tuning", i, [u, u, i, c_int_p, c_int_p, c_int_p])
+    sig("stb_fill_status", i, [])
     sig("stb_fill_profile_begin", None, [])
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
@@ -243,6 +244,10 @@ class DeviceTables:
         check(self.L.stb_fill_S(dp(a), self.D, self.N, self.M, self.tables.data_ptr(), self.stride,
                                 self.S1.data_ptr(), self.N, self.ws.data_ptr(), self.ws_bytes,
                                 variant, stream_ptr(stream)))
+
+    def status(self):
+        """wait for the last fill of this thread and raise if a chain-form fill gave up"""
+        check(self.L.stb_fill_status())
 
     def rowoff(self, n):
         return int(self.L.stb_rowoff(n, self.M))

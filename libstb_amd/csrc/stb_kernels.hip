@@ -1123,6 +1123,349 @@ __global__ __launch_bounds__(256) void k_s1(const double *a, double *S1, uint64_
     S1[(uint64_t)d * s1stride + n - 1] = (n == 1) ? 0.0 : lgamma((double)n - ad) - lg1;
 }
 
+// ---- chain form: ONE launch per fill, column blocks hand their right edge to the next block ------
+//
+// The forms above advance every strip by R rows per launch and recompute an R-column halo so that
+// strips never talk to each other.  Here a column block owns its 64*C columns for ALL rows: the
+// value its first column needs from the left (the previous block's last column, one row up) comes
+// through global memory, so there is no halo, no launch per row block and no frontier round trip.
+//
+//  * wave 0 (producer) carries the recurrence of the block's 64*C columns, C per lane sharing one
+//    exponent, and writes raw significands to a two-slot LDS ring, CH_U rows (a "trip") per slot;
+//  * the consumer waves turn slot q-1 into logs and store them while the producer fills slot q
+//    (C slices of 64 columns x RH groups of CH_U/RH rows);
+//  * the comm wave publishes the last column of slot q-1 as 8-byte granules (the raw double; 0 = not
+//    yet written: every value a neighbour will ever ask for is > 0) with write-through stores, and
+//    polls the left neighbour's granules for trip q+1 with L1-bypassing loads into LDS.  The data is
+//    its own flag, so no fence or ordering is needed (one aligned 8-byte store per granule).
+//
+// Block (d, j) starts at the trip in which the diagonal enters its first column and lags its left
+// neighbour by the hand-off latency; since a triangular table starts column block j at row 64*C*j
+// anyway the skew is free.  Blocks take their (j, d) from an atomic ticket, j-major, so a block only
+// ever waits for a block with a smaller ticket, i.e. one that is running or done: forward progress
+// does not depend on dispatch order or on how many blocks are resident.  Every poll is bounded by
+// wall-clock time; on expiry the block records an error and stops waiting (stb_fill_status).
+#define CH_U 8
+#define CH_K 8  // trips of look-ahead of the edge loads
+#define CH_EOFF (1ull << 40)
+
+struct chain_args {
+  unsigned *hdr;               // [0] ticket, [1] error code, [2] error detail; zeroed per fill
+  unsigned long long *edge_v;  // [D][B][EV]  last column of a block, indexed by row
+  unsigned long long *edge_e;  // [D][B][NP]  its exponent per period, + CH_EOFF
+  uint64_t EV, NP;
+  int D, B;                    // tables, column blocks per table
+  int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
+  unsigned long long timeout;  // wall_clock64 ticks a poll may last
+};
+
+template <int C, int RH>
+__global__ __launch_bounds__(64 * (2 + C * RH)) void k_fill_chain(fill_args A, chain_args X) {
+  constexpr int U = CH_U;
+  constexpr int OW = 64 * C;      // columns of a block
+  constexpr int UR = U / RH;      // rows of a trip one consumer wave converts
+  constexpr int NW = 2 + C * RH;  // waves: producer, C*RH consumers, comm
+  constexpr int COMM = (NW > 4) ? 4 : NW - 1;
+  static_assert(U % RH == 0 && UR >= 1, "rows per consumer");
+  static_assert(OW <= 128, "a block's overhang must fit the row slack");
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(16))) double vbuf[2][U][OW];
+  __shared__ int ebuf[2][OW];
+  __shared__ __attribute__((aligned(16))) double edge_in[2][U];
+  __shared__ int edge_ep[2];
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
+  if (tid < 128) lt[tid] = g_logtab[tid];
+  if (tid < 2 * U) (&edge_in[0][0])[tid] = 0.0;
+  __syncthreads();
+  const int j = (int)(s_ticket / (unsigned)X.D);
+  const int d = (int)(s_ticket % (unsigned)X.D);
+  if (j >= X.B) return;  // (never: the grid is exactly B*D blocks)
+
+  const unsigned N = A.N, M = A.M;
+  const int TP = X.TP, G = X.G;
+  const int c0 = 1 + j * OW;                       // first column of the block
+  const int g0 = (c0 <= 3) ? 0 : (c0 - 3) / U;     // trip in which the diagonal reaches column c0
+  double *table = A.tables + (uint64_t)d * A.tstride;
+
+  // position of a trip inside the renormalisation periods, advanced without dividing
+  struct trip_pos {
+    int g, p, tin;
+    __device__ __forceinline__ void init(int g_, int TP_) {
+      g = g_;
+      p = g_ / TP_;
+      tin = g_ - p * TP_;
+    }
+    __device__ __forceinline__ void next(int TP_) {
+      g++;
+      if (++tin == TP_) {
+        tin = 0;
+        p++;
+      }
+    }
+  };
+
+#ifdef STB_STAMPS
+  unsigned long long t_work = 0, t_begin = __builtin_amdgcn_s_memtime(), t_mark = 0;
+  int n_trips = 0;
+#define CH_MARK() (t_mark = __builtin_amdgcn_s_memtime())
+#define CH_ACC() (t_work += __builtin_amdgcn_s_memtime() - t_mark, n_trips++)
+#define CH_DUMP()                                                                      \
+  do {                                                                                 \
+    if (g_dbg && lane == 0 && d == 0 && j < 512) {                                     \
+      unsigned long long *q_ = g_dbg + ((size_t)j * 16 + wave) * 4;                    \
+      q_[0] = t_work;                                                                  \
+      q_[1] = __builtin_amdgcn_s_memtime() - t_begin;                                  \
+      q_[2] = n_trips;                                                                 \
+    }                                                                                  \
+  } while (0)
+#else
+#define CH_MARK() do {} while (0)
+#define CH_ACC() do {} while (0)
+#define CH_DUMP() do {} while (0)
+#endif
+
+  if (wave == 0) {
+    // ================= producer =================
+    __builtin_amdgcn_s_setprio(3);
+    const double a = A.a[d];
+    double v[C], coef[C], s = 1.0;
+    int ep = 1 + PC_BIAS;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + lane * C + i;
+      // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; every other block starts above the diagonal
+      v[i] = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+      coef[i] = (double)(2 + g0 * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0
+    }
+    lds_barrier();  // B0: the comm wave has fetched the edge of trip g0
+    trip_pos q;
+    q.init(g0, TP);
+    while (q.g < G) {
+      // ---- period set-up: freeze the scale of the cross-lane input (bounds: see k_fill_pc) ----
+      {
+        int dl = wave_shr1(ep, ep) - ep;
+        if (lane == 0) dl = (j == 0) ? 0 : edge_ep[q.p & 1] - ep;
+        s = ldexp(1.0, min(max(dl, -1100), 220));
+#pragma unroll
+        for (int i = 0; i < C; i++) ebuf[q.p & 1][lane * C + i] = ep;
+      }
+      const int gend = min(G, q.g + (TP - q.tin));
+      for (int g = q.g; g < gend; g++) {
+        CH_MARK();
+        double e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = edge_in[g & 1][u];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const double t0 = wave_shr1(v[C - 1], e[u]) * s;
+#pragma unroll
+          for (int i = C - 1; i > 0; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+          v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+          for (int i = 0; i < C; i++) coef[i] += 1.0;
+          if (C == 1) {
+            vbuf[g & 1][u][lane] = v[0];
+          } else {
+#pragma unroll
+            for (int i = 0; i < C; i += 2)
+              *reinterpret_cast<double2 *>(&vbuf[g & 1][u][lane * C + i]) = make_double2(v[i], v[i + 1]);
+          }
+        }
+        CH_ACC();
+        lds_barrier();
+      }
+      q.g = gend;
+      q.tin = 0;
+      q.p++;
+      if (q.g < G) {
+        // renormalise the lane: largest significand back to 2^-PC_BIAS * [0.5,1)
+        int kmax = -4000;
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+        if (kmax > -4000) {
+#pragma unroll
+          for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+          ep += kmax + PC_BIAS;
+        }
+      }
+    }
+  } else if (wave != COMM) {
+    // ================= consumers =================
+    const int ci = wave - 1 - (wave > COMM ? 1 : 0);
+    const int slice = ci % C, rh = ci / C;
+    const int ridx = slice * 64 + lane;  // my column inside the block
+    const int cc = c0 + ridx;
+    const int coff = cc - 2;             // its offset in a table row (column 1: the slack before it)
+    uint64_t rowoff = stb_row_offset((unsigned)(3 + g0 * U), M);
+    trip_pos q;  // the trip being converted (one behind the producer)
+    q.init(g0, TP);
+    lds_barrier();  // B0
+    for (int g = g0; g <= G; g++) {
+      CH_MARK();
+      if (g > g0) {
+        const int gt = q.g;
+        const int myep = ebuf[q.p & 1][ridx];
+        const int r0 = 3 + gt * U;
+        const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+        const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch &&
+                          !(j == 0 && gt == 0);
+        double *rowbase = table + rowoff;
+        if (fast) {
+          double x[UR], z[UR], kf[UR], r[UR], pl[UR];
+          double2 t[UR];
+#pragma unroll
+          for (int u = 0; u < UR; u++) x[u] = vbuf[gt & 1][rh * UR + u][ridx];
+#pragma unroll
+          for (int u = 0; u < UR; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+          for (int u = 0; u < UR; u++) {
+            const int hi = __double2hiint(x[u]);
+            z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+            kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+          }
+#pragma unroll
+          for (int u = 0; u < UR; u++) r[u] = fma(z[u], t[u].x, -1.0);
+#pragma unroll
+          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], 1.0);
+#pragma unroll
+          for (int u = 0; u < UR; u++)
+            rowbase[(size_t)(rh * UR + u) * pitch + coff] =
+                fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+          rowoff += (uint64_t)U * pitch;
+        } else {
+          for (int u = 0; u < U; u++) {
+            const int rr = r0 + u;
+            if (u / UR == rh && (unsigned)rr <= N && cc >= 2)
+              rowbase[coff] = bfp_log(vbuf[gt & 1][u][ridx], myep, lt);
+            const unsigned pt = stb_row_pitch((unsigned)rr, M);
+            rowbase += pt;
+            rowoff += pt;
+          }
+        }
+        q.next(TP);
+      }
+      CH_ACC();
+      if (g < G) lds_barrier();
+    }
+  } else {
+    // ================= comm =================
+    const bool has_left = j > 0, has_right = j < X.B - 1;
+    const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (has_left ? j - 1 : 0)) * X.EV;
+    unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
+    const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (has_left ? j - 1 : 0)) * X.NP;
+    unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
+    bool aborted = false;
+    // The left edge for a trip: lanes 0..U-1 one row each (the value one row above the row they
+    // feed), lane U the neighbour's exponent when the trip opens a period (or the block), lane U+1
+    // the exponent of the period before: the row above the first row of a period was produced
+    // under it.  Loads are issued CH_K trips ahead (edge_issue) so that their latency overlaps the
+    // trips in between; edge_take polls only if a granule was not there yet.
+    auto edge_ptr = [&](const trip_pos &t) -> const unsigned long long * {
+      if (!has_left || t.g >= G) return nullptr;
+      if (lane < U) {
+        const int nn = 2 + t.g * U + lane;
+        // rows above the neighbour's diagonal are zero; rows past N feed nothing that is stored
+        if (nn >= c0 - 1 && (unsigned)nn < N) return ev_in + nn;
+      } else if (lane == U && (t.g == g0 || t.tin == 0)) {
+        return ee_in + t.p;
+      } else if (lane == U + 1 && t.tin == 0 && t.p >= 1 && 2 + t.g * U >= c0 - 1) {
+        return ee_in + t.p - 1;
+      }
+      return nullptr;
+    };
+    auto edge_issue = [&](const trip_pos &t) -> unsigned long long {
+      const unsigned long long *ptr = edge_ptr(t);
+      return ptr ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    };
+    auto edge_take = [&](const trip_pos &t, unsigned long long val) {
+      if (!has_left) return;
+      const unsigned long long *ptr = edge_ptr(t);
+      bool ready = (ptr == nullptr) || (val != 0) || aborted;
+      if (!__all(ready)) {
+        const unsigned long long t_begin = wall_clock64();
+        for (;;) {
+          if (!ready) {
+            val = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready = val != 0;
+          }
+          if (__all(ready)) break;
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || wall_clock64() - t_begin > X.timeout) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 1u + (unsigned)t.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            aborted = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const int ex = (int)(long long)(val - CH_EOFF);
+      const int e_cur = __builtin_amdgcn_readlane(ex, U), e_prev = __builtin_amdgcn_readlane(ex, U + 1);
+      double x = __longlong_as_double((long long)val);
+      if (lane == 0 && t.tin == 0 && t.p >= 1 && ptr != nullptr) x = ldexp(x, e_prev - e_cur);
+      if (lane < U) edge_in[t.g & 1][lane] = (ptr != nullptr) ? x : 0.0;
+      if (lane == U && ptr != nullptr) edge_ep[t.p & 1] = e_cur;
+    };
+    auto publish = [&](const trip_pos &t) {
+      if (!has_right) return;
+      if (lane < U) {
+        const double x = vbuf[t.g & 1][lane][OW - 1];
+        __hip_atomic_store(ev_out + 3 + t.g * U + lane, (unsigned long long)__double_as_longlong(x),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (lane == U && (t.g == g0 || t.tin == 0)) {
+        __hip_atomic_store(ee_out + t.p, (unsigned long long)((long long)ebuf[t.p & 1][OW - 1] + (long long)CH_EOFF),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    trip_pos qi, qt, qp;  // next trip to issue loads for / to take / to publish
+    qt.init(g0, TP);
+    qp = qt;
+    edge_take(qt, edge_issue(qt));
+    qt.next(TP);
+    qi = qt;
+    unsigned long long pend[CH_K];
+#pragma unroll
+    for (int k = 0; k < CH_K; k++) {
+      pend[k] = edge_issue(qi);
+      qi.next(TP);
+    }
+    lds_barrier();  // B0
+    for (int gb = g0; gb < G; gb += CH_K) {
+#pragma unroll
+      for (int k = 0; k < CH_K; k++) {
+        const int g = gb + k;
+        if (g >= G) break;
+        CH_MARK();
+        if (g > g0) {
+          publish(qp);
+          qp.next(TP);
+        }
+        if (g + 1 < G) {
+          edge_take(qt, pend[k]);  // trip g + 1
+          qt.next(TP);
+          pend[k] = edge_issue(qi);  // trip g + 1 + CH_K
+          qi.next(TP);
+        }
+        CH_ACC();
+        lds_barrier();
+      }
+    }
+    publish(qp);  // trip G - 1
+  }
+  CH_DUMP();
+}
+
 static int ensure_logtab() {
   static bool done[64] = {false};
   int dev = 0;
@@ -1148,22 +1491,45 @@ static unsigned frontier_pitch(unsigned M) { return (unsigned)align_up((size_t)M
 // periods of a launch never exceed this (R <= 252, P >= 1 ... in practice 2-4)
 #define STB_PPL_MAX 8
 
-extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
-  (void)N;
-  size_t W = frontier_pitch(M);
-  return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) +
-         (size_t)D * STB_EP_RING * STB_PPL_MAX * W * sizeof(int) + 512;
-}
-
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
   if (!s || !*s) return dflt;
   return atoi(s);
 }
 
+// geometry of the chain form (k_fill_chain): column blocks per table, trips, edge stream lengths
+struct chain_geom {
+  int C, RH, B, G;
+  uint64_t EV, NPmax;
+  size_t bytes;  // header + edge streams for D tables
+};
+static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
+  chain_geom g;
+  g.C = env_int("STB_CHAIN_C", 2) == 1 ? 1 : 2;
+  g.RH = env_int("STB_CHAIN_RH", 2);
+  if (g.RH != 1 && g.RH != 2 && g.RH != 4) g.RH = 2;
+  const unsigned cols = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
+  g.B = (int)((cols + 64 * g.C - 1) / (64 * g.C));
+  if (g.B < 1) g.B = 1;
+  g.G = (N > 2) ? (int)((N - 2 + CH_U - 1) / CH_U) : 0;
+  g.EV = (uint64_t)3 + (uint64_t)g.G * CH_U + 8;
+  g.NPmax = (uint64_t)g.G + 2;
+  g.bytes = 256 + (size_t)D * g.B * (g.EV + g.NPmax) * sizeof(unsigned long long);
+  return g;
+}
+
+extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
+  size_t W = frontier_pitch(M);
+  const size_t ring = (size_t)D * STB_EP_RING * STB_PPL_MAX * W * sizeof(int);
+  const size_t chain = (N >= 3 && M >= 2 && D >= 1) ? chain_geometry(N, M, D).bytes + 256 : 0;
+  return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) +
+         (ring > chain ? ring : chain) + 512;
+}
+
 #define STB_MODE_BFP 3    // S table, block-floating cells + table log (default)
 #define STB_MODE_SPLIT 4  // same arithmetic, recurrence and log in separate kernels / streams
 #define STB_MODE_PC 5     // same arithmetic, producer wave + consumer waves through LDS
+#define STB_MODE_CHAIN 6  // same arithmetic, one launch: column blocks chained through edge granules
 
 // auxiliary streams and an event pool for the split variant (per host thread and device)
 struct split_ctx {
@@ -1248,11 +1614,32 @@ extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
   return 0;
 }
 
+// header of the last chain fill issued by this thread (ticket, error code, error detail)
+static thread_local unsigned *g_chain_hdr = nullptr;
+
+extern "C" int stb_fill_status(void) {
+  STB_ENTRY;
+  if (!g_chain_hdr) return 0;
+  unsigned h[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(h, g_chain_hdr, sizeof(h), hipMemcpyDeviceToHost));  // waits for the fill
+  if (h[1] != 0)
+    return fail("stb_fill_S: chain fill gave up waiting for a neighbour block (trip %u, block %u of table %u)",
+                h[1] - 1, h[2] & 0xffffu, h[2] >> 16);
+  return 0;
+}
+
 extern "C" int stb_default_variant(void);
 extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
   const bool few = (uint64_t)D * M < 25000;
   const int v = stb_default_variant();
-  const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : (few ? 1 : 2);
+  const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : v == STB_FILL_CHAIN ? 3 : (few ? 1 : 2);
+  if (form == 3) {
+    const chain_geom g = chain_geometry(N, M, D);
+    if (C_out) *C_out = g.C;
+    if (R_out) *R_out = (int)N;
+    if (launches) *launches = 1;
+    return 3;
+  }
   int C = env_int("STB_FILL_C", form == 2 ? 4 : 2);
   int R = env_int("STB_FILL_R", form == 2 ? 128 : form == 1 ? 96 : 64);
   if (form == 2 && R > 128) R = 128;
@@ -1260,7 +1647,7 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
   if (launches) *launches = ((int)N - 1 + R - 1) / R;
-  return form; /* 0 fused (k_fill_bfp), 1 split (k_rec + k_logconv), 2 producer/consumer (k_fill_pc) */
+  return form; /* 0 fused (k_fill_bfp), 1 split (k_rec + k_logconv), 2 producer/consumer (k_fill_pc), 3 chain */
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -1292,7 +1679,8 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
   // rows per renormalisation period
   int P = 1;
-  if (mode == STB_MODE_PC && N >= (1u << 27)) mode = STB_MODE_BFP;  // see the scale bound in k_fill_pc
+  if ((mode == STB_MODE_PC || mode == STB_MODE_CHAIN) && N >= (1u << 27)) mode = STB_MODE_BFP;  // see the scale bound in k_fill_pc
+  if (mode == STB_MODE_CHAIN && N < 3) mode = STB_MODE_BFP;
   if (mode == STB_MODE_PC) {
     // geometry is fixed by the block shape: 256 columns per block, NCW consumer waves
     C = 4;
@@ -1302,7 +1690,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     if (R > H) R = H;
     if (R < 1) R = 1;
   }
-  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT || mode == STB_MODE_PC) {
+  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT || mode == STB_MODE_PC || mode == STB_MODE_CHAIN) {
     if (ensure_logtab()) return 1;
     // A cell grows per row by U^n_m = n - m a + S^n_{m-1}/S^n_m, and the last term reaches n(n-1)/2
     // next to the diagonal, so the bound is N^2 per row, not N.  v starts at 2^-BFP_BIAS and the
@@ -1310,7 +1698,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     int bits = 1;
     while ((1ull << bits) < (unsigned long long)N) bits++;
     bits = 2 * bits + 1;
-    P = (mode == STB_MODE_PC ? 1450 : 1700) / bits;  // the producer/consumer form starts at 2^-700
+    P = (mode == STB_MODE_PC || mode == STB_MODE_CHAIN ? 1450 : 1700) / bits;  // these start at 2^-700
     int Penv = env_int("STB_FILL_P", 0);
     if (Penv > 0 && Penv < P) P = Penv;
     if (P < 1) P = 1;
@@ -1338,6 +1726,95 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
   const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  if (mode == STB_MODE_CHAIN) {
+    const chain_geom cg = chain_geometry(N, M, D);
+    int Pc = 1450;
+    {
+      int bits = 1;
+      while ((1ull << bits) < (unsigned long long)N) bits++;
+      Pc /= 2 * bits + 1;
+    }
+    const int Penv = env_int("STB_FILL_P", 0);
+    if (Penv > 0 && Penv < Pc) Pc = Penv;
+    chain_args X;
+    X.TP = Pc / CH_U;
+    if (X.TP < 1) return fail("%s: renormalisation period %d shorter than a trip", who, Pc);
+    X.G = cg.G;
+    X.D = D;
+    X.B = cg.B;
+    X.EV = cg.EV;
+    X.NP = (uint64_t)(cg.G / X.TP + 2);
+    char *cb = (char *)align_up((size_t)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int)), 256);
+    if ((size_t)(cb - (char *)d_ws) + cg.bytes > ws_bytes) return fail("%s: workspace too small for the chain form", who);
+    X.hdr = (unsigned *)cb;
+    X.edge_e = (unsigned long long *)(cb + 256);
+    X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
+    X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
+    const size_t zero_bytes = 256 + (size_t)D * cg.B * (X.NP + X.EV) * sizeof(unsigned long long);
+    HIPCHK(hipMemsetAsync(cb, 0, align_up(zero_bytes, 16), st));
+    g_chain_hdr = X.hdr;
+    hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+      while (g_prof.made < g_prof.used + 2) {
+        if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+        g_prof.made++;
+      }
+      if (g_prof.made >= g_prof.used + 2) {
+        p0 = g_prof.ev[g_prof.used];
+        p1 = g_prof.ev[g_prof.used + 1];
+        g_prof.used += 2;
+      }
+    }
+#ifdef STB_STAMPS
+    static unsigned long long *h_cdbg = nullptr;
+    {
+      unsigned long long *z = nullptr;
+      if (getenv("STB_STAMP_FILE")) {
+        if (!h_cdbg) HIPCHK(hipMalloc(&h_cdbg, sizeof(unsigned long long) * 512 * 16 * 4));
+        HIPCHK(hipMemsetAsync(h_cdbg, 0, sizeof(unsigned long long) * 512 * 16 * 4, st));
+        z = h_cdbg;
+      }
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dbg), &z, sizeof(z), 0, hipMemcpyHostToDevice, st));
+    }
+#endif
+    const dim3 grid((unsigned)cg.B * (unsigned)D);
+#define STB_LAUNCH_CHAIN(CC, RR)                                                                           \
+  do {                                                                                                     \
+    if (p0)                                                                                                \
+      hipExtLaunchKernelGGL((k_fill_chain<CC, RR>), grid, dim3(64 * (2 + CC * RR)), 0, st, p0, p1, 0, A, X); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((k_fill_chain<CC, RR>), grid, dim3(64 * (2 + CC * RR)), 0, st, A, X);             \
+  } while (0)
+    if (cg.C == 1) {
+      if (cg.RH == 1) STB_LAUNCH_CHAIN(1, 1);
+      else if (cg.RH == 2) STB_LAUNCH_CHAIN(1, 2);
+      else STB_LAUNCH_CHAIN(1, 4);
+    } else {
+      if (cg.RH == 1) STB_LAUNCH_CHAIN(2, 1);
+      else if (cg.RH == 2) STB_LAUNCH_CHAIN(2, 2);
+      else STB_LAUNCH_CHAIN(2, 4);
+    }
+#undef STB_LAUNCH_CHAIN
+    HIPCHK(hipGetLastError());
+#ifdef STB_STAMPS
+    if (getenv("STB_STAMP_FILE") && h_cdbg) {
+      HIPCHK(hipStreamSynchronize(st));
+      const size_t cnt = (size_t)512 * 16 * 4;
+      unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+      HIPCHK(hipMemcpy(h, h_cdbg, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("STB_STAMP_FILE"), "w");
+      for (int jj = 0; jj < 512; jj++)
+        for (int w = 0; w < 16; w++) {
+          unsigned long long *q = h + ((size_t)jj * 16 + w) * 4;
+          if (q[1]) fprintf(f, "%d %d %llu %llu %llu\n", jj, w, q[0], q[1], q[2]);
+        }
+      fclose(f);
+      free(h);
+    }
+#endif
+    return 0;
+  }
   if (mode == STB_MODE_PC) {
     const int ncw = (256 - H) / 64;
     const int OW = 64 * ncw;
@@ -1524,7 +2001,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 extern "C" int stb_default_variant(void) {
   const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
   return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
-          v == STB_FILL_PC)
+          v == STB_FILL_PC || v == STB_FILL_CHAIN)
              ? v
              : STB_FILL_SCALED;
 }
@@ -1543,6 +2020,7 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
                    : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
                    : variant == STB_FILL_FUSED ? STB_MODE_BFP
                    : variant == STB_FILL_PC ? STB_MODE_PC
+                   : variant == STB_FILL_CHAIN ? STB_MODE_CHAIN
                    : (few ? STB_MODE_SPLIT : STB_MODE_PC);
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
