@@ -1126,58 +1126,73 @@ __global__ __launch_bounds__(256) void k_s1(const double *a, double *S1, uint64_
 // ---- chain form: ONE launch per fill, column blocks hand their right edge to the next block ------
 //
 // The forms above advance every strip by R rows per launch and recompute an R-column halo so that
-// strips never talk to each other.  Here a column block owns its 64*C columns for ALL rows: the
-// value its first column needs from the left (the previous block's last column, one row up) comes
-// through global memory, so there is no halo, no launch per row block and no frontier round trip.
+// strips never talk to each other.  Here a column block owns its 64*P columns for ALL rows: what a
+// column needs from its left neighbour (one row up) travels wave to wave, so there is no halo, no
+// launch per row block and no frontier round trip.  Nothing in the steady state is a barrier: the
+// waves of a block run free and meet through counters in LDS.
 //
-//  * wave 0 (producer) carries the recurrence of the block's 64*C columns, C per lane sharing one
-//    exponent, and writes raw significands to a two-slot LDS ring, CH_U rows (a "trip") per slot;
-//  * the consumer waves turn slot q-1 into logs and store them while the producer fills slot q
-//    (C slices of 64 columns x RH groups of CH_U/RH rows);
-//  * the comm wave publishes the last column of slot q-1 as 8-byte granules (the raw double; 0 = not
-//    yet written: every value a neighbour will ever ask for is > 0) with write-through stores, and
-//    polls the left neighbour's granules for trip q+1 with L1-bypassing loads into LDS.  The data is
-//    its own flag, so no fence or ordering is needed (one aligned 8-byte store per granule).
+//  * P producer waves, 64 columns each (one per lane, DPP shift inside the wave), carry the
+//    recurrence and write raw significands into an LDS ring of CH_RD trips (a trip = CH_U rows).
+//    Producer w reads the last column of producer w-1 from that ring, one trip behind it.
+//  * NC consumer waves take (trip, slice) items round-robin, turn 8 rows x 64 columns into logs
+//    (stage-major, as in k_fill_pc) and store them; they are off the producers' critical path.
+//  * The publisher wave writes the block's last column to global memory as 8-byte granules: the raw
+//    double per row (-0.0 for an exact zero, so that 0 = "not written yet") and the lane exponent
+//    per trip, with write-through stores.  The fetcher wave of the next block reads 128 rows per
+//    round trip with L1-bypassing loads, delivers the leading complete trips into an LDS ring and
+//    re-reads the rest.  A granule is its own flag (one aligned 8-byte store), so the hand-off needs
+//    no fence and no ordering.
 //
 // Block (d, j) starts at the trip in which the diagonal enters its first column and lags its left
-// neighbour by the hand-off latency; since a triangular table starts column block j at row 64*C*j
-// anyway the skew is free.  Blocks take their (j, d) from an atomic ticket, j-major, so a block only
-// ever waits for a block with a smaller ticket, i.e. one that is running or done: forward progress
-// does not depend on dispatch order or on how many blocks are resident.  Every poll is bounded by
-// wall-clock time; on expiry the block records an error and stops waiting (stb_fill_status).
-#define CH_U 8
-#define CH_K 8  // trips of look-ahead of the edge loads
+// neighbour by the hand-off latency; a triangular table starts column block j at row 64*P*j anyway.
+// Blocks take their (j, d) from an atomic ticket, j-major, so a block only ever waits for a block
+// with a smaller ticket, i.e. one that is running or done: forward progress does not depend on
+// dispatch order or on how many blocks are resident.  Every wait is bounded by wall-clock time; on
+// expiry the block records an error, stops waiting and runs to its end (stb_fill_status).
+#define CH_U 8    // rows per trip
+#define CH_RD 8   // trips in the significand ring (power of two)
+#define CH_RE 32  // trips in the edge ring (power of two, >= 2 * 16)
 #define CH_EOFF (1ull << 40)
+#define CH_NEGZERO 0x8000000000000000ull
 
 struct chain_args {
   unsigned *hdr;               // [0] ticket, [1] error code, [2] error detail; zeroed per fill
   unsigned long long *edge_v;  // [D][B][EV]  last column of a block, indexed by row
-  unsigned long long *edge_e;  // [D][B][NP]  its exponent per period, + CH_EOFF
+  unsigned long long *edge_e;  // [D][B][NP]  its lane exponent, indexed by trip, + CH_EOFF
   uint64_t EV, NP;
   int D, B;                    // tables, column blocks per table
   int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
-  unsigned long long timeout;  // wall_clock64 ticks a poll may last
+  unsigned long long timeout;  // wall_clock64 ticks a wait may last
 };
 
-template <int C, int RH>
-__global__ __launch_bounds__(64 * (2 + C * RH)) void k_fill_chain(fill_args A, chain_args X) {
-  constexpr int U = CH_U;
-  constexpr int OW = 64 * C;      // columns of a block
-  constexpr int UR = U / RH;      // rows of a trip one consumer wave converts
-  constexpr int NW = 2 + C * RH;  // waves: producer, C*RH consumers, comm
-  constexpr int COMM = (NW > 4) ? 4 : NW - 1;
-  static_assert(U % RH == 0 && UR >= 1, "rows per consumer");
-  static_assert(OW <= 128, "a block's overhang must fit the row slack");
+__device__ __forceinline__ int lds_peek(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS executes one wave's instructions in order: data written before the counter is visible to
+// whoever sees the counter.  The empty asm keeps the compiler from reordering around it.
+__device__ __forceinline__ void lds_post(int *p, int v) {
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+template <int P, int NC>
+__global__ __launch_bounds__(64 * (P + NC + 2)) void k_fill_chain(fill_args A, chain_args X) {
+  constexpr int U = CH_U, RD = CH_RD, RE = CH_RE;
+  constexpr int OW = 64 * P;  // columns of a block
+  static_assert(P >= 1 && P <= NC && P + NC + 2 <= 16, "block shape");
   __shared__ double2 lt[128];
-  __shared__ __attribute__((aligned(16))) double vbuf[2][U][OW];
-  __shared__ int ebuf[2][OW];
-  __shared__ __attribute__((aligned(16))) double edge_in[2][U];
-  __shared__ int edge_ep[2];
+  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][OW];
+  __shared__ int ebuf[4][OW];
+  __shared__ int slot_p[RD][P];
+  __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
+  __shared__ int edge_e[RE];
+  __shared__ int prod_done[P], cons_cnt[NC], pub_done, edge_ready, s_abort;
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = g_logtab[tid];
-  if (tid < 2 * U) (&edge_in[0][0])[tid] = 0.0;
+  for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
   __syncthreads();
   const int j = (int)(s_ticket / (unsigned)X.D);
   const int d = (int)(s_ticket % (unsigned)X.D);
@@ -1185,285 +1200,326 @@ __global__ __launch_bounds__(64 * (2 + C * RH)) void k_fill_chain(fill_args A, c
 
   const unsigned N = A.N, M = A.M;
   const int TP = X.TP, G = X.G;
-  const int c0 = 1 + j * OW;                       // first column of the block
-  const int g0 = (c0 <= 3) ? 0 : (c0 - 3) / U;     // trip in which the diagonal reaches column c0
+  const int c0 = 1 + j * OW;  // first column of the block
+  auto first_trip = [&](int w) {  // trip in which the diagonal reaches the first column of slice w
+    const int c = c0 + 64 * w;
+    return (c <= 3) ? 0 : (c - 3) / U;
+  };
+  const int g0b = first_trip(0);
+  const bool has_left = j > 0, has_right = j < X.B - 1;
   double *table = A.tables + (uint64_t)d * A.tstride;
+  if (tid < P) prod_done[tid] = first_trip(tid);
+  if (tid < NC) cons_cnt[tid] = 0;
+  if (tid == 0) {
+    pub_done = has_right ? first_trip(P - 1) : 0x7fffffff;
+    edge_ready = has_left ? g0b : 0x7fffffff;
+    s_abort = 0;
+  }
+  __syncthreads();
 
-  // position of a trip inside the renormalisation periods, advanced without dividing
-  struct trip_pos {
-    int g, p, tin;
-    __device__ __forceinline__ void init(int g_, int TP_) {
-      g = g_;
-      p = g_ / TP_;
-      tin = g_ - p * TP_;
+  bool aborted = false;
+#ifdef STB_STAMPS
+  unsigned long long t_wait = 0, t_start = __builtin_amdgcn_s_memtime();
+  int n_wait = 0;
+#define CH_WAITED() (t_wait += __builtin_amdgcn_s_memtime() - t_w0, n_wait++)
+#else
+#define CH_WAITED() do {} while (0)
+#endif
+  // wait until *cnt >= need; bounded: on expiry (or when another wave gave up) stop waiting for good
+  auto wait_ge = [&](const int *cnt, int need, unsigned code) {
+    if (aborted || lds_peek(cnt) >= need) return;
+#ifdef STB_STAMPS
+    const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned long long t_begin = wall_clock64();
+    for (;;) {
+      __builtin_amdgcn_s_sleep(1);
+      if (lds_peek(cnt) >= need) {
+        CH_WAITED();
+        return;
+      }
+      if (lds_peek(&s_abort)) break;
+      if ((unsigned long long)wall_clock64() - t_begin > X.timeout) {
+        if (lane == 0) {
+          __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.hdr + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        break;
+      }
     }
-    __device__ __forceinline__ void next(int TP_) {
-      g++;
-      if (++tin == TP_) {
+    aborted = true;
+  };
+
+  if (wave < P) {
+    // ================= producers =================
+    __builtin_amdgcn_s_setprio(3);
+    const int w = wave;
+    const int g0w = first_trip(w);
+    const int col = 64 * w + lane;  // my column inside the block
+    const int c = c0 + col;
+    const double a = A.a[d];
+    // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
+    double v = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+    double coef = (double)(2 + g0w * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0w
+    double s = 1.0;
+    int ep = 1 + PC_BIAS;
+    int p = g0w / TP, tin = g0w - p * TP;
+    // the consumer item that last used the ring slot trip g is about to overwrite
+    // the consumer item that last used the ring slot a trip is about to overwrite
+    int chk_i = (g0w - RD - g0b) * P + w;
+    int chk_c = (chk_i >= 0) ? chk_i % NC : w, chk_k = (chk_i >= 0) ? chk_i / NC : 0;  // (first i >= 0 is w)
+    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w - 1];
+    const int *next_cnt = (w < P - 1) ? &prod_done[w + 1] : &pub_done;
+    // What a trip needs from the other waves -- the left neighbour's progress, the consumers' and
+    // the right neighbour's progress on the ring slot it overwrites -- and its U left inputs are
+    // read one trip AHEAD, under the previous trip's arithmetic, so that no LDS round trip sits on
+    // the row chain.  The inputs are speculative: they are valid if the counter read BEFORE them
+    // (LDS is in order) already covered the trip; otherwise wait and read again.
+    int n_left, n_cons, n_next;
+    double ne[U];
+    auto load_left = [&](double(&x)[U], int g) {
+      if (w == 0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = edge_in[(g & (RE - 1)) * U + u];
+      } else {
+        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][64 * w - 1];
+#pragma unroll
+        for (int u = 1; u < U; u++) x[u] = vbuf[g & (RD - 1)][u - 1][64 * w - 1];
+      }
+    };
+    auto look_ahead = [&](int g) {
+      n_left = lds_peek(left_cnt);
+      n_cons = lds_peek(&cons_cnt[chk_c]);
+      n_next = lds_peek(next_cnt);
+      asm volatile("" ::: "memory");
+      load_left(ne, g);
+    };
+    look_ahead(g0w);
+    for (int g = g0w; g < G; g++) {
+      double e[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) e[u] = ne[u];
+      const bool chk = chk_i >= 0;
+      const int next_need = (w < P - 1) ? g - RD + 2 : g - RD + 1;
+      if (n_left < g + 1 || (chk && (n_cons < chk_k + 1 || n_next < next_need))) {
+        wait_ge(left_cnt, g + 1, 0x100u + (unsigned)g);
+        if (chk) {
+          wait_ge(&cons_cnt[chk_c], chk_k + 1, 0x300u + (unsigned)g);  // slot g % RD converted
+          wait_ge(next_cnt, next_need, 0x400u + (unsigned)g);          // ... read by w+1 / published
+        }
+        asm volatile("" ::: "memory");
+        load_left(e, g);
+      }
+      if (chk) {
+        chk_c += P;
+        if (chk_c >= NC) {
+          chk_c -= NC;
+          chk_k++;
+        }
+      }
+      chk_i += P;
+      if (g + 1 < G) look_ahead(g + 1);
+      if (g == g0w || tin == 0) {
+        // ---- period set-up ----
+        if (g != g0w && v != 0.0) {  // renormalise: significand back to 2^-PC_BIAS * [0.5,1)
+          const int k = __builtin_amdgcn_frexp_exp(v);
+          v = ldexp(v, -k - PC_BIAS);
+          ep += k + PC_BIAS;
+        }
+        // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
+        int el = ep;
+        if (w == 0) {
+          if (has_left) el = edge_e[g & (RE - 1)];
+        } else {
+          el = ebuf[p & 3][64 * w - 1];
+          // the row above the first row of a period was produced under the previous exponent
+          if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 3][64 * w - 1] - el);
+        }
+        int dl = wave_shr1(ep, ep) - ep;
+        if (lane == 0) dl = el - ep;
+        s = ldexp(1.0, min(max(dl, -1100), 220));
+        ebuf[p & 3][col] = ep;
+      }
+      if (lane == 0) slot_p[g & (RD - 1)][w] = p & 3;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const double t0 = wave_shr1(v, e[u]) * s;
+        v = fma(coef, v, t0);
+        coef += 1.0;
+        vbuf[g & (RD - 1)][u][col] = v;
+      }
+      lds_post(&prod_done[w], g + 1);
+      if (++tin == TP) {
         tin = 0;
         p++;
       }
     }
-  };
-
-#ifdef STB_STAMPS
-  unsigned long long t_work = 0, t_begin = __builtin_amdgcn_s_memtime(), t_mark = 0;
-  int n_trips = 0;
-#define CH_MARK() (t_mark = __builtin_amdgcn_s_memtime())
-#define CH_ACC() (t_work += __builtin_amdgcn_s_memtime() - t_mark, n_trips++)
-#define CH_DUMP()                                                                      \
-  do {                                                                                 \
-    if (g_dbg && lane == 0 && d == 0 && j < 512) {                                     \
-      unsigned long long *q_ = g_dbg + ((size_t)j * 16 + wave) * 4;                    \
-      q_[0] = t_work;                                                                  \
-      q_[1] = __builtin_amdgcn_s_memtime() - t_begin;                                  \
-      q_[2] = n_trips;                                                                 \
-    }                                                                                  \
-  } while (0)
-#else
-#define CH_MARK() do {} while (0)
-#define CH_ACC() do {} while (0)
-#define CH_DUMP() do {} while (0)
-#endif
-
-  if (wave == 0) {
-    // ================= producer =================
-    __builtin_amdgcn_s_setprio(3);
-    const double a = A.a[d];
-    double v[C], coef[C], s = 1.0;
-    int ep = 1 + PC_BIAS;
-#pragma unroll
-    for (int i = 0; i < C; i++) {
-      const int c = c0 + lane * C + i;
-      // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; every other block starts above the diagonal
-      v[i] = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
-      coef[i] = (double)(2 + g0 * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0
-    }
-    lds_barrier();  // B0: the comm wave has fetched the edge of trip g0
-    trip_pos q;
-    q.init(g0, TP);
-    while (q.g < G) {
-      // ---- period set-up: freeze the scale of the cross-lane input (bounds: see k_fill_pc) ----
-      {
-        int dl = wave_shr1(ep, ep) - ep;
-        if (lane == 0) dl = (j == 0) ? 0 : edge_ep[q.p & 1] - ep;
-        s = ldexp(1.0, min(max(dl, -1100), 220));
-#pragma unroll
-        for (int i = 0; i < C; i++) ebuf[q.p & 1][lane * C + i] = ep;
-      }
-      const int gend = min(G, q.g + (TP - q.tin));
-      for (int g = q.g; g < gend; g++) {
-        CH_MARK();
-        double e[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) e[u] = edge_in[g & 1][u];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const double t0 = wave_shr1(v[C - 1], e[u]) * s;
-#pragma unroll
-          for (int i = C - 1; i > 0; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
-          v[0] = fma(coef[0], v[0], t0);
-#pragma unroll
-          for (int i = 0; i < C; i++) coef[i] += 1.0;
-          if (C == 1) {
-            vbuf[g & 1][u][lane] = v[0];
-          } else {
-#pragma unroll
-            for (int i = 0; i < C; i += 2)
-              *reinterpret_cast<double2 *>(&vbuf[g & 1][u][lane * C + i]) = make_double2(v[i], v[i + 1]);
-          }
-        }
-        CH_ACC();
-        lds_barrier();
-      }
-      q.g = gend;
-      q.tin = 0;
-      q.p++;
-      if (q.g < G) {
-        // renormalise the lane: largest significand back to 2^-PC_BIAS * [0.5,1)
-        int kmax = -4000;
-#pragma unroll
-        for (int i = 0; i < C; i++)
-          if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
-        if (kmax > -4000) {
-#pragma unroll
-          for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
-          ep += kmax + PC_BIAS;
-        }
-      }
-    }
-  } else if (wave != COMM) {
+  } else if (wave < P + NC) {
     // ================= consumers =================
-    const int ci = wave - 1 - (wave > COMM ? 1 : 0);
-    const int slice = ci % C, rh = ci / C;
-    const int ridx = slice * 64 + lane;  // my column inside the block
-    const int cc = c0 + ridx;
-    const int coff = cc - 2;             // its offset in a table row (column 1: the slack before it)
-    uint64_t rowoff = stb_row_offset((unsigned)(3 + g0 * U), M);
-    trip_pos q;  // the trip being converted (one behind the producer)
-    q.init(g0, TP);
-    lds_barrier();  // B0
-    for (int g = g0; g <= G; g++) {
-      CH_MARK();
-      if (g > g0) {
-        const int gt = q.g;
-        const int myep = ebuf[q.p & 1][ridx];
-        const int r0 = 3 + gt * U;
+    const int ci = wave - P;
+    int w = ci % P, t = g0b + ci / P;
+    int done = 0;
+    for (; t < G;) {
+      if (t >= first_trip(w)) {
+        wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
+        const int ridx = 64 * w + lane;
+        const int cc = c0 + ridx;
+        const int coff = cc - 2;  // offset in a table row (column 1: the slack before the row)
+        const int slot = t & (RD - 1);
+        const int myep = ebuf[slot_p[slot][w]][ridx];
+        const int r0 = 3 + t * U;
         const unsigned pitch = stb_row_pitch((unsigned)r0, M);
         const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch &&
-                          !(j == 0 && gt == 0);
-        double *rowbase = table + rowoff;
+                          !(j == 0 && t == 0 && w == 0);
+        double *rowbase = table + stb_row_offset((unsigned)r0, M);
         if (fast) {
-          double x[UR], z[UR], kf[UR], r[UR], pl[UR];
-          double2 t[UR];
+          double x[U], z[U], kf[U], r[U], pl[U];
+          double2 tt[U];
 #pragma unroll
-          for (int u = 0; u < UR; u++) x[u] = vbuf[gt & 1][rh * UR + u][ridx];
+          for (int u = 0; u < U; u++) x[u] = vbuf[slot][u][ridx];
 #pragma unroll
-          for (int u = 0; u < UR; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+          for (int u = 0; u < U; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
 #pragma unroll
-          for (int u = 0; u < UR; u++) {
+          for (int u = 0; u < U; u++) {
             const int hi = __double2hiint(x[u]);
             z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
             kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
           }
 #pragma unroll
-          for (int u = 0; u < UR; u++) r[u] = fma(z[u], t[u].x, -1.0);
+          for (int u = 0; u < U; u++) r[u] = fma(z[u], tt[u].x, -1.0);
 #pragma unroll
-          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], 0.2, -0.25);
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], 0.2, -0.25);
 #pragma unroll
-          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
 #pragma unroll
-          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], -0.5);
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], -0.5);
 #pragma unroll
-          for (int u = 0; u < UR; u++) pl[u] = fma(r[u], pl[u], 1.0);
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0);
 #pragma unroll
-          for (int u = 0; u < UR; u++)
-            rowbase[(size_t)(rh * UR + u) * pitch + coff] =
-                fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
-          rowoff += (uint64_t)U * pitch;
+          for (int u = 0; u < U; u++)
+            rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
         } else {
           for (int u = 0; u < U; u++) {
             const int rr = r0 + u;
-            if (u / UR == rh && (unsigned)rr <= N && cc >= 2)
-              rowbase[coff] = bfp_log(vbuf[gt & 1][u][ridx], myep, lt);
-            const unsigned pt = stb_row_pitch((unsigned)rr, M);
-            rowbase += pt;
-            rowoff += pt;
+            if ((unsigned)rr <= N && cc >= 2) rowbase[coff] = bfp_log(vbuf[slot][u][ridx], myep, lt);
+            rowbase += stb_row_pitch((unsigned)rr, M);
           }
         }
-        q.next(TP);
       }
-      CH_ACC();
-      if (g < G) lds_barrier();
+      done++;
+      lds_post(&cons_cnt[ci], done);
+      w += NC % P;
+      t += NC / P;
+      if (w >= P) {
+        w -= P;
+        t++;
+      }
+    }
+  } else if (wave == P + NC) {
+    // ================= publisher =================
+    if (has_right) {
+      unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
+      unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
+      for (int t = first_trip(P - 1); t < G; t++) {
+        wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);
+        const int slot = t & (RD - 1);
+        if (lane < U) {
+          unsigned long long b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][OW - 1]);
+          if ((b << 1) == 0) b = CH_NEGZERO;
+          __hip_atomic_store(ev_out + 3 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == U) {
+          const long long ex = (long long)ebuf[slot_p[slot][P - 1]][OW - 1] + (long long)CH_EOFF;
+          __hip_atomic_store(ee_out + t, (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_post(&pub_done, t + 1);
+      }
     }
   } else {
-    // ================= comm =================
-    const bool has_left = j > 0, has_right = j < X.B - 1;
-    const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (has_left ? j - 1 : 0)) * X.EV;
-    unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
-    const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (has_left ? j - 1 : 0)) * X.NP;
-    unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
-    bool aborted = false;
-    // The left edge for a trip: lanes 0..U-1 one row each (the value one row above the row they
-    // feed), lane U the neighbour's exponent when the trip opens a period (or the block), lane U+1
-    // the exponent of the period before: the row above the first row of a period was produced
-    // under it.  Loads are issued CH_K trips ahead (edge_issue) so that their latency overlaps the
-    // trips in between; edge_take polls only if a granule was not there yet.
-    auto edge_ptr = [&](const trip_pos &t) -> const unsigned long long * {
-      if (!has_left || t.g >= G) return nullptr;
-      if (lane < U) {
-        const int nn = 2 + t.g * U + lane;
-        // rows above the neighbour's diagonal are zero; rows past N feed nothing that is stored
-        if (nn >= c0 - 1 && (unsigned)nn < N) return ev_in + nn;
-      } else if (lane == U && (t.g == g0 || t.tin == 0)) {
-        return ee_in + t.p;
-      } else if (lane == U + 1 && t.tin == 0 && t.p >= 1 && 2 + t.g * U >= c0 - 1) {
-        return ee_in + t.p - 1;
-      }
-      return nullptr;
-    };
-    auto edge_issue = [&](const trip_pos &t) -> unsigned long long {
-      const unsigned long long *ptr = edge_ptr(t);
-      return ptr ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    };
-    auto edge_take = [&](const trip_pos &t, unsigned long long val) {
-      if (!has_left) return;
-      const unsigned long long *ptr = edge_ptr(t);
-      bool ready = (ptr == nullptr) || (val != 0) || aborted;
-      if (!__all(ready)) {
-        const unsigned long long t_begin = wall_clock64();
-        for (;;) {
-          if (!ready) {
-            val = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ready = val != 0;
+    // ================= fetcher =================
+    if (has_left) {
+      const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
+      const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (j - 1)) * X.NP;
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      for (int t = g0b; t < G;) {
+        // trips t .. t+nt-1 may be written: their ring slots were read by the first producer
+        int lim = lds_peek(&prod_done[0]) + RE;
+        if (lim > G) lim = G;
+        if (lim <= t) {
+          wait_ge(&prod_done[0], t - RE + 1, 0x800u + (unsigned)t);
+          if (aborted) break;
+          continue;
+        }
+        const int nt = min(16, lim - t);
+        // 128 rows (the values one row above the rows they feed) and 17 trip exponents, one round trip
+        const int row0 = 2 + t * U;
+        const int ra = row0 + lane, rb = row0 + 64 + lane;
+        const bool need_a = lane < 8 * nt, need_b = 64 + lane < 8 * nt;
+        const bool need_e = lane <= nt;
+        unsigned long long va = 0, vb = 0, ve = 0;
+        if (need_a) va = __hip_atomic_load(ev_in + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_b) vb = __hip_atomic_load(ev_in + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_e) ve = __hip_atomic_load(ee_in + t - 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ma = __ballot(!need_a || va != 0);
+        const unsigned long long mb = __ballot(!need_b || vb != 0);
+        const unsigned long long me = __ballot(!need_e || ve != 0);
+        int nr = 0;  // leading trips with all 8 rows, their exponent and the one before it present
+        for (; nr < nt; nr++) {
+          const unsigned long long rows = (nr < 8) ? (ma >> (8 * nr)) : (mb >> (8 * (nr - 8)));
+          if ((rows & 0xffull) != 0xffull || ((me >> nr) & 3ull) != 3ull) break;
+        }
+        if (nr == 0) {
+          if (!timing) {
+            timing = true;
+            t_begin = wall_clock64();
           }
-          if (__all(ready)) break;
           const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || wall_clock64() - t_begin > X.timeout) {
-            if (err == 0 && lane == 0) {
-              __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(X.hdr + 1, 1u + (unsigned)t.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
+            if (lane == 0) {
+              __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (err == 0) {
+                __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 1, 0x900u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
-            aborted = true;
+            lds_post(&edge_ready, 0x7fffffff);  // release the producer: it runs on with stale edges
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(2);
+          continue;
         }
-      }
-      const int ex = (int)(long long)(val - CH_EOFF);
-      const int e_cur = __builtin_amdgcn_readlane(ex, U), e_prev = __builtin_amdgcn_readlane(ex, U + 1);
-      double x = __longlong_as_double((long long)val);
-      if (lane == 0 && t.tin == 0 && t.p >= 1 && ptr != nullptr) x = ldexp(x, e_prev - e_cur);
-      if (lane < U) edge_in[t.g & 1][lane] = (ptr != nullptr) ? x : 0.0;
-      if (lane == U && ptr != nullptr) edge_ep[t.p & 1] = e_cur;
-    };
-    auto publish = [&](const trip_pos &t) {
-      if (!has_right) return;
-      if (lane < U) {
-        const double x = vbuf[t.g & 1][lane][OW - 1];
-        __hip_atomic_store(ev_out + 3 + t.g * U + lane, (unsigned long long)__double_as_longlong(x),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (lane == U && (t.g == g0 || t.tin == 0)) {
-        __hip_atomic_store(ee_out + t.p, (unsigned long long)((long long)ebuf[t.p & 1][OW - 1] + (long long)CH_EOFF),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    };
-    trip_pos qi, qt, qp;  // next trip to issue loads for / to take / to publish
-    qt.init(g0, TP);
-    qp = qt;
-    edge_take(qt, edge_issue(qt));
-    qt.next(TP);
-    qi = qt;
-    unsigned long long pend[CH_K];
-#pragma unroll
-    for (int k = 0; k < CH_K; k++) {
-      pend[k] = edge_issue(qi);
-      qi.next(TP);
-    }
-    lds_barrier();  // B0
-    for (int gb = g0; gb < G; gb += CH_K) {
-#pragma unroll
-      for (int k = 0; k < CH_K; k++) {
-        const int g = gb + k;
-        if (g >= G) break;
-        CH_MARK();
-        if (g > g0) {
-          publish(qp);
-          qp.next(TP);
+        timing = false;
+        // exponent of each row's trip (lane q of ve holds trip t-1+q) and of the trip before it
+        const int ex = (int)(long long)(ve - CH_EOFF);
+        const int ka = lane >> 3, kb = 8 + (lane >> 3);
+        const int ea = __shfl(ex, ka + 1), ea1 = __shfl(ex, ka);
+        const int eb = __shfl(ex, kb + 1), eb1 = __shfl(ex, kb);
+        double xa = __longlong_as_double((long long)va), xb = __longlong_as_double((long long)vb);
+        // the first row of a trip comes from the trip before: bring it to this trip's exponent
+        if ((lane & 7) == 0) {
+          xa = ldexp(xa, ea1 - ea);
+          xb = ldexp(xb, eb1 - eb);
         }
-        if (g + 1 < G) {
-          edge_take(qt, pend[k]);  // trip g + 1
-          qt.next(TP);
-          pend[k] = edge_issue(qi);  // trip g + 1 + CH_K
-          qi.next(TP);
-        }
-        CH_ACC();
-        lds_barrier();
+        if (ka < nr) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
+        if (kb < nr) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
+        if (lane >= 1 && lane <= nr) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+        t += nr;
+        lds_post(&edge_ready, t);
       }
     }
-    publish(qp);  // trip G - 1
   }
-  CH_DUMP();
+#ifdef STB_STAMPS
+  if (g_dbg && lane == 0 && d == 0 && j < 512) {
+    unsigned long long *q_ = g_dbg + ((size_t)j * 16 + wave) * 4;
+    q_[0] = t_wait;
+    q_[1] = __builtin_amdgcn_s_memtime() - t_start;
+    q_[2] = n_wait;
+    q_[3] = t_start;
+  }
+#endif
 }
 
 static int ensure_logtab() {
@@ -1499,22 +1555,24 @@ static int env_int(const char *name, int dflt) {
 
 // geometry of the chain form (k_fill_chain): column blocks per table, trips, edge stream lengths
 struct chain_geom {
-  int C, RH, B, G;
-  uint64_t EV, NPmax;
+  int P, NC, B, G;
+  uint64_t EV, NP;
   size_t bytes;  // header + edge streams for D tables
 };
 static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   chain_geom g;
-  g.C = env_int("STB_CHAIN_C", 2) == 1 ? 1 : 2;
-  g.RH = env_int("STB_CHAIN_RH", 2);
-  if (g.RH != 1 && g.RH != 2 && g.RH != 4) g.RH = 2;
+  g.P = env_int("STB_CHAIN_P", 4);
+  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = 4;
+  g.NC = env_int("STB_CHAIN_NC", g.P == 4 ? 10 : g.P == 2 ? 6 : 3);
+  if (g.NC < g.P) g.NC = g.P;
+  if (g.P + g.NC + 2 > 16) g.NC = 14 - g.P;
   const unsigned cols = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
-  g.B = (int)((cols + 64 * g.C - 1) / (64 * g.C));
+  g.B = (int)((cols + 64 * g.P - 1) / (64 * g.P));
   if (g.B < 1) g.B = 1;
   g.G = (N > 2) ? (int)((N - 2 + CH_U - 1) / CH_U) : 0;
-  g.EV = (uint64_t)3 + (uint64_t)g.G * CH_U + 8;
-  g.NPmax = (uint64_t)g.G + 2;
-  g.bytes = 256 + (size_t)D * g.B * (g.EV + g.NPmax) * sizeof(unsigned long long);
+  g.EV = (uint64_t)3 + (uint64_t)g.G * CH_U + 136;  // the fetcher reads 128 rows at a time
+  g.NP = (uint64_t)g.G + 24;                        // ... and 17 trip exponents
+  g.bytes = 256 + (size_t)D * g.B * (g.EV + g.NP) * sizeof(unsigned long long);
   return g;
 }
 
@@ -1635,7 +1693,7 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
   const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : v == STB_FILL_CHAIN ? 3 : (few ? 1 : 2);
   if (form == 3) {
     const chain_geom g = chain_geometry(N, M, D);
-    if (C_out) *C_out = g.C;
+    if (C_out) *C_out = g.P;
     if (R_out) *R_out = (int)N;
     if (launches) *launches = 1;
     return 3;
@@ -1743,15 +1801,14 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     X.D = D;
     X.B = cg.B;
     X.EV = cg.EV;
-    X.NP = (uint64_t)(cg.G / X.TP + 2);
+    X.NP = cg.NP;
     char *cb = (char *)align_up((size_t)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int)), 256);
     if ((size_t)(cb - (char *)d_ws) + cg.bytes > ws_bytes) return fail("%s: workspace too small for the chain form", who);
     X.hdr = (unsigned *)cb;
     X.edge_e = (unsigned long long *)(cb + 256);
     X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
     X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
-    const size_t zero_bytes = 256 + (size_t)D * cg.B * (X.NP + X.EV) * sizeof(unsigned long long);
-    HIPCHK(hipMemsetAsync(cb, 0, align_up(zero_bytes, 16), st));
+    HIPCHK(hipMemsetAsync(cb, 0, align_up(cg.bytes, 16), st));
     g_chain_hdr = X.hdr;
     hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
     hipEvent_t p0 = nullptr, p1 = nullptr;
@@ -1779,24 +1836,27 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     }
 #endif
     const dim3 grid((unsigned)cg.B * (unsigned)D);
-#define STB_LAUNCH_CHAIN(CC, RR)                                                                           \
-  do {                                                                                                     \
-    if (p0)                                                                                                \
-      hipExtLaunchKernelGGL((k_fill_chain<CC, RR>), grid, dim3(64 * (2 + CC * RR)), 0, st, p0, p1, 0, A, X); \
-    else                                                                                                   \
-      hipLaunchKernelGGL((k_fill_chain<CC, RR>), grid, dim3(64 * (2 + CC * RR)), 0, st, A, X);             \
+#define STB_LAUNCH_CHAIN(PP, NN)                                                                         \
+  do {                                                                                                   \
+    if (p0)                                                                                              \
+      hipExtLaunchKernelGGL((k_fill_chain<PP, NN>), grid, dim3(64 * (PP + NN + 2)), 0, st, p0, p1, 0, A, X); \
+    else                                                                                                 \
+      hipLaunchKernelGGL((k_fill_chain<PP, NN>), grid, dim3(64 * (PP + NN + 2)), 0, st, A, X);           \
   } while (0)
-    if (cg.C == 1) {
-      if (cg.RH == 1) STB_LAUNCH_CHAIN(1, 1);
-      else if (cg.RH == 2) STB_LAUNCH_CHAIN(1, 2);
-      else STB_LAUNCH_CHAIN(1, 4);
-    } else {
-      if (cg.RH == 1) STB_LAUNCH_CHAIN(2, 1);
-      else if (cg.RH == 2) STB_LAUNCH_CHAIN(2, 2);
-      else STB_LAUNCH_CHAIN(2, 4);
+    const int shape = cg.P * 100 + cg.NC;
+    switch (shape) {
+      case 103: STB_LAUNCH_CHAIN(1, 3); break;
+      case 104: STB_LAUNCH_CHAIN(1, 4); break;
+      case 106: STB_LAUNCH_CHAIN(1, 6); break;
+      case 204: STB_LAUNCH_CHAIN(2, 4); break;
+      case 206: STB_LAUNCH_CHAIN(2, 6); break;
+      case 208: STB_LAUNCH_CHAIN(2, 8); break;
+      case 406: STB_LAUNCH_CHAIN(4, 6); break;
+      case 408: STB_LAUNCH_CHAIN(4, 8); break;
+      case 410: STB_LAUNCH_CHAIN(4, 10); break;
+      default: return fail("%s: no chain kernel for %d producers / %d consumers", who, cg.P, cg.NC);
     }
 #undef STB_LAUNCH_CHAIN
-    HIPCHK(hipGetLastError());
 #ifdef STB_STAMPS
     if (getenv("STB_STAMP_FILE") && h_cdbg) {
       HIPCHK(hipStreamSynchronize(st));
@@ -1807,12 +1867,13 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       for (int jj = 0; jj < 512; jj++)
         for (int w = 0; w < 16; w++) {
           unsigned long long *q = h + ((size_t)jj * 16 + w) * 4;
-          if (q[1]) fprintf(f, "%d %d %llu %llu %llu\n", jj, w, q[0], q[1], q[2]);
+          if (q[1]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, w, q[0], q[1], q[2], q[3]);
         }
       fclose(f);
       free(h);
     }
 #endif
+    HIPCHK(hipGetLastError());
     return 0;
   }
   if (mode == STB_MODE_PC) {

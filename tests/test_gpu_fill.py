@@ -157,12 +157,12 @@ def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     assert orc.max_err(got, tab) <= TOL
 
 
-@pytest.mark.parametrize("C,RH", [(1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4)])
-def test_chain_geometries_agree(monkeypatch, C, RH):
-    """chain form: every (columns per lane, consumer row groups) shape computes the same tables and
+@pytest.mark.parametrize("P,NC", [(1, 3), (1, 6), (2, 4), (2, 6), (2, 8), (4, 6), (4, 8), (4, 10)])
+def test_chain_geometries_agree(monkeypatch, P, NC):
+    """chain form: every (producer waves, consumer waves) block shape computes the same tables and
     no block gives up waiting for its neighbour (several column blocks, several tables)"""
-    monkeypatch.setenv("STB_CHAIN_C", str(C))
-    monkeypatch.setenv("STB_CHAIN_RH", str(RH))
+    monkeypatch.setenv("STB_CHAIN_P", str(P))
+    monkeypatch.setenv("STB_CHAIN_NC", str(NC))
     a = np.array([0.05, 0.5, 0.93])
     T = capi.DeviceTables(900, 700, D=3)
     T.tables.fill_(float("nan"))

@@ -16,6 +16,7 @@ T.fill(a, capi.FILL_CHAIN); torch.cuda.synchronize()
 T.status()
 rows = np.loadtxt("gpurun_out/stamps_chain.txt", dtype=np.int64, ndmin=2)
 blocks = sorted(set(rows[:, 0]))
-for j in blocks[:3] + blocks[len(blocks) // 2:len(blocks) // 2 + 1] + blocks[-1:]:
+tmin = rows[:, 5].min()
+for j in blocks[:2] + blocks[len(blocks) // 2:len(blocks) // 2 + 1] + blocks[-1:]:
     for r in rows[rows[:, 0] == j]:
-        print(f"block {r[0]:3d} wave {r[1]:2d}: work {r[2]:9d} total {r[3]:9d} trips {r[4]:5d}  work/trip {r[2] / max(r[4], 1):7.0f} total/trip {r[3] / max(r[4], 1):7.0f}")
+        print(f"block {r[0]:3d} wave {r[1]:2d}: start {r[5] - tmin:9d} total {r[3]:9d} waiting {r[2]:9d} ({100.0 * r[2] / max(r[3], 1):5.1f}%) in {r[4]:6d} waits")

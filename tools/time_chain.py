@@ -12,7 +12,7 @@ from libstb_amd import capi, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-combos = (sys.argv[3] if len(sys.argv) > 3 else "2:2,2:4,2:1,1:2,1:4").split(",")
+combos = (sys.argv[3] if len(sys.argv) > 3 else "4:10,4:8,2:6,2:8,1:3,1:6").split(",")
 M = int(sys.argv[4]) if len(sys.argv) > 4 else N
 a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
 
@@ -40,14 +40,14 @@ ref_rows = [T.row(d, n).clone() for d in range(D) for n in (3, 4, 130, N // 3, N
 ref_sum = T.tables.nan_to_num(0.0, 0.0, 0.0)[:, :8].sum().item()
 for cb in combos:
     C, RH = cb.split(":")
-    os.environ["STB_CHAIN_C"] = C
-    os.environ["STB_CHAIN_RH"] = RH
+    os.environ["STB_CHAIN_P"] = C
+    os.environ["STB_CHAIN_NC"] = RH
     T2 = capi.DeviceTables(N, M, D=D)
     T2.tables.fill_(float("nan"))
     ms = timed(T2, capi.FILL_CHAIN)
     T2.status()
     got = [T2.row(d, n) for d in range(D) for n in (3, 4, 130, N // 3, N - 1, N)]
     err = max(((g - r).abs() / r.abs().clamp(min=1.0)).max().item() for g, r in zip(got, ref_rows))
-    print(f"N={N} M={M} D={D} chain C={C} RH={RH}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
+    print(f"N={N} M={M} D={D} chain P={C} NC={RH}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
           f"{cells * 8 / ms / 1e6:8.1f} GB/s  max rel err vs auto on probe rows {err:.2e}", flush=True)
     del T2
