@@ -12,7 +12,7 @@ second of the slowest rank.
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # one discount per GPU
     python bench.py --discounts-per-gpu 8                    # the batched mode (configs[2] shape)
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_fill_bfp) against HBM:
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_fill_chain) against HBM:
 algorithmic bytes = 8 B per stored cell, duration = device time of the fill kernels
 measured with per-launch HIP start/stop events inside the timed region.  `cpu_baseline` times the
 reference's (or the oracle's) single-core fill of the same table on this box's host CPU.
@@ -232,8 +232,15 @@ def main():
     if rank == 0:
         Cc, Rr, nl = C.c_int(), C.c_int(), C.c_int()
         form = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
-        form = {capi.FILL_SPLIT: 1, capi.FILL_PC: 2, capi.FILL_FUSED: 0, capi.FILL_SCALED: form}.get(args.variant, 3)
-        split = form == 1
+        # 0 fused, 1 split, 2 producer/consumer, 3 chain, 4 chain with converter blocks, 5 ablation forms
+        form = {capi.FILL_SPLIT: 1, capi.FILL_PC: 2, capi.FILL_FUSED: 0, capi.FILL_CHAIN: 3,
+                capi.FILL_CHAINX: 4 if Dl <= 2 else 3, capi.FILL_SCALED: form}.get(args.variant, 5)
+        FORMS = ["fused", "split", "pc", "chain", "chainx", "other"]
+        KERNELS = ["k_fill_bfp", "k_rec", "k_fill_pc", "k_fill_chain", "k_fill_chainx", "k_fill_rows"]
+        KERNEL_NOTES = ["k_fill_bfp", "k_rec (recurrence; logs follow in k_logconv on a second stream)",
+                        "k_fill_pc (producer wave + consumer waves per column block)",
+                        "k_fill_chain (one launch per fill: producer, consumer, publisher and fetcher waves per column block)",
+                        "k_fill_chainx (one launch per fill: chain blocks + converter blocks)", "k_fill_rows"]
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches
         bytes_per_launch = 8.0 * cells_rank * args.steps / launches  # 8 B per stored cell
@@ -246,8 +253,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tpath):
             db = json.load(open(tpath))
-            key = f"N{N}_M{M}_D{Dl}_{['fused', 'split', 'pc', 'other'][form]}"
-            want = ["k_fill_bfp", "k_rec", "k_fill_pc", "k_fill_rows"][form]
+            key = f"N{N}_M{M}_D{Dl}_{FORMS[form]}"
+            want = KERNELS[form]
             for kname, rec in db.get(key, {}).items():
                 if kname.startswith(want):
                     traffic = rec["hbm_bytes_per_launch"]
@@ -276,8 +283,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ["k_fill_bfp", "k_rec (recurrence; logs follow in k_logconv on a second stream)",
-                           "k_fill_pc (producer wave + consumer waves per column block)", "k_fill_rows"][form],
+                "kernel": KERNEL_NOTES[form],
+                "form": FORMS[form],
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -288,7 +295,7 @@ def main():
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_per_step": kms.value / args.steps,
-                "note": "one table per GPU is bound by N serial row steps of one lone wavefront per strip, not by HBM; see DESIGN.md",
+                "note": "one table per GPU is bound by the N serial row steps of the recurrence (one wave per 64 columns), not by HBM; see DESIGN.md",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

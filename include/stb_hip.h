@@ -64,6 +64,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
 #define STB_FILL_FUSED 4       /* recurrence and log in one kernel (8 B of HBM traffic per cell) */
 #define STB_FILL_PC 5          /* one producer wave (recurrence) + consumer waves (logs) per column block, via LDS */
 #define STB_FILL_CHAIN 6       /* one launch: column blocks keep their columns for all rows, edges handed on in HBM */
+#define STB_FILL_CHAINX 7      /* the same chain alone in its blocks; logs by converter blocks of the same launch (D <= 2) */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,

@@ -226,6 +226,7 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void 
     } else if (stb_memcpy_d2h(hS, im->d_S, sizeof(double) * stb_table_elems(N, M), NULL))
       return 1;
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
+    if (stb_fill_status()) return 1; /* (the copies above waited for the fill) */
   }
   if (sp->flags & S_UVTABLE) {
     if (stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL)) return 1;
@@ -242,6 +243,7 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void 
                    stb_default_variant(), NULL))
       return 1;
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
+    if (stb_fill_status()) return 1;
   }
   if (stb_stream_sync(NULL)) return 1;
   return 0;

@@ -1163,6 +1163,7 @@ struct chain_args {
   int D, B;                    // tables, column blocks per table
   int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
+  int dbg;                     // diagnostic switches (STB_CHAIN_DBG), 0 in production
 };
 
 __device__ __forceinline__ int lds_peek(const int *p) {
@@ -1522,6 +1523,498 @@ __global__ __launch_bounds__(64 * (P + NC + 2)) void k_fill_chain(fill_args A, c
 #endif
 }
 
+// ---- chain form with the logs on OTHER compute units (one or two tables) -----------------------
+//
+// With one table in flight k_fill_chain leaves 200+ compute units idle while every busy one is
+// saturated by its own consumer waves (a slice's logs cost ~3x its recurrence).  Here a producer
+// block is only the chain -- P producer waves of two columns per lane, publisher, fetcher, as
+// above -- and writes the raw significands straight to their place in the table with
+// write-through stores, plus one exponent per lane and period to a side array.  The remaining
+// blocks of the SAME launch are converters: block q owns the 64-column chunk q, its 8 waves take
+// CX_ITEM-trip items round-robin, wait for the owning producer's progress word, and turn the raw
+// significands into logs in place.  A producer publishes "trips complete" only for stores that
+// have left the wave (s_waitcnt vmcnt(N), N = the stores of the last CX_LAG trips), so a converter
+// that has seen the word may read the bytes (sc1 loads; first touch of those lines on its side).
+// Tickets: producer blocks first (j-major), then converter blocks; every wait is on a block with a
+// smaller ticket.  The static LDS (the ring) keeps this kernel at one block per compute unit, so
+// producers never share theirs.
+#define CX_LAG 6   // trips whose raw stores may still be in flight when progress is published
+#define CX_ITEM 4  // trips per converter item
+#define CX_FLUSH 8 // trips between two write-backs of the raw significands
+
+// one 16-byte write-through store (sc1: the line is written to memory, not kept dirty in this
+// XCD's L2), not counted by the compiler: callers order it with their own s_waitcnt vmcnt
+typedef double stb_dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pair_wt(double *p, double2 v) {
+  stb_dvec2 x;
+  x.x = v.x;
+  x.y = v.y;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+
+struct chainx_args {
+  unsigned *progress;        // [D][B][P] trips complete in the table, per producer wave; zeroed per fill
+  int *expo;                 // [D][NPer][EWh] lane exponent per period and column pair
+  unsigned long long *dump;  // 64 words nobody reads: where the stores of absent columns go
+  uint64_t EWh;
+  int NPer, Q;               // periods, 64-column chunks per table
+};
+
+template <int P>
+__global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, chainx_args Y) {
+  constexpr int U = CH_U, RD = 4, RE = CH_RE;
+  constexpr int OW = 128 * P;  // columns of a producer block
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][OW];
+  __shared__ int ebuf[4][OW];
+  __shared__ int slot_p[RD][P];
+  __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
+  __shared__ int edge_e[RE];
+  __shared__ int prod_done[P], stored_done[P], pub_done, edge_ready, s_abort, seen_prog;
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: keeps the role loops on the scalar unit)
+  if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
+  if (tid < 128) lt[tid] = g_logtab[tid];
+  for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
+  __syncthreads();
+  const unsigned N = A.N, M = A.M;
+  const int TP = X.TP, G = X.G;
+  const unsigned nprod = (unsigned)X.B * (unsigned)X.D;
+  const bool converter = s_ticket >= nprod;
+  const int j = converter ? 0 : (int)(s_ticket / (unsigned)X.D);
+  const int d = converter ? (int)((s_ticket - nprod) % (unsigned)X.D) : (int)(s_ticket % (unsigned)X.D);
+  const int c0 = j * OW;  // first column of the block; column 0 is a dummy that stays zero
+  auto first_trip = [&](int w) {  // trip in which the diagonal reaches the first column of slice w
+    const int c = c0 + 128 * w;
+    return (c <= 3) ? 0 : (c - 3) / U;
+  };
+  const int g0b = first_trip(0);
+  const bool has_left = j > 0, has_right = j < X.B - 1;
+  if (tid < P) prod_done[tid] = first_trip(tid);
+  if (tid < P) stored_done[tid] = 0;
+  if (tid == 0) {
+    seen_prog = 0;
+    pub_done = first_trip(P - 1);
+    edge_ready = has_left ? g0b : 0x7fffffff;
+    s_abort = 0;
+  }
+  __syncthreads();
+  double *table = A.tables + (uint64_t)d * A.tstride;
+  bool aborted = false;
+#ifdef STB_STAMPS
+  unsigned long long t_wait = 0;
+  const unsigned long long w_start = wall_clock64();
+  int n_wait = 0;
+#define CX_DUMP(ID)                                                           \
+  do {                                                                        \
+    if (g_dbg && lane == 0 && d == 0 && (ID) < 512) {                         \
+      unsigned long long *q_ = g_dbg + ((size_t)(ID) * 16 + wave) * 4;        \
+      q_[0] = t_wait;                                                         \
+      q_[1] = wall_clock64();                                                 \
+      q_[2] = n_wait;                                                         \
+      q_[3] = w_start;                                                        \
+    }                                                                         \
+  } while (0)
+#else
+#define CX_DUMP(ID) do {} while (0)
+#endif
+
+  if (converter) {
+    // ======================= converter block: chunk q of table d =======================
+    const int q = (int)((s_ticket - nprod) / (unsigned)X.D);
+    if (q >= Y.Q) return;
+    const int jo = (64 * q) / OW, wo = ((64 * q) % OW) / 128;  // owning block and producer wave
+    const int c0s = jo * OW + 128 * wo;                        // first column of the owning slice
+    const int t0 = (c0s <= 3) ? 0 : (c0s - 3) / U;             // its first trip
+    const int cc = 64 * q + lane;                              // my column
+    const bool ok = cc >= 2 && (unsigned)cc <= M;
+    const unsigned *prog = Y.progress + (((uint64_t)d * X.B + jo) * P + wo) * 32;
+    const int *expo = Y.expo + (uint64_t)d * Y.NPer * Y.EWh + (cc >> 1);
+    double *dump = reinterpret_cast<double *>(Y.dump) + lane;
+    for (int ii = wave;; ii += 8) {
+      const int ta = t0 + CX_ITEM * ii;
+      if (ta >= G) break;
+      const int tb = min(G, ta + CX_ITEM);
+      // ---- wait for the producer: poll its word sparingly (a hot word slows the store that
+      // updates it) and share what was seen through LDS ----
+      if (lds_peek(&seen_prog) < tb) {
+        const unsigned long long t_begin = wall_clock64();
+#ifdef STB_STAMPS
+        n_wait++;
+#endif
+        for (;;) {
+          const int pr = (int)__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pr > lds_peek(&seen_prog)) lds_post(&seen_prog, pr);
+          if (pr >= tb) break;
+          bool seen = false;
+          for (int k = 0; k < 4 + wave && !seen; k++) {  // (staggered: the waves do not poll in step)
+            __builtin_amdgcn_s_sleep(8);
+            seen = lds_peek(&seen_prog) >= tb;
+          }
+          if (seen) break;
+          const bool late = (unsigned long long)wall_clock64() - t_begin > X.timeout;
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || late) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, (unsigned)(q | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0xA00u + (unsigned)ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            aborted = true;
+            break;
+          }
+        }
+      }
+#ifdef STB_STAMPS
+      if (n_wait) t_wait += 0;
+#endif
+      if (aborted) break;
+      asm volatile("" ::: "memory");
+      for (int t = ta; t < tb; t++) {
+        const int r0 = 3 + t * U;
+        const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+        const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch;
+        const int myep = __hip_atomic_load(expo + (uint64_t)(t / TP) * Y.EWh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double *cell = ok ? table + stb_row_offset((unsigned)r0, M) + (cc - 2) : dump;
+        if (fast) {
+          const size_t inc = ok ? pitch : 0;
+          double x[U], z[U], kf[U], r[U], pl[U];
+          double2 tt[U];
+#pragma unroll
+          for (int u = 0; u < U; u++)
+            x[u] = __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<unsigned long long *>(cell + u * inc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+          for (int u = 0; u < U; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int hi = __double2hiint(x[u]);
+            z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+            kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) r[u] = fma(z[u], tt[u].x, -1.0);
+#pragma unroll
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0);
+#pragma unroll
+          for (int u = 0; u < U; u++) cell[u * inc] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+        } else {
+          for (int u = 0; u < U; u++) {
+            const int rr = r0 + u;
+            if ((unsigned)rr <= N) {
+              const double x = __longlong_as_double((long long)__hip_atomic_load(
+                  reinterpret_cast<unsigned long long *>(cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              *cell = bfp_log(x, myep, lt);
+            }
+            if (ok) cell += stb_row_pitch((unsigned)rr, M);
+          }
+        }
+      }
+    }
+    CX_DUMP(256 + q);
+    return;
+  }
+
+  // ======================= producer block (d, j) =======================
+  if (wave >= P + 3) return;
+  auto wait_ge = [&](const int *cnt, int need, unsigned code) {
+    if (aborted || lds_peek(cnt) >= need) return;
+    const unsigned long long t_begin = wall_clock64();
+    for (;;) {
+      __builtin_amdgcn_s_sleep(1);
+      if (lds_peek(cnt) >= need) {
+#ifdef STB_STAMPS
+        t_wait += wall_clock64() - t_begin;
+        n_wait++;
+#endif
+        return;
+      }
+      if (lds_peek(&s_abort)) break;
+      if ((unsigned long long)wall_clock64() - t_begin > X.timeout) {
+        if (lane == 0) {
+          __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.hdr + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        break;
+      }
+    }
+    aborted = true;
+  };
+
+  if (wave < P) {
+    // ================= producers: two columns per lane sharing one exponent =================
+    __builtin_amdgcn_s_setprio(3);
+    const int w = wave;
+    const int g0w = first_trip(w);
+    const int col = 128 * w + 2 * lane;  // first of my two columns inside the block
+    const int cA = c0 + col, cB = cA + 1;
+    const double a = A.a[d];
+    // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
+    double v0 = (cA == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+    double v1 = (cB == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : 0.0;
+    double coef0 = (double)(2 + g0w * U) - (double)cA * a;  // n - 1 - c a for the first row of trip g0w
+    double coef1 = (double)(2 + g0w * U) - (double)cB * a;
+    double s = 1.0;
+    int ep = 1 + PC_BIAS;
+    int p = g0w / TP, tin = g0w - p * TP;
+    // where my pair of cells of a row lives (16-byte aligned: cA is even and rows are 512-byte
+    // aligned); the pair (0, 1) has no slot and pairs past M are not stored: those go to the dump
+    const bool okP = cA >= 2 && (unsigned)cA <= M && !(X.dbg & 1);
+    double *dump = reinterpret_cast<double *>(Y.dump) + 2 * lane;
+    double *pA = okP ? table + stb_row_offset((unsigned)(3 + g0w * U), M) + (cA - 2) : dump;
+    int *expo = Y.expo + (uint64_t)d * Y.NPer * Y.EWh + (cA >> 1);
+    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w - 1];
+    const int *next_cnt = (w < P - 1) ? &prod_done[w + 1] : &pub_done;
+    int n_left, n_next;
+    double ne[U];
+    auto load_left = [&](double(&x)[U], int g) {
+      if (w == 0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = edge_in[(g & (RE - 1)) * U + u];
+      } else {
+        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][128 * w - 1];
+#pragma unroll
+        for (int u = 1; u < U; u++) x[u] = vbuf[g & (RD - 1)][u - 1][128 * w - 1];
+      }
+    };
+    auto look_ahead = [&](int g) {
+      n_left = lds_peek(left_cnt);
+      n_next = lds_peek(next_cnt);
+      asm volatile("" ::: "memory");
+      load_left(ne, g);
+    };
+    look_ahead(g0w);
+#ifdef STB_STAMPS
+    unsigned long long sec[6] = {0, 0, 0, 0, 0, 0}, tm = __builtin_amdgcn_s_memtime();
+#define CX_SEC(I) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sec[I] += n_ - tm; tm = n_; } while (0)
+#else
+#define CX_SEC(I) do {} while (0)
+#endif
+    for (int g = g0w; g < G; g++) {
+      double e[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) e[u] = ne[u];
+      const int next_need = (w < P - 1) ? g - RD + 2 : g - RD + 1;
+      if (n_left < g + 1 || n_next < next_need) {
+        wait_ge(left_cnt, g + 1, 0x100u + (unsigned)g);
+        wait_ge(next_cnt, next_need, 0x400u + (unsigned)g);  // slot g % RD read by w+1 / published
+        asm volatile("" ::: "memory");
+        load_left(e, g);
+      }
+      CX_SEC(0);
+      if (g + 1 < G) look_ahead(g + 1);
+      CX_SEC(1);
+      if (g == g0w || tin == 0) {
+        // ---- period set-up ----
+        if (g != g0w) {  // renormalise: the larger significand back to 2^-PC_BIAS * [0.5,1)
+          int kmax = -4000;
+          if (v0 != 0.0) kmax = __builtin_amdgcn_frexp_exp(v0);
+          if (v1 != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v1));
+          if (kmax > -4000) {
+            v0 = ldexp(v0, -kmax - PC_BIAS);
+            v1 = ldexp(v1, -kmax - PC_BIAS);
+            ep += kmax + PC_BIAS;
+          }
+        }
+        int el = ep;
+        if (w == 0) {
+          if (has_left) el = edge_e[g & (RE - 1)];
+        } else {
+          el = ebuf[p & 3][128 * w - 1];
+          // the row above the first row of a period was produced under the previous exponent
+          if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 3][128 * w - 1] - el);
+        }
+        int dl = wave_shr1(ep, ep) - ep;
+        if (lane == 0) dl = el - ep;
+        s = ldexp(1.0, min(max(dl, -1100), 220));
+        *reinterpret_cast<int2 *>(&ebuf[p & 3][col]) = make_int2(ep, ep);
+        __hip_atomic_store(expo + (uint64_t)p * Y.EWh, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      CX_SEC(2);
+      if (lane == 0) slot_p[g & (RD - 1)][w] = p & 3;
+      const int r0 = 3 + g * U;
+      const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+      const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch;
+      CX_SEC(3);
+      if (fast) {
+        const size_t incA = okP ? pitch : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const double t0 = wave_shr1(v1, e[u]) * s;
+          v1 = fma(coef1, v1, v0);
+          v0 = fma(coef0, v0, t0);
+          coef0 += 1.0;
+          coef1 += 1.0;
+          const double2 vv = make_double2(v0, v1);
+          *reinterpret_cast<double2 *>(&vbuf[g & (RD - 1)][u][col]) = vv;
+          *reinterpret_cast<double2 *>(pA) = vv;
+          pA += incA;
+        }
+      } else {
+        for (int u = 0; u < U; u++) {
+          const double t0 = wave_shr1(v1, e[u]) * s;
+          v1 = fma(coef1, v1, v0);
+          v0 = fma(coef0, v0, t0);
+          coef0 += 1.0;
+          coef1 += 1.0;
+          const double2 vv = make_double2(v0, v1);
+          *reinterpret_cast<double2 *>(&vbuf[g & (RD - 1)][u][col]) = vv;
+          const int rr = r0 + u;
+          *reinterpret_cast<double2 *>(((unsigned)rr <= N) ? pA : dump) = vv;
+          if (okP) pA += stb_row_pitch((unsigned)rr, M);
+        }
+      }
+      CX_SEC(4);
+      lds_post(&prod_done[w], g + 1);
+      // trips up to g - CX_LAG have left the wave: at most the stores of the last CX_LAG trips
+      // (U each, plus an exponent word now and then) can still be in flight.  The publisher wave
+      // passes the count on to the converters: a store to a polled word must not sit in THIS queue.
+      if (!(X.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CX_LAG * U) : "memory");
+      if (g + 1 - CX_LAG > g0w) lds_post(&stored_done[w], g + 1 - CX_LAG);
+      if (++tin == TP) {
+        tin = 0;
+        p++;
+      }
+      CX_SEC(5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_post(&stored_done[w], G);
+#ifdef STB_STAMPS
+    if (g_dbg && lane == 0 && d == 0 && j < 8) {
+      unsigned long long *q_ = g_dbg + ((size_t)(500 + j) * 16 + wave) * 4;
+      q_[0] = sec[0] | (sec[1] << 32);
+      q_[1] = sec[2] | (sec[3] << 32);
+      q_[2] = sec[4] | (sec[5] << 32);
+      q_[3] = 1;
+    }
+#endif
+  } else if (wave == P) {
+    // ================= publisher: the block's last column, and everybody's progress =================
+    unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
+    unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
+    for (int t = first_trip(P - 1); t < G; t++) {
+      wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);
+      const int slot = t & (RD - 1);
+      if (has_right) {
+        if (lane < U) {
+          unsigned long long b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][OW - 1]);
+          if ((b << 1) == 0) b = CH_NEGZERO;
+          __hip_atomic_store(ev_out + 3 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == U) {
+          const long long ex = (long long)ebuf[slot_p[slot][P - 1]][OW - 1] + (long long)CH_EOFF;
+          __hip_atomic_store(ee_out + t, (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      lds_post(&pub_done, t + 1);
+    }
+  } else if (wave == P + 1) {
+    // ================= fetcher =================
+    if (has_left) {
+      const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
+      const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (j - 1)) * X.NP;
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      for (int t = g0b; t < G;) {
+        int lim = lds_peek(&prod_done[0]) + RE;
+        if (lim > G) lim = G;
+        if (lim <= t) {
+          wait_ge(&prod_done[0], t - RE + 1, 0x800u + (unsigned)t);
+          if (aborted) break;
+          continue;
+        }
+        const int nt = min(16, lim - t);
+        const int row0 = 2 + t * U;
+        const int ra = row0 + lane, rb = row0 + 64 + lane;
+        const bool need_a = lane < 8 * nt, need_b = 64 + lane < 8 * nt;
+        const bool need_e = lane <= nt;
+        unsigned long long va = 0, vb = 0, ve = 0;
+        if (need_a) va = __hip_atomic_load(ev_in + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_b) vb = __hip_atomic_load(ev_in + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_e) ve = __hip_atomic_load(ee_in + t - 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ma = __ballot(!need_a || va != 0);
+        const unsigned long long mb = __ballot(!need_b || vb != 0);
+        const unsigned long long me = __ballot(!need_e || ve != 0);
+        int nr = 0;
+        for (; nr < nt; nr++) {
+          const unsigned long long rows = (nr < 8) ? (ma >> (8 * nr)) : (mb >> (8 * (nr - 8)));
+          if ((rows & 0xffull) != 0xffull || ((me >> nr) & 3ull) != 3ull) break;
+        }
+        if (nr == 0) {
+          if (!timing) {
+            timing = true;
+            t_begin = wall_clock64();
+          }
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
+            if (lane == 0) {
+              __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (err == 0) {
+                __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 1, 0x900u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+            lds_post(&edge_ready, 0x7fffffff);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        timing = false;
+        const int ex = (int)(long long)(ve - CH_EOFF);
+        const int ka = lane >> 3, kb = 8 + (lane >> 3);
+        const int ea = __shfl(ex, ka + 1), ea1 = __shfl(ex, ka);
+        const int eb = __shfl(ex, kb + 1), eb1 = __shfl(ex, kb);
+        double xa = __longlong_as_double((long long)va), xb = __longlong_as_double((long long)vb);
+        if ((lane & 7) == 0) {
+          xa = ldexp(xa, ea1 - ea);
+          xb = ldexp(xb, eb1 - eb);
+        }
+        if (ka < nr) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
+        if (kb < nr) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
+        if (lane >= 1 && lane <= nr) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+        t += nr;
+        lds_post(&edge_ready, t);
+      }
+    }
+  } else {
+    // ================= flusher: makes the raw significands visible and tells the converters =================
+    // The producers store with plain (write-back) stores, which the L2 acknowledges quickly, and
+    // post in LDS how many trips have left their queues.  This wave writes the XCD's dirty lines
+    // back (agent-scope release) every CX_FLUSH trips and only then passes the counts on.
+    unsigned *prog = Y.progress + (((uint64_t)d * X.B + j) * P + (lane < P ? lane : 0)) * 32;
+    int told = 0;
+    const unsigned long long t_begin = wall_clock64();
+    for (;;) {
+      const int sd = (lane < P) ? lds_peek(&stored_done[lane]) : 0x7fffffff;
+      int m = sd;  // min over the producers
+#pragma unroll
+      for (int o = 1; o < P; o <<= 1) m = min(m, __shfl_xor(m, o));
+      m = __builtin_amdgcn_readfirstlane(m);
+      if (m >= told + CX_FLUSH || (m >= G && told < G)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < P) __hip_atomic_store(prog, (unsigned)sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        told = m;
+        if (m >= G) break;
+      } else {
+        if (X.dbg & 2) __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(4);
+        if (lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > 4 * X.timeout) break;
+      }
+    }
+  }
+  CX_DUMP(j);
+}
+
 static int ensure_logtab() {
   static bool done[64] = {false};
   int dev = 0;
@@ -1576,18 +2069,59 @@ static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   return g;
 }
 
-extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
+// geometry of the chain form with external converters (k_fill_chainx)
+struct chainx_geom {
+  int P, B, G, Q, NPer;
+  uint64_t EV, NP, EWh;
+  size_t prog_bytes, zero_bytes, bytes;  // progress words; what is zeroed per fill; everything
+};
+static chainx_geom chainx_geometry(unsigned N, unsigned M, int D) {
+  chainx_geom g;
+  g.P = env_int("STB_CHAINX_P", 4);
+  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = 4;
+  const unsigned cols = (M < N - 1) ? M : N - 1;
+  const int OW = 128 * g.P;
+  g.B = (int)((cols + 1 + OW - 1) / OW);  // columns 0 (a dummy) .. cols
+  if (g.B < 1) g.B = 1;
+  g.Q = (int)((cols + 1 + 63) / 64);
+  g.G = (N > 2) ? (int)((N - 2 + CH_U - 1) / CH_U) : 0;
+  g.EV = (uint64_t)3 + (uint64_t)g.G * CH_U + 136;
+  g.NP = (uint64_t)g.G + 24;
+  g.NPer = g.G + 2;  // (a period is at least one trip)
+  g.EWh = (uint64_t)g.B * OW / 2;
+  g.prog_bytes = align_up((size_t)D * g.B * g.P * 32 * sizeof(unsigned), 256);  // one 128-byte line per word
+  g.zero_bytes = 256 + g.prog_bytes + (size_t)D * g.B * (g.EV + g.NP) * sizeof(unsigned long long);
+  g.bytes = align_up(g.zero_bytes, 256) + 2048 + (size_t)D * g.NPer * g.EWh * sizeof(int);
+  return g;
+}
+
+static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
   size_t W = frontier_pitch(M);
   const size_t ring = (size_t)D * STB_EP_RING * STB_PPL_MAX * W * sizeof(int);
-  const size_t chain = (N >= 3 && M >= 2 && D >= 1) ? chain_geometry(N, M, D).bytes + 256 : 0;
+  size_t chain = (N >= 3 && M >= 2 && D >= 1) ? chain_geometry(N, M, D).bytes + 256 : 0;
+  if (N >= 3 && M >= 2 && D >= 1 && D <= 2) {
+    const size_t cx = chainx_geometry(N, M, D).bytes + 256;
+    if (cx > chain) chain = cx;
+  }
   return align_up((size_t)D * sizeof(double), 256) + (size_t)D * 2 * W * (sizeof(double) + sizeof(int)) +
          (ring > chain ? ring : chain) + 512;
+}
+
+// enough for D tables and for any smaller batch run in the same workspace
+extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
+  size_t need = fill_workspace_need(N, M, D);
+  for (int d2 = 1; d2 <= 2 && d2 < D; d2++) {
+    const size_t n2 = fill_workspace_need(N, M, d2);
+    if (n2 > need) need = n2;
+  }
+  return need;
 }
 
 #define STB_MODE_BFP 3    // S table, block-floating cells + table log (default)
 #define STB_MODE_SPLIT 4  // same arithmetic, recurrence and log in separate kernels / streams
 #define STB_MODE_PC 5     // same arithmetic, producer wave + consumer waves through LDS
 #define STB_MODE_CHAIN 6  // same arithmetic, one launch: column blocks chained through edge granules
+#define STB_MODE_CHAINX 7 // the chain alone in its blocks, logs by converter blocks of the same launch
 
 // auxiliary streams and an event pool for the split variant (per host thread and device)
 struct split_ctx {
@@ -1688,9 +2222,16 @@ extern "C" int stb_fill_status(void) {
 
 extern "C" int stb_default_variant(void);
 extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
-  const bool few = (uint64_t)D * M < 25000;
+  const bool few = (uint64_t)D * M <= 200000 && N >= 3 && N < (1u << 27);
   const int v = stb_default_variant();
-  const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : v == STB_FILL_CHAIN ? 3 : (few ? 1 : 2);
+  const int form = v == STB_FILL_SPLIT ? 1 : v == STB_FILL_PC ? 2 : v == STB_FILL_FUSED ? 0 : (v == STB_FILL_CHAIN || v == STB_FILL_CHAINX) ? 3 : (few ? 3 : 2);
+  if (v == STB_FILL_CHAINX && D <= 2) {
+    const chainx_geom g = chainx_geometry(N, M, D);
+    if (C_out) *C_out = g.P;
+    if (R_out) *R_out = (int)N;
+    if (launches) *launches = 1;
+    return 4;
+  }
   if (form == 3) {
     const chain_geom g = chain_geometry(N, M, D);
     if (C_out) *C_out = g.P;
@@ -1705,7 +2246,7 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
   if (launches) *launches = ((int)N - 1 + R - 1) / R;
-  return form; /* 0 fused (k_fill_bfp), 1 split (k_rec + k_logconv), 2 producer/consumer (k_fill_pc), 3 chain */
+  return form; /* 0 fused (k_fill_bfp), 1 split (k_rec + k_logconv), 2 producer/consumer (k_fill_pc), 3 chain, 4 chain with external converters */
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -1716,8 +2257,8 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   if (N < 2 || M < 2) return fail("%s: bounds N=%u M=%u too small", who, N, M);
   if (!a_host || !d_tables || !d_ws || (mode != STB_MODE_VRATIO && !d_S1))
     return fail("%s: null pointer", who);
-  if (ws_bytes < stb_fill_workspace_bytes(N, M, D))
-    return fail("%s: workspace %zu < %zu", who, ws_bytes, stb_fill_workspace_bytes(N, M, D));
+  if (ws_bytes < fill_workspace_need(N, M, D))
+    return fail("%s: workspace %zu < %zu", who, ws_bytes, fill_workspace_need(N, M, D));
   const uint64_t need = (mode == STB_MODE_VRATIO) ? stb_vtable_elems(N, M) : stb_table_elems(N, M);
   if (D > 1 && (table_stride < need || (mode != STB_MODE_VRATIO && s1_stride < N)))
     return fail("%s: strides too small", who);
@@ -1737,8 +2278,10 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   if (H > 64 * C - C) return fail("STB_FILL_R=%d too large for C=%d", R, C);
   // rows per renormalisation period
   int P = 1;
-  if ((mode == STB_MODE_PC || mode == STB_MODE_CHAIN) && N >= (1u << 27)) mode = STB_MODE_BFP;  // see the scale bound in k_fill_pc
-  if (mode == STB_MODE_CHAIN && N < 3) mode = STB_MODE_BFP;
+  if (mode == STB_MODE_CHAINX && D > 2) mode = STB_MODE_CHAIN;  // converters need a compute unit per chunk
+  if ((mode == STB_MODE_PC || mode == STB_MODE_CHAIN || mode == STB_MODE_CHAINX) && N >= (1u << 27))
+    mode = STB_MODE_BFP;  // see the scale bound in k_fill_pc
+  if ((mode == STB_MODE_CHAIN || mode == STB_MODE_CHAINX) && N < 3) mode = STB_MODE_BFP;
   if (mode == STB_MODE_PC) {
     // geometry is fixed by the block shape: 256 columns per block, NCW consumer waves
     C = 4;
@@ -1748,7 +2291,8 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     if (R > H) R = H;
     if (R < 1) R = 1;
   }
-  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT || mode == STB_MODE_PC || mode == STB_MODE_CHAIN) {
+  if (mode == STB_MODE_BFP || mode == STB_MODE_SPLIT || mode == STB_MODE_PC || mode == STB_MODE_CHAIN ||
+      mode == STB_MODE_CHAINX) {
     if (ensure_logtab()) return 1;
     // A cell grows per row by U^n_m = n - m a + S^n_{m-1}/S^n_m, and the last term reaches n(n-1)/2
     // next to the diagonal, so the bound is N^2 per row, not N.  v starts at 2^-BFP_BIAS and the
@@ -1756,7 +2300,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     int bits = 1;
     while ((1ull << bits) < (unsigned long long)N) bits++;
     bits = 2 * bits + 1;
-    P = (mode == STB_MODE_PC || mode == STB_MODE_CHAIN ? 1450 : 1700) / bits;  // these start at 2^-700
+    P = (mode == STB_MODE_PC || mode == STB_MODE_CHAIN || mode == STB_MODE_CHAINX ? 1450 : 1700) / bits;  // these start at 2^-700
     int Penv = env_int("STB_FILL_P", 0);
     if (Penv > 0 && Penv < P) P = Penv;
     if (P < 1) P = 1;
@@ -1784,6 +2328,97 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
   const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  if (mode == STB_MODE_CHAINX) {
+    const chainx_geom cg = chainx_geometry(N, M, D);
+    int Pc = 1450;
+    {
+      int bits = 1;
+      while ((1ull << bits) < (unsigned long long)N) bits++;
+      Pc /= 2 * bits + 1;
+    }
+    const int Penv = env_int("STB_FILL_P", 0);
+    if (Penv > 0 && Penv < Pc) Pc = Penv;
+    chain_args X;
+    chainx_args Y;
+    X.TP = Pc / CH_U;
+    if (X.TP < 1) return fail("%s: renormalisation period %d shorter than a trip", who, Pc);
+    X.G = cg.G;
+    X.D = D;
+    X.B = cg.B;
+    X.EV = cg.EV;
+    X.NP = cg.NP;
+    char *cb = (char *)align_up((size_t)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int)), 256);
+    if ((size_t)(cb - (char *)d_ws) + cg.bytes > ws_bytes) return fail("%s: workspace too small for the chain form", who);
+    X.hdr = (unsigned *)cb;
+    Y.progress = (unsigned *)(cb + 256);
+    X.edge_e = (unsigned long long *)(cb + 256 + cg.prog_bytes);
+    X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
+    char *tail = cb + align_up(cg.zero_bytes, 256);
+    Y.dump = (unsigned long long *)tail;
+    Y.expo = (int *)(tail + 2048);
+    Y.EWh = cg.EWh;
+    Y.NPer = cg.NPer;
+    Y.Q = cg.Q;
+    X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
+    X.dbg = env_int("STB_CHAIN_DBG", 0);
+    HIPCHK(hipMemsetAsync(cb, 0, align_up(cg.zero_bytes, 16), st));
+    g_chain_hdr = X.hdr;
+    hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+      while (g_prof.made < g_prof.used + 2) {
+        if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+        g_prof.made++;
+      }
+      if (g_prof.made >= g_prof.used + 2) {
+        p0 = g_prof.ev[g_prof.used];
+        p1 = g_prof.ev[g_prof.used + 1];
+        g_prof.used += 2;
+      }
+    }
+#ifdef STB_STAMPS
+    static unsigned long long *h_xdbg = nullptr;
+    {
+      unsigned long long *z = nullptr;
+      if (getenv("STB_STAMP_FILE")) {
+        if (!h_xdbg) HIPCHK(hipMalloc(&h_xdbg, sizeof(unsigned long long) * 512 * 16 * 4));
+        HIPCHK(hipMemsetAsync(h_xdbg, 0, sizeof(unsigned long long) * 512 * 16 * 4, st));
+        z = h_xdbg;
+      }
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dbg), &z, sizeof(z), 0, hipMemcpyHostToDevice, st));
+    }
+#endif
+    const dim3 grid(((unsigned)cg.B + (unsigned)cg.Q) * (unsigned)D);
+#define STB_LAUNCH_CHAINX(PP)                                                                  \
+  do {                                                                                         \
+    if (p0)                                                                                    \
+      hipExtLaunchKernelGGL((k_fill_chainx<PP>), grid, dim3(512), 0, st, p0, p1, 0, A, X, Y);  \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_fill_chainx<PP>), grid, dim3(512), 0, st, A, X, Y);                \
+  } while (0)
+    if (cg.P == 1) STB_LAUNCH_CHAINX(1);
+    else if (cg.P == 2) STB_LAUNCH_CHAINX(2);
+    else STB_LAUNCH_CHAINX(4);
+#undef STB_LAUNCH_CHAINX
+    HIPCHK(hipGetLastError());
+#ifdef STB_STAMPS
+    if (getenv("STB_STAMP_FILE") && h_xdbg) {
+      HIPCHK(hipStreamSynchronize(st));
+      const size_t cnt = (size_t)512 * 16 * 4;
+      unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+      HIPCHK(hipMemcpy(h, h_xdbg, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("STB_STAMP_FILE"), "w");
+      for (int jj = 0; jj < 512; jj++)
+        for (int w = 0; w < 16; w++) {
+          unsigned long long *q = h + ((size_t)jj * 16 + w) * 4;
+          if (q[1]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, w, q[0], q[1], q[2], q[3]);
+        }
+      fclose(f);
+      free(h);
+    }
+#endif
+    return 0;
+  }
   if (mode == STB_MODE_CHAIN) {
     const chain_geom cg = chain_geometry(N, M, D);
     int Pc = 1450;
@@ -1808,6 +2443,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     X.edge_e = (unsigned long long *)(cb + 256);
     X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
     X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
+    X.dbg = env_int("STB_CHAIN_DBG", 0);
     HIPCHK(hipMemsetAsync(cb, 0, align_up(cg.bytes, 16), st));
     g_chain_hdr = X.hdr;
     hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
@@ -2062,7 +2698,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 extern "C" int stb_default_variant(void) {
   const int v = env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
   return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
-          v == STB_FILL_PC || v == STB_FILL_CHAIN)
+          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX)
              ? v
              : STB_FILL_SCALED;
 }
@@ -2071,18 +2707,20 @@ extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, d
                           uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws,
                           size_t ws_bytes, int variant, void *stream) {
   STB_ENTRY;
-  // STB_FILL_SCALED picks the form by how many tables are in flight: with one or two, the fill is
-  // bound by the serial row chain and the split form (shortest chain, logs on other CUs) wins; from
-  // three 10^4-column tables on, the producer/consumer form (8 B per cell instead of 24, logs on the
-  // other SIMDs of the same CU) is faster and keeps gaining up to HBM-bound batches
-  const bool few = (uint64_t)D * M < 25000;
+  // STB_FILL_SCALED picks the form by how many table columns are in flight.  Up to about twenty
+  // 10^4-column tables the chain form wins (one launch, no halo; measured 1.0 vs 1.3 ms for one
+  // table against the split form, 1.3 vs 1.8 ms for eight against the producer/consumer form);
+  // beyond that its one block per compute unit is too few waves and the producer/consumer form,
+  // which re-launches per 128 rows but keeps six blocks per compute unit, is faster.
+  const bool few = (uint64_t)D * M <= 200000;
   const int mode = variant == STB_FILL_LOGDOMAIN ? STB_MODE_LOGDOM
                    : variant == STB_FILL_SCALED_STEP ? STB_MODE_SCALED
                    : variant == STB_FILL_SPLIT ? STB_MODE_SPLIT
                    : variant == STB_FILL_FUSED ? STB_MODE_BFP
                    : variant == STB_FILL_PC ? STB_MODE_PC
                    : variant == STB_FILL_CHAIN ? STB_MODE_CHAIN
-                   : (few ? STB_MODE_SPLIT : STB_MODE_PC);
+                   : variant == STB_FILL_CHAINX ? STB_MODE_CHAINX
+                   : (few ? STB_MODE_CHAIN : STB_MODE_PC);
   return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, mode,
                      (hipStream_t)stream);
 }
@@ -2574,6 +3212,7 @@ extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, in
   HIPCHK(hipEventRecord(g->ev[3], g->st));
   HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * 2 * g->Dmax, hipMemcpyDeviceToHost, g->st));
   HIPCHK(hipStreamSynchronize(g->st));
+  if (stb_fill_status()) return 1;
   for (int d = 0; d < D; d++) out_host[d] = h[g->Dmax + d] + h[d];
   if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
   if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));

@@ -51,3 +51,15 @@ for cb in combos:
     print(f"N={N} M={M} D={D} chain P={C} NC={RH}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
           f"{cells * 8 / ms / 1e6:8.1f} GB/s  max rel err vs auto on probe rows {err:.2e}", flush=True)
     del T2
+
+for P in (os.environ.get("CHAINX_P", "4,2").split(",") if D <= 2 else []):
+    os.environ["STB_CHAINX_P"] = P
+    T2 = capi.DeviceTables(N, M, D=D)
+    T2.tables.fill_(float("nan"))
+    ms = timed(T2, capi.FILL_CHAINX)
+    T2.status()
+    got = [T2.row(d, n) for d in range(D) for n in (3, 4, 130, N // 3, N - 1, N)]
+    err = max(((g - r).abs() / r.abs().clamp(min=1.0)).max().item() for g, r in zip(got, ref_rows))
+    print(f"N={N} M={M} D={D} chainx P={P}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
+          f"{cells * 8 / ms / 1e6:8.1f} GB/s  max rel err vs auto on probe rows {err:.2e}", flush=True)
+    del T2
