@@ -1177,11 +1177,11 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
   asm volatile("" ::: "memory");
 }
 
-template <int P, int NC>
-__global__ __launch_bounds__(64 * (P + NC + 2)) void k_fill_chain(fill_args A, chain_args X) {
+template <int P, int NC, int NF>
+__global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args A, chain_args X) {
   constexpr int U = CH_U, RD = CH_RD, RE = CH_RE;
   constexpr int OW = 64 * P;  // columns of a block
-  static_assert(P >= 1 && P <= NC && P + NC + 2 <= 16, "block shape");
+  static_assert(P >= 1 && P <= NC && NF >= 1 && P + NC + 1 + NF <= 16, "block shape");
   __shared__ double2 lt[128];
   __shared__ __attribute__((aligned(16))) double vbuf[RD][U][OW];
   __shared__ int ebuf[4][OW];
@@ -1439,13 +1439,17 @@ __global__ __launch_bounds__(64 * (P + NC + 2)) void k_fill_chain(fill_args A, c
       }
     }
   } else {
-    // ================= fetcher =================
+    // ================= fetchers (waves P+NC+1 ..) =================
     if (has_left) {
       const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
       const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (j - 1)) * X.NP;
       unsigned long long t_begin = 0;
       bool timing = false;
       for (int t = g0b; t < G;) {
+        // (NF fetcher waves run this same loop out of step: each delivers what its own load found
+        // complete beyond what has been delivered already, so the polling period divides by NF)
+        t = max(t, lds_peek(&edge_ready));
+        if (t >= G) break;
         // trips t .. t+nt-1 may be written: their ring slots were read by the first producer
         int lim = lds_peek(&prod_done[0]) + RE;
         if (lim > G) lim = G;
@@ -1504,11 +1508,14 @@ __global__ __launch_bounds__(64 * (P + NC + 2)) void k_fill_chain(fill_args A, c
           xa = ldexp(xa, ea1 - ea);
           xb = ldexp(xb, eb1 - eb);
         }
-        if (ka < nr) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
-        if (kb < nr) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
-        if (lane >= 1 && lane <= nr) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+        const int cur = lds_peek(&edge_ready);  // trips below it were delivered by another fetcher
+        if (ka < nr && t + ka >= cur) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
+        if (kb < nr && t + kb >= cur) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
+        if (lane >= 1 && lane <= nr && t - 1 + lane >= cur) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
         t += nr;
-        lds_post(&edge_ready, t);
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_max(&edge_ready, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
       }
     }
   }
@@ -2048,7 +2055,7 @@ static int env_int(const char *name, int dflt) {
 
 // geometry of the chain form (k_fill_chain): column blocks per table, trips, edge stream lengths
 struct chain_geom {
-  int P, NC, B, G;
+  int P, NC, NF, B, G;
   uint64_t EV, NP;
   size_t bytes;  // header + edge streams for D tables
 };
@@ -2058,7 +2065,10 @@ static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   if (g.P != 1 && g.P != 2 && g.P != 4) g.P = 4;
   g.NC = env_int("STB_CHAIN_NC", g.P == 4 ? 10 : g.P == 2 ? 6 : 3);
   if (g.NC < g.P) g.NC = g.P;
-  if (g.P + g.NC + 2 > 16) g.NC = 14 - g.P;
+  g.NF = env_int("STB_CHAIN_NF", 1);
+  if (g.NF < 1) g.NF = 1;
+  if (g.NF > 3) g.NF = 3;
+  if (g.P + g.NC + 1 + g.NF > 16) g.NC = 15 - g.NF - g.P;
   const unsigned cols = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
   g.B = (int)((cols + 64 * g.P - 1) / (64 * g.P));
   if (g.B < 1) g.B = 1;
@@ -2472,25 +2482,32 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     }
 #endif
     const dim3 grid((unsigned)cg.B * (unsigned)D);
-#define STB_LAUNCH_CHAIN(PP, NN)                                                                         \
-  do {                                                                                                   \
-    if (p0)                                                                                              \
-      hipExtLaunchKernelGGL((k_fill_chain<PP, NN>), grid, dim3(64 * (PP + NN + 2)), 0, st, p0, p1, 0, A, X); \
-    else                                                                                                 \
-      hipLaunchKernelGGL((k_fill_chain<PP, NN>), grid, dim3(64 * (PP + NN + 2)), 0, st, A, X);           \
+#define STB_LAUNCH_CHAIN(PP, NN, FF)                                                                          \
+  do {                                                                                                        \
+    if (p0)                                                                                                   \
+      hipExtLaunchKernelGGL((k_fill_chain<PP, NN, FF>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, p0, p1, 0, A, X); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_fill_chain<PP, NN, FF>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, A, X);       \
   } while (0)
-    const int shape = cg.P * 100 + cg.NC;
+    const int shape = cg.P * 1000 + cg.NC * 10 + cg.NF;
     switch (shape) {
-      case 103: STB_LAUNCH_CHAIN(1, 3); break;
-      case 104: STB_LAUNCH_CHAIN(1, 4); break;
-      case 106: STB_LAUNCH_CHAIN(1, 6); break;
-      case 204: STB_LAUNCH_CHAIN(2, 4); break;
-      case 206: STB_LAUNCH_CHAIN(2, 6); break;
-      case 208: STB_LAUNCH_CHAIN(2, 8); break;
-      case 406: STB_LAUNCH_CHAIN(4, 6); break;
-      case 408: STB_LAUNCH_CHAIN(4, 8); break;
-      case 410: STB_LAUNCH_CHAIN(4, 10); break;
-      default: return fail("%s: no chain kernel for %d producers / %d consumers", who, cg.P, cg.NC);
+      case 1031: STB_LAUNCH_CHAIN(1, 3, 1); break;
+      case 1032: STB_LAUNCH_CHAIN(1, 3, 2); break;
+      case 1033: STB_LAUNCH_CHAIN(1, 3, 3); break;
+      case 1041: STB_LAUNCH_CHAIN(1, 4, 1); break;
+      case 1061: STB_LAUNCH_CHAIN(1, 6, 1); break;
+      case 2041: STB_LAUNCH_CHAIN(2, 4, 1); break;
+      case 2061: STB_LAUNCH_CHAIN(2, 6, 1); break;
+      case 2062: STB_LAUNCH_CHAIN(2, 6, 2); break;
+      case 2063: STB_LAUNCH_CHAIN(2, 6, 3); break;
+      case 2081: STB_LAUNCH_CHAIN(2, 8, 1); break;
+      case 2083: STB_LAUNCH_CHAIN(2, 8, 3); break;
+      case 4061: STB_LAUNCH_CHAIN(4, 6, 1); break;
+      case 4081: STB_LAUNCH_CHAIN(4, 8, 1); break;
+      case 4083: STB_LAUNCH_CHAIN(4, 8, 3); break;
+      case 4092: STB_LAUNCH_CHAIN(4, 9, 2); break;
+      case 4101: STB_LAUNCH_CHAIN(4, 10, 1); break;
+      default: return fail("%s: no chain kernel for %d producers / %d consumers / %d fetchers", who, cg.P, cg.NC, cg.NF);
     }
 #undef STB_LAUNCH_CHAIN
 #ifdef STB_STAMPS

@@ -39,20 +39,22 @@ print(f"N={N} M={M} D={D} auto: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s", 
 ref_rows = [T.row(d, n).clone() for d in range(D) for n in (3, 4, 130, N // 3, N - 1, N)]
 ref_sum = T.tables.nan_to_num(0.0, 0.0, 0.0)[:, :8].sum().item()
 for cb in combos:
-    C, RH = cb.split(":")
+    parts = cb.split(":")
+    C, RH = parts[0], parts[1]
     os.environ["STB_CHAIN_P"] = C
     os.environ["STB_CHAIN_NC"] = RH
+    os.environ["STB_CHAIN_NF"] = parts[2] if len(parts) > 2 else "1"
     T2 = capi.DeviceTables(N, M, D=D)
     T2.tables.fill_(float("nan"))
     ms = timed(T2, capi.FILL_CHAIN)
     T2.status()
     got = [T2.row(d, n) for d in range(D) for n in (3, 4, 130, N // 3, N - 1, N)]
     err = max(((g - r).abs() / r.abs().clamp(min=1.0)).max().item() for g, r in zip(got, ref_rows))
-    print(f"N={N} M={M} D={D} chain P={C} NC={RH}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
+    print(f"N={N} M={M} D={D} chain {cb}: {ms:8.3f} ms {cells / ms / 1e6:9.2f} Gcells/s "
           f"{cells * 8 / ms / 1e6:8.1f} GB/s  max rel err vs auto on probe rows {err:.2e}", flush=True)
     del T2
 
-for P in (os.environ.get("CHAINX_P", "4,2").split(",") if D <= 2 else []):
+for P in (os.environ.get("CHAINX_P", "").split(",") if D <= 2 and os.environ.get("CHAINX_P") else []):
     os.environ["STB_CHAINX_P"] = P
     T2 = capi.DeviceTables(N, M, D=D)
     T2.tables.fill_(float("nan"))
