@@ -19,6 +19,7 @@
 // No CPU fallback exists in this file: without a device every entry point fails with a message.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include <cmath>
@@ -1559,6 +1560,29 @@ __device__ __forceinline__ void store_pair_wt(double *p, double2 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 
+// the cold part of a bounded wait on an LDS counter, out of line so that the callers' row loops stay
+// straight-line code: returns false when the wait was given up (timeout, or another wave gave up)
+__device__ __attribute__((noinline)) bool chain_wait_slow(const int *cnt, int need, int *abort_flag, unsigned *hdr,
+                                                          unsigned long long timeout, unsigned code, unsigned who, int nap) {
+  const unsigned long long t_begin = wall_clock64();
+  for (;;) {
+    // (a spinning wave takes issue slots from the producer it shares a SIMD with)
+    for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+    if ((unsigned long long)wall_clock64() - t_begin > timeout) {
+      if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __hip_atomic_store(hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(hdr + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      return false;
+    }
+  }
+}
+
 struct chainx_args {
   unsigned *progress;        // [D][B][P] trips complete in the table, per producer wave; zeroed per fill
   int *expo;                 // [D][NPer][EWh] lane exponent per period and column pair
@@ -1569,10 +1593,13 @@ struct chainx_args {
 
 template <int P>
 __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, chainx_args Y) {
-  constexpr int U = CH_U, RD = 4, RE = CH_RE;
+  constexpr int U = CH_U, RD = 16, RE = CH_RE;
   constexpr int OW = 128 * P;  // columns of a producer block
   __shared__ double2 lt[128];
-  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][OW];
+  // only the LAST column of each producer's slice goes through LDS (to the next producer or the
+  // publisher); a ring of RD trips leaves the producers ~14 trips of slack against each other
+  __shared__ __attribute__((aligned(16))) double xedge[P][RD][U];
+  __shared__ double lds_pad[11776];  // (92 KB: one block per compute unit, see above)
   __shared__ int ebuf[4][OW];
   __shared__ int slot_p[RD][P];
   __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
@@ -1584,6 +1611,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = g_logtab[tid];
   for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
+  if (tid == 0) lds_pad[X.G % 11776] = 0.0;  // (keeps the pad allocated)
   __syncthreads();
   const unsigned N = A.N, M = A.M;
   const int TP = X.TP, G = X.G;
@@ -1729,32 +1757,15 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
   }
 
   // ======================= producer block (d, j) =======================
-  if (wave >= P + 3) return;
+  // helper waves: publisher, fetcher, flusher; with two producers the flusher takes wave 6 so that
+  // (waves going round-robin over the four SIMDs) no helper shares a SIMD with a producer
+  constexpr int W_PUB = P, W_FETCH = P + 1, W_FLUSH = (P <= 2) ? 6 : P + 2;
+  if (wave >= P && wave != W_PUB && wave != W_FETCH && wave != W_FLUSH) return;
+
   auto wait_ge = [&](const int *cnt, int need, unsigned code) {
     if (aborted || lds_peek(cnt) >= need) return;
-    const unsigned long long t_begin = wall_clock64();
-    for (;;) {
-      __builtin_amdgcn_s_sleep(1);
-      if (lds_peek(cnt) >= need) {
-#ifdef STB_STAMPS
-        t_wait += wall_clock64() - t_begin;
-        n_wait++;
-#endif
-        return;
-      }
-      if (lds_peek(&s_abort)) break;
-      if ((unsigned long long)wall_clock64() - t_begin > X.timeout) {
-        if (lane == 0) {
-          __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(X.hdr + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        break;
-      }
-    }
-    aborted = true;
+    if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, (unsigned)(j | (d << 16)), wave < P ? 1 : 4))
+      aborted = true;
   };
 
   if (wave < P) {
@@ -1788,9 +1799,9 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
 #pragma unroll
         for (int u = 0; u < U; u++) x[u] = edge_in[(g & (RE - 1)) * U + u];
       } else {
-        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][128 * w - 1];
+        x[0] = xedge[w - 1][(g - 1) & (RD - 1)][U - 1];
 #pragma unroll
-        for (int u = 1; u < U; u++) x[u] = vbuf[g & (RD - 1)][u - 1][128 * w - 1];
+        for (int u = 1; u < U; u++) x[u] = xedge[w - 1][g & (RD - 1)][u - 1];
       }
     };
     auto look_ahead = [&](int g) {
@@ -1800,27 +1811,22 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
       load_left(ne, g);
     };
     look_ahead(g0w);
-#ifdef STB_STAMPS
-    unsigned long long sec[6] = {0, 0, 0, 0, 0, 0}, tm = __builtin_amdgcn_s_memtime();
-#define CX_SEC(I) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sec[I] += n_ - tm; tm = n_; } while (0)
-#else
-#define CX_SEC(I) do {} while (0)
-#endif
-    for (int g = g0w; g < G; g++) {
+    // One trip.  The hot path is straight-line: everything that is rare (a counter that is short, a
+    // period boundary, the last, partial trip) sits behind one unlikely branch each.
+    auto trip = [&](int g, auto partial_tag) {
+      constexpr bool partial = decltype(partial_tag)::value;
       double e[U];
 #pragma unroll
       for (int u = 0; u < U; u++) e[u] = ne[u];
       const int next_need = (w < P - 1) ? g - RD + 2 : g - RD + 1;
-      if (n_left < g + 1 || n_next < next_need) {
+      if (__builtin_expect(n_left < g + 1 || n_next < next_need, 0)) {
         wait_ge(left_cnt, g + 1, 0x100u + (unsigned)g);
         wait_ge(next_cnt, next_need, 0x400u + (unsigned)g);  // slot g % RD read by w+1 / published
         asm volatile("" ::: "memory");
         load_left(e, g);
       }
-      CX_SEC(0);
-      if (g + 1 < G) look_ahead(g + 1);
-      CX_SEC(1);
-      if (g == g0w || tin == 0) {
+      if (g + 1 < G && !(X.dbg & 16)) look_ahead(g + 1);
+      if (__builtin_expect(g == g0w || tin == 0, 0)) {
         // ---- period set-up ----
         if (g != g0w) {  // renormalise: the larger significand back to 2^-PC_BIAS * [0.5,1)
           int kmax = -4000;
@@ -1846,65 +1852,44 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
         *reinterpret_cast<int2 *>(&ebuf[p & 3][col]) = make_int2(ep, ep);
         __hip_atomic_store(expo + (uint64_t)p * Y.EWh, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      CX_SEC(2);
       if (lane == 0) slot_p[g & (RD - 1)][w] = p & 3;
       const int r0 = 3 + g * U;
-      const unsigned pitch = stb_row_pitch((unsigned)r0, M);
-      const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch;
-      CX_SEC(3);
-      if (fast) {
-        const size_t incA = okP ? pitch : 0;
+      // (a trip never straddles a change of the row pitch: rows 3+8g .. 10+8g have lengths
+      // 1+8g .. 8+8g, inside one group of 64)
+      const size_t incA = okP ? stb_row_pitch((unsigned)r0, M) : 0;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const double t0 = wave_shr1(v1, e[u]) * s;
-          v1 = fma(coef1, v1, v0);
-          v0 = fma(coef0, v0, t0);
-          coef0 += 1.0;
-          coef1 += 1.0;
-          const double2 vv = make_double2(v0, v1);
-          *reinterpret_cast<double2 *>(&vbuf[g & (RD - 1)][u][col]) = vv;
+      for (int u = 0; u < U; u++) {
+        const double t0 = wave_shr1(v1, e[u]) * s;
+        v1 = fma(coef1, v1, v0);
+        v0 = fma(coef0, v0, t0);
+        coef0 += 1.0;
+        coef1 += 1.0;
+        const double2 vv = make_double2(v0, v1);
+        if (lane == 63) xedge[w][g & (RD - 1)][u] = v1;
+        if (partial)
+          *reinterpret_cast<double2 *>(((unsigned)(r0 + u) <= N) ? pA : dump) = vv;
+        else
           *reinterpret_cast<double2 *>(pA) = vv;
-          pA += incA;
-        }
-      } else {
-        for (int u = 0; u < U; u++) {
-          const double t0 = wave_shr1(v1, e[u]) * s;
-          v1 = fma(coef1, v1, v0);
-          v0 = fma(coef0, v0, t0);
-          coef0 += 1.0;
-          coef1 += 1.0;
-          const double2 vv = make_double2(v0, v1);
-          *reinterpret_cast<double2 *>(&vbuf[g & (RD - 1)][u][col]) = vv;
-          const int rr = r0 + u;
-          *reinterpret_cast<double2 *>(((unsigned)rr <= N) ? pA : dump) = vv;
-          if (okP) pA += stb_row_pitch((unsigned)rr, M);
-        }
+        pA += incA;
       }
-      CX_SEC(4);
       lds_post(&prod_done[w], g + 1);
       // trips up to g - CX_LAG have left the wave: at most the stores of the last CX_LAG trips
-      // (U each, plus an exponent word now and then) can still be in flight.  The publisher wave
+      // (U each, plus an exponent word now and then) can still be in flight.  The flusher wave
       // passes the count on to the converters: a store to a polled word must not sit in THIS queue.
-      if (!(X.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CX_LAG * U) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CX_LAG * U) : "memory");
       if (g + 1 - CX_LAG > g0w) lds_post(&stored_done[w], g + 1 - CX_LAG);
       if (++tin == TP) {
         tin = 0;
         p++;
       }
-      CX_SEC(5);
-    }
+    };
+    const int Gfull = ((int)N >= 2 + U) ? ((int)N - 2) / U : 0;  // trips whose rows all exist
+    int g = g0w;
+    for (; g < Gfull; g++) trip(g, std::false_type{});
+    for (; g < G; g++) trip(g, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_post(&stored_done[w], G);
-#ifdef STB_STAMPS
-    if (g_dbg && lane == 0 && d == 0 && j < 8) {
-      unsigned long long *q_ = g_dbg + ((size_t)(500 + j) * 16 + wave) * 4;
-      q_[0] = sec[0] | (sec[1] << 32);
-      q_[1] = sec[2] | (sec[3] << 32);
-      q_[2] = sec[4] | (sec[5] << 32);
-      q_[3] = 1;
-    }
-#endif
-  } else if (wave == P) {
+  } else if (wave == W_PUB) {
     // ================= publisher: the block's last column, and everybody's progress =================
     unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
     unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
@@ -1913,7 +1898,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
       const int slot = t & (RD - 1);
       if (has_right) {
         if (lane < U) {
-          unsigned long long b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][OW - 1]);
+          unsigned long long b = (unsigned long long)__double_as_longlong(xedge[P - 1][slot][lane]);
           if ((b << 1) == 0) b = CH_NEGZERO;
           __hip_atomic_store(ev_out + 3 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (lane == U) {
@@ -1923,7 +1908,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
       }
       lds_post(&pub_done, t + 1);
     }
-  } else if (wave == P + 1) {
+  } else if (wave == W_FETCH) {
     // ================= fetcher =================
     if (has_left) {
       const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
@@ -2013,8 +1998,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
         told = m;
         if (m >= G) break;
       } else {
-        if (X.dbg & 2) __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(32);
         if (lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > 4 * X.timeout) break;
       }
     }
