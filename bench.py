@@ -78,32 +78,39 @@ def sweep_extra(dev):
     g = synth.groups(1000, 1000, 4000, "wide")
     M = max(int(g.t.max()) + 1, 10)
     N = max(int(g.n.max()) + 1, M)
-    out = {"pairs": g.pairs, "N": N, "M": M}
-    h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
-                            g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p),
-                            capi.dp(g.bpar), N, M, 64)
-    if not h:
-        return {"error": capi.last_error()}
-    try:
-        for D in (1, 64):
-            x = np.ascontiguousarray(synth.discount_grid(64)[:D] if D > 1 else np.array([0.45]))
-            res = np.zeros(D)
-            mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
-            best = None
-            for _ in range(4):
-                t0 = time.perf_counter()
-                capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(res), C.byref(mf), C.byref(ms), C.byref(mt)))
-                wall = time.perf_counter() - t0
-                if best is None or wall < best[0]:
-                    best = (wall, mf.value, ms.value, mt.value)
-            wall, f_ms, s_ms, t_ms = best
-            ge = D * g.pairs
-            out[f"D{D}"] = {"grid_evals": ge, "fill_ms": f_ms, "sweep_ms": s_ms, "terms_ms": t_ms, "wall_ms": wall * 1e3,
-                            "grid_evals_per_s_sweep_only": ge / (s_ms * 1e-3),
-                            "grid_evals_per_s_end_to_end": ge / wall,
-                            "sweep_algorithmic_GBs": ge * (8 + 6.0 / D) / (s_ms * 1e-3) / 1e9}
-    finally:
-        L.stb_groups_free(h)
+    out = {"pairs": g.pairs, "N": N, "M": M,
+           "note": "fused: the chain fill sums count*log S itself (no table stored, no second pass); "
+                   "two_pass: tables stored, then the sorted gather-sum (fill_ms / sweep_ms / terms_ms are device times)"}
+    for label, fused in (("fused", "1"), ("two_pass", "0")):
+        os.environ["STB_ATERMS_FUSED"] = fused
+        h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
+                                g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p),
+                                capi.dp(g.bpar), N, M, 64)
+        if not h:
+            return {"error": capi.last_error()}
+        try:
+            for D in (1, 64):
+                x = np.ascontiguousarray(synth.discount_grid(64)[:D] if D > 1 else np.array([0.45]))
+                res = np.zeros(D)
+                mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
+                best = None
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(res), C.byref(mf), C.byref(ms), C.byref(mt)))
+                    wall = time.perf_counter() - t0
+                    if best is None or wall < best[0]:
+                        best = (wall, mf.value, ms.value, mt.value)
+                wall, f_ms, s_ms, t_ms = best
+                ge = D * g.pairs
+                rec = {"grid_evals": ge, "fill_ms": f_ms, "sweep_ms": s_ms, "terms_ms": t_ms, "wall_ms": wall * 1e3,
+                       "grid_evals_per_s_end_to_end": ge / wall}
+                if label == "two_pass":
+                    rec["grid_evals_per_s_sweep_only"] = ge / (s_ms * 1e-3)
+                    rec["sweep_algorithmic_GBs"] = ge * (8 + 6.0 / D) / (s_ms * 1e-3) / 1e9
+                out.setdefault(f"D{D}", {})[label] = rec
+        finally:
+            L.stb_groups_free(h)
+    os.environ.pop("STB_ATERMS_FUSED", None)
     # one whole samplea() / sampleb() call (host ARMS + device posteriors) on the same groups, and
     # the reference's own samplea on this box's host CPU when oracle/_ref is present
     try:

@@ -1165,6 +1165,8 @@ struct chain_args {
   int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
   int dbg;                     // diagnostic switches (STB_CHAIN_DBG), 0 in production
+  const unsigned *cnt;         // DOT kernels: occurrence count per cell, in the table's own layout
+  double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
 };
 
 __device__ __forceinline__ int lds_peek(const int *p) {
@@ -1178,7 +1180,9 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
   asm volatile("" ::: "memory");
 }
 
-template <int P, int NC, int NF>
+// DOT: the logs are not stored; each is multiplied by the cell's occurrence count and summed (the
+// whole of aterms' table part, lib/samplea.c:68-80, without a table in memory or a second pass).
+template <int P, int NC, int NF, bool DOT>
 __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args A, chain_args X) {
   constexpr int U = CH_U, RD = CH_RD, RE = CH_RE;
   constexpr int OW = 64 * P;  // columns of a block
@@ -1364,6 +1368,7 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
     const int ci = wave - P;
     int w = ci % P, t = g0b + ci / P;
     int done = 0;
+    double acc = 0.0;  // (DOT) this lane's share of the sum
     for (; t < G;) {
       if (t >= first_trip(w)) {
         wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
@@ -1376,10 +1381,17 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         const unsigned pitch = stb_row_pitch((unsigned)r0, M);
         const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch &&
                           !(j == 0 && t == 0 && w == 0);
-        double *rowbase = table + stb_row_offset((unsigned)r0, M);
+        const uint64_t rowoff = stb_row_offset((unsigned)r0, M);
+        double *rowbase = table + rowoff;
+        const unsigned *cntbase = X.cnt + rowoff;
         if (fast) {
           double x[U], z[U], kf[U], r[U], pl[U];
           double2 tt[U];
+          unsigned cn[U];
+          if (DOT) {
+#pragma unroll
+            for (int u = 0; u < U; u++) cn[u] = cntbase[(size_t)u * pitch + coff];
+          }
 #pragma unroll
           for (int u = 0; u < U; u++) x[u] = vbuf[slot][u][ridx];
 #pragma unroll
@@ -1401,13 +1413,30 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
 #pragma unroll
           for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0);
 #pragma unroll
-          for (int u = 0; u < U; u++)
-            rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+          for (int u = 0; u < U; u++) {
+            const double val = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+            if (DOT) {
+              // (cells outside the table proper -- the row slack -- have count 0 and may hold anything)
+              acc += (cn[u] != 0) ? (double)cn[u] * val : 0.0;
+            } else {
+              rowbase[(size_t)u * pitch + coff] = val;
+            }
+          }
         } else {
           for (int u = 0; u < U; u++) {
             const int rr = r0 + u;
-            if ((unsigned)rr <= N && cc >= 2) rowbase[coff] = bfp_log(vbuf[slot][u][ridx], myep, lt);
-            rowbase += stb_row_pitch((unsigned)rr, M);
+            if ((unsigned)rr <= N && cc >= 2) {
+              const double val = bfp_log(vbuf[slot][u][ridx], myep, lt);
+              if (DOT) {
+                const unsigned c = cntbase[coff];
+                acc += (c != 0) ? (double)c * val : 0.0;
+              } else {
+                rowbase[coff] = val;
+              }
+            }
+            const unsigned pt = stb_row_pitch((unsigned)rr, M);
+            rowbase += pt;
+            cntbase += pt;
           }
         }
       }
@@ -1419,6 +1448,12 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         w -= P;
         t++;
       }
+    }
+    if (DOT) {
+      // fixed-shape tree over the wave: the same bits on every run
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) X.dotp[((uint64_t)d * X.B + j) * NC + ci] = acc;
     }
   } else if (wave == P + NC) {
     // ================= publisher =================
@@ -2203,6 +2238,14 @@ extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
 // header of the last chain fill issued by this thread (ticket, error code, error detail)
 static thread_local unsigned *g_chain_hdr = nullptr;
 
+// set by stb_groups_aterms around its fill: run the chain form as a DOT kernel (no table stored)
+struct dot_request {
+  const unsigned *cnt = nullptr;
+  double *dotp = nullptr;
+  int parts_per_table = 0;  // out: B * NC
+};
+static thread_local dot_request *g_dot_req = nullptr;
+
 extern "C" int stb_fill_status(void) {
   STB_ENTRY;
   if (!g_chain_hdr) return 0;
@@ -2466,33 +2509,37 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     }
 #endif
     const dim3 grid((unsigned)cg.B * (unsigned)D);
-#define STB_LAUNCH_CHAIN(PP, NN, FF)                                                                          \
+    X.cnt = g_dot_req ? g_dot_req->cnt : nullptr;
+    X.dotp = g_dot_req ? g_dot_req->dotp : nullptr;
+    if (g_dot_req) g_dot_req->parts_per_table = cg.B * cg.NC;
+#define STB_LAUNCH_CHAIN1(PP, NN, FF, DD)                                                                      \
   do {                                                                                                        \
     if (p0)                                                                                                   \
-      hipExtLaunchKernelGGL((k_fill_chain<PP, NN, FF>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, p0, p1, 0, A, X); \
+      hipExtLaunchKernelGGL((k_fill_chain<PP, NN, FF, DD>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, p0, p1, 0, A, X); \
     else                                                                                                      \
-      hipLaunchKernelGGL((k_fill_chain<PP, NN, FF>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, A, X);       \
+      hipLaunchKernelGGL((k_fill_chain<PP, NN, FF, DD>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, A, X);   \
+  } while (0)
+#define STB_LAUNCH_CHAIN(PP, NN, FF)               \
+  do {                                             \
+    if (X.cnt) STB_LAUNCH_CHAIN1(PP, NN, FF, true); \
+    else STB_LAUNCH_CHAIN1(PP, NN, FF, false);      \
   } while (0)
     const int shape = cg.P * 1000 + cg.NC * 10 + cg.NF;
     switch (shape) {
       case 1031: STB_LAUNCH_CHAIN(1, 3, 1); break;
-      case 1032: STB_LAUNCH_CHAIN(1, 3, 2); break;
       case 1033: STB_LAUNCH_CHAIN(1, 3, 3); break;
-      case 1041: STB_LAUNCH_CHAIN(1, 4, 1); break;
       case 1061: STB_LAUNCH_CHAIN(1, 6, 1); break;
       case 2041: STB_LAUNCH_CHAIN(2, 4, 1); break;
       case 2061: STB_LAUNCH_CHAIN(2, 6, 1); break;
-      case 2062: STB_LAUNCH_CHAIN(2, 6, 2); break;
       case 2063: STB_LAUNCH_CHAIN(2, 6, 3); break;
       case 2081: STB_LAUNCH_CHAIN(2, 8, 1); break;
-      case 2083: STB_LAUNCH_CHAIN(2, 8, 3); break;
       case 4061: STB_LAUNCH_CHAIN(4, 6, 1); break;
       case 4081: STB_LAUNCH_CHAIN(4, 8, 1); break;
       case 4083: STB_LAUNCH_CHAIN(4, 8, 3); break;
-      case 4092: STB_LAUNCH_CHAIN(4, 9, 2); break;
       case 4101: STB_LAUNCH_CHAIN(4, 10, 1); break;
       default: return fail("%s: no chain kernel for %d producers / %d consumers / %d fetchers", who, cg.P, cg.NC, cg.NF);
     }
+#undef STB_LAUNCH_CHAIN1
 #undef STB_LAUNCH_CHAIN
 #ifdef STB_STAMPS
     if (getenv("STB_STAMP_FILE") && h_cdbg) {
@@ -3057,6 +3104,15 @@ struct stb_groups {
   size_t ws_fill, ws_sweep, ws_terms;
   hipStream_t st;
   hipEvent_t ev[4];
+  // fused evaluation (stb_groups_aterms with the chain form): occurrence count per table cell, the
+  // pairs that do not address a table cell (t = 1, t = n, out of bounds), partial sums of the fill
+  unsigned *d_cnt;
+  uint32_t *d_n2;
+  uint16_t *d_t2;
+  uint64_t G2;
+  double *d_dotp;
+  size_t dotp_elems;
+  int fused;
 };
 
 // The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
@@ -3117,7 +3173,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   STB_ENTRY;
   if (!g) return;
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
-                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms};
+                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto &e : g->ev)
@@ -3135,6 +3191,31 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
       return nullptr;                                                                         \
     }                                                                                         \
   } while (0)
+
+// occurrence count of every table cell among the pairs (same classification as k_sweep_partial)
+__global__ void k_count_pairs(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M,
+                              unsigned *cnt) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  if (nn <= 1 || nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) return;
+  atomicAdd(&cnt[stb_row_offset(nn, M) + (tt - 2)], 1u);
+}
+
+// out[d] += sum of the DOT kernel's partial sums of table d, in a fixed order
+__global__ __launch_bounds__(64) void k_dot_reduce(const double *dotp, int parts, double *out) {
+  const int d = blockIdx.x, lane = threadIdx.x;
+  dd_t acc{0.0, 0.0};
+  for (int i = lane; i < parts; i += 64) dd_add(acc, dotp[(size_t)d * parts + i]);
+  // lanes in order, on lane 0
+  dd_t tot{0.0, 0.0};
+  for (int l = 0; l < 64; l++) {
+    const double hi = __shfl(acc.hi, l), lo = __shfl(acc.lo, l);
+    dd_add(tot, hi);
+    dd_add(tot, lo);
+  }
+  if (lane == 0) out[d] += tot.hi + tot.lo;
+}
 
 extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T,
                                            const uint32_t *nflat, const uint16_t *tflat,
@@ -3188,6 +3269,58 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
     stb_groups_free(g);
     return nullptr;
   }
+  // ---- fused evaluation: count slab + the pairs outside the table ----
+  g->fused = env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);
+  if (g->fused) {
+    const uint64_t elems = stb_table_elems(N, M);
+    GCHK(hipMalloc(&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
+    GCHK(hipMemsetAsync(g->d_cnt, 0, sizeof(unsigned) * (elems ? elems : 1), g->st));
+    if (G)
+      hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t, G,
+                         N, M, g->d_cnt);
+    uint64_t G2 = 0;
+    for (uint64_t q = 0; q < G; q++) {
+      const unsigned nn = nflat[q], tt = tflat[q];
+      if (nn > 1 && (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N)) G2++;
+    }
+    g->G2 = G2;
+    uint32_t *hn = (uint32_t *)malloc(sizeof(uint32_t) * (G2 ? G2 : 1));
+    uint16_t *ht = (uint16_t *)malloc(sizeof(uint16_t) * (G2 ? G2 : 1));
+    if (!hn || !ht) {
+      free(hn);
+      free(ht);
+      fail("stb_groups_create: out of host memory");
+      stb_groups_free(g);
+      return nullptr;
+    }
+    uint64_t k2 = 0;
+    for (uint64_t q = 0; q < G; q++) {
+      const unsigned nn = nflat[q], tt = tflat[q];
+      if (nn > 1 && (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N)) {
+        hn[k2] = nn;
+        ht[k2] = (uint16_t)tt;
+        k2++;
+      }
+    }
+    hipError_t e1 = hipMalloc(&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
+    hipError_t e2 = hipMalloc(&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
+    if (e1 == hipSuccess && e2 == hipSuccess && G2) {
+      e1 = hipMemcpy(g->d_n2, hn, sizeof(uint32_t) * G2, hipMemcpyHostToDevice);
+      e2 = hipMemcpy(g->d_t2, ht, sizeof(uint16_t) * G2, hipMemcpyHostToDevice);
+    }
+    free(hn);
+    free(ht);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      fail("stb_groups_create: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      stb_groups_free(g);
+      return nullptr;
+    }
+    // partial sums: at most (column blocks of 64) x 14 consumer waves per table
+    g->dotp_elems = (size_t)Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+    GCHK(hipMalloc(&g->d_dotp, sizeof(double) * g->dotp_elems));
+    GCHK(hipStreamSynchronize(g->st));
+    GCHK(hipGetLastError());
+  }
   return g;
 }
 
@@ -3199,13 +3332,33 @@ extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, in
   if (D < 1 || D > g->Dmax) return fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
   double h[2 * STB_TERMS_DMAX];
   HIPCHK(hipEventRecord(g->ev[0], g->st));
-  if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
-                 g->ws_fill, stb_default_variant(), g->st))
-    return 1;
-  HIPCHK(hipEventRecord(g->ev[1], g->st));
-  if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
-                  g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
-    return 1;
+  const int v = stb_default_variant();
+  if (g->fused && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN)) {
+    // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
+    // then the few pairs that address no cell (t = 1 -> S1, t = n -> 0, out of bounds -> -inf)
+    dot_request req;
+    req.cnt = g->d_cnt;
+    req.dotp = g->d_dotp;
+    g_dot_req = &req;
+    const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
+                              g->ws_fill, STB_FILL_CHAIN, g->st);
+    g_dot_req = nullptr;
+    if (rc) return 1;
+    if ((size_t)D * req.parts_per_table > g->dotp_elems) return fail("stb_groups_aterms: partial-sum buffer too small");
+    HIPCHK(hipEventRecord(g->ev[1], g->st));
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+    hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(64), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
+  } else {
+    if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
+                   g->ws_fill, v, g->st))
+      return 1;
+    HIPCHK(hipEventRecord(g->ev[1], g->st));
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+  }
   HIPCHK(hipEventRecord(g->ev[2], g->st));
   if (stb_restaurant_terms(x_host, D, g->d_T, g->d_bpar, (uint64_t)g->I, g->d_out + g->Dmax,
                            g->d_ws_terms, g->ws_terms, g->st))

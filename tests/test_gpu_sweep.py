@@ -142,3 +142,46 @@ def test_config4_shape_sweep_is_deterministic():
     a = capi.sweep(T, dg).cpu().numpy()
     b = capi.sweep(T, dg).cpu().numpy()
     assert a[0] == b[0] and np.isfinite(a[0])
+
+
+def test_fused_aterms_equals_table_then_sweep(monkeypatch):
+    """stb_groups_aterms with the chain form never stores the tables (count * log S summed inside the
+    fill); it must agree with the stored-table + gather path, edge pairs included"""
+    L = capi.lib()
+    g = synth.groups(80, 60, 900, "wide")
+    n, t = g.n.copy(), g.t.copy()
+    n[0], t[0] = 1, 1          # skipped
+    n[1], t[1] = 77, 77        # t = n: contributes 0
+    n[2], t[2] = 500, 1        # t = 1: S1
+    n[3], t[3] = 3, 2          # first cell of the table
+    n[4], t[4] = 900, 2
+    n[5], t[5] = 900, 899      # next to the diagonal
+    n[6:40], t[6:40] = 400, 123  # one cell many times
+    N, M = 900, 900
+    x = np.array([0.11, 0.5, 0.83])
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("STB_ATERMS_FUSED", fused)
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar),
+                                N, M, len(x))
+        assert h, capi.last_error()
+        try:
+            out = np.zeros(len(x))
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), len(x), capi.dp(out)))
+            outs.append(out)
+        finally:
+            L.stb_groups_free(h)
+    assert np.all(np.isfinite(outs[0]))
+    assert orc.close(outs[0], outs[1], 1e-12), (outs[0], outs[1])
+    # an out-of-bounds pair makes the whole sum -inf on both paths
+    n[7], t[7] = 50, 60
+    for fused in ("1", "0"):
+        monkeypatch.setenv("STB_ATERMS_FUSED", fused)
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar),
+                                N, M, len(x))
+        try:
+            out = np.zeros(len(x))
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), len(x), capi.dp(out)))
+            assert np.all(np.isneginf(out))
+        finally:
+            L.stb_groups_free(h)
