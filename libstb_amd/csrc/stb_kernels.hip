@@ -3112,7 +3112,7 @@ struct stb_groups {
   uint64_t G2;
   double *d_dotp;
   size_t dotp_elems;
-  int fused;
+  int fused, fused_ready;
 };
 
 // The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
@@ -3269,59 +3269,62 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
     stb_groups_free(g);
     return nullptr;
   }
-  // ---- fused evaluation: count slab + the pairs outside the table ----
-  g->fused = env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);
-  if (g->fused) {
-    const uint64_t elems = stb_table_elems(N, M);
-    GCHK(hipMalloc(&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
-    GCHK(hipMemsetAsync(g->d_cnt, 0, sizeof(unsigned) * (elems ? elems : 1), g->st));
-    if (G)
-      hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t, G,
-                         N, M, g->d_cnt);
-    uint64_t G2 = 0;
-    for (uint64_t q = 0; q < G; q++) {
-      const unsigned nn = nflat[q], tt = tflat[q];
-      if (nn > 1 && (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N)) G2++;
-    }
-    g->G2 = G2;
-    uint32_t *hn = (uint32_t *)malloc(sizeof(uint32_t) * (G2 ? G2 : 1));
-    uint16_t *ht = (uint16_t *)malloc(sizeof(uint16_t) * (G2 ? G2 : 1));
-    if (!hn || !ht) {
-      free(hn);
-      free(ht);
-      fail("stb_groups_create: out of host memory");
-      stb_groups_free(g);
-      return nullptr;
-    }
-    uint64_t k2 = 0;
-    for (uint64_t q = 0; q < G; q++) {
-      const unsigned nn = nflat[q], tt = tflat[q];
+  g->fused = env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);  // set up on first use
+  return g;
+}
+
+// Lazy set-up of the fused evaluation (first call with more than one discount): occurrence count
+// per table cell, and the pairs that address no cell.  The pairs come back from the device in their
+// sorted order, so the result does not depend on the order the caller supplied them in.
+static int groups_fused_setup(stb_groups_t *g) {
+  const unsigned N = g->N, M = g->M;
+  const uint64_t G = g->G;
+  const uint64_t elems = stb_table_elems(N, M);
+  HIPCHK(hipMalloc(&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
+  HIPCHK(hipMemsetAsync(g->d_cnt, 0, sizeof(unsigned) * (elems ? elems : 1), g->st));
+  if (G)
+    hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t, G, N,
+                       M, g->d_cnt);
+  uint32_t *hn = (uint32_t *)malloc(sizeof(uint32_t) * (G ? G : 1));
+  uint16_t *ht = (uint16_t *)malloc(sizeof(uint16_t) * (G ? G : 1));
+  if (!hn || !ht) {
+    free(hn);
+    free(ht);
+    return fail("stb_groups_aterms: out of host memory");
+  }
+  hipError_t e1 = hipSuccess, e2 = hipSuccess;
+  if (G) {
+    e1 = hipMemcpyAsync(hn, g->d_n, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, g->st);
+    e2 = hipMemcpyAsync(ht, g->d_t, sizeof(uint16_t) * G, hipMemcpyDeviceToHost, g->st);
+  }
+  if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(g->st);
+  uint64_t G2 = 0;
+  if (e1 == hipSuccess && e2 == hipSuccess) {
+    for (uint64_t q = 0; q < G; q++) {  // compact in place: the pairs outside the table
+      const unsigned nn = hn[q], tt = ht[q];
       if (nn > 1 && (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N)) {
-        hn[k2] = nn;
-        ht[k2] = (uint16_t)tt;
-        k2++;
+        hn[G2] = nn;
+        ht[G2] = (uint16_t)tt;
+        G2++;
       }
     }
-    hipError_t e1 = hipMalloc(&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
-    hipError_t e2 = hipMalloc(&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
+    g->G2 = G2;
+    e1 = hipMalloc(&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
+    if (e1 == hipSuccess) e2 = hipMalloc(&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
     if (e1 == hipSuccess && e2 == hipSuccess && G2) {
       e1 = hipMemcpy(g->d_n2, hn, sizeof(uint32_t) * G2, hipMemcpyHostToDevice);
       e2 = hipMemcpy(g->d_t2, ht, sizeof(uint16_t) * G2, hipMemcpyHostToDevice);
     }
-    free(hn);
-    free(ht);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      fail("stb_groups_create: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-      stb_groups_free(g);
-      return nullptr;
-    }
-    // partial sums: at most (column blocks of 64) x 14 consumer waves per table
-    g->dotp_elems = (size_t)Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
-    GCHK(hipMalloc(&g->d_dotp, sizeof(double) * g->dotp_elems));
-    GCHK(hipStreamSynchronize(g->st));
-    GCHK(hipGetLastError());
   }
-  return g;
+  free(hn);
+  free(ht);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail("stb_groups_aterms: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  // partial sums: at most (column blocks of 64) x 16 waves per table
+  g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+  HIPCHK(hipMalloc(&g->d_dotp, sizeof(double) * g->dotp_elems));
+  HIPCHK(hipGetLastError());
+  g->fused_ready = 1;
+  return 0;
 }
 
 extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D,
@@ -3331,9 +3334,12 @@ extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, in
   if (!g) return fail("stb_groups_aterms: null group set");
   if (D < 1 || D > g->Dmax) return fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
   double h[2 * STB_TERMS_DMAX];
-  HIPCHK(hipEventRecord(g->ev[0], g->st));
   const int v = stb_default_variant();
-  if (g->fused && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN)) {
+  // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
+  const bool fuse = g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
+  if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
+  HIPCHK(hipEventRecord(g->ev[0], g->st));
+  if (fuse) {
     // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
     // then the few pairs that address no cell (t = 1 -> S1, t = n -> 0, out of bounds -> -inf)
     dot_request req;
