@@ -883,6 +883,7 @@ __global__ __launch_bounds__(256) void k_logconv(fill_args A, split_args X, int 
 #define PC_U 8
 #define PC_BIAS 700  // per-lane shared exponent: leave room below for the smallest cell of a lane
 #ifdef STB_STAMPS
+__device__ unsigned long long *g_dbg2;  // hand-off timeline: [block<160][trip<1280][4] wall-clock stamps
 __device__ unsigned long long *g_dbg;  // diagnostic build: [launch][block<512][wave<4][4]
 #endif
 
@@ -1164,7 +1165,6 @@ struct chain_args {
   int D, B;                    // tables, column blocks per table
   int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
-  int dbg;                     // diagnostic switches (STB_CHAIN_DBG), 0 in production
   const unsigned *cnt;         // DOT kernels: occurrence count per cell, in the table's own layout
   double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
 };
@@ -1349,6 +1349,9 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         s = ldexp(1.0, min(max(dl, -1100), 220));
         ebuf[p & 3][col] = ep;
       }
+#ifdef STB_STAMPS
+      if (g_dbg2 && d == 0 && w == 0 && lane == 0 && j < 160 && g < 1280) g_dbg2[((size_t)j * 1280 + g) * 4 + 3] = wall_clock64();
+#endif
       if (lane == 0) slot_p[g & (RD - 1)][w] = p & 3;
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -1357,6 +1360,9 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         coef += 1.0;
         vbuf[g & (RD - 1)][u][col] = v;
       }
+#ifdef STB_STAMPS
+      if (g_dbg2 && d == 0 && w == P - 1 && lane == 0 && j < 160 && g < 1280) g_dbg2[((size_t)j * 1280 + g) * 4 + 0] = wall_clock64();
+#endif
       lds_post(&prod_done[w], g + 1);
       if (++tin == TP) {
         tin = 0;
@@ -1471,6 +1477,9 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
           const long long ex = (long long)ebuf[slot_p[slot][P - 1]][OW - 1] + (long long)CH_EOFF;
           __hip_atomic_store(ee_out + t, (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef STB_STAMPS
+        if (g_dbg2 && d == 0 && lane == 0 && j < 160 && t < 1280) g_dbg2[((size_t)j * 1280 + t) * 4 + 1] = wall_clock64();
+#endif
         lds_post(&pub_done, t + 1);
       }
     }
@@ -1548,6 +1557,9 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         if (ka < nr && t + ka >= cur) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
         if (kb < nr && t + kb >= cur) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
         if (lane >= 1 && lane <= nr && t - 1 + lane >= cur) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+#ifdef STB_STAMPS
+        if (g_dbg2 && d == 0 && lane < nr && j < 160 && t + lane < 1280) g_dbg2[((size_t)j * 1280 + t + lane) * 4 + 2] = wall_clock64();
+#endif
         t += nr;
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_max(&edge_ready, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1821,7 +1833,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
     int p = g0w / TP, tin = g0w - p * TP;
     // where my pair of cells of a row lives (16-byte aligned: cA is even and rows are 512-byte
     // aligned); the pair (0, 1) has no slot and pairs past M are not stored: those go to the dump
-    const bool okP = cA >= 2 && (unsigned)cA <= M && !(X.dbg & 1);
+    const bool okP = cA >= 2 && (unsigned)cA <= M;
     double *dump = reinterpret_cast<double *>(Y.dump) + 2 * lane;
     double *pA = okP ? table + stb_row_offset((unsigned)(3 + g0w * U), M) + (cA - 2) : dump;
     int *expo = Y.expo + (uint64_t)d * Y.NPer * Y.EWh + (cA >> 1);
@@ -1860,7 +1872,7 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
         asm volatile("" ::: "memory");
         load_left(e, g);
       }
-      if (g + 1 < G && !(X.dbg & 16)) look_ahead(g + 1);
+      if (g + 1 < G) look_ahead(g + 1);
       if (__builtin_expect(g == g0w || tin == 0, 0)) {
         // ---- period set-up ----
         if (g != g0w) {  // renormalise: the larger significand back to 2^-PC_BIAS * [0.5,1)
@@ -2039,6 +2051,212 @@ __global__ __launch_bounds__(512) void k_fill_chainx(fill_args A, chain_args X, 
     }
   }
   CX_DUMP(j);
+}
+
+// ---- chain form of the V-table fill (lib/stable.c:451-482) ------------------------
+//
+// V^n_m needs V^{n-1}_m and V^{n-1}_{m-1}: the same stencil as the S table, with plain doubles (the
+// ratios stay O(1): no exponents, no logs).  So a block is only the chain: P producer waves of one
+// column per lane that store their row segment straight into the table, a publisher and a fetcher
+// exactly as in k_fill_chain (8-byte granules; -0.0 stands for an exact zero).  The cell update is
+// the reference's own expression with contraction off, so the table is bit-identical to it.
+template <int P>
+__global__ __launch_bounds__(64 * (P + 2)) void k_fillv_chain(fill_args A, chain_args X) {
+  constexpr int U = CH_U, RD = 16, RE = CH_RE;
+  constexpr int OW = 64 * P;
+  __shared__ __attribute__((aligned(16))) double xedge[P][RD][U];  // last column of each slice
+  __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
+  __shared__ int prod_done[P], pub_done, edge_ready, s_abort;
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
+  for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
+  __syncthreads();
+  const int j = (int)(s_ticket / (unsigned)X.D);
+  const int d = (int)(s_ticket % (unsigned)X.D);
+  if (j >= X.B) return;
+  const unsigned N = A.N, M = A.M;
+  const int G = X.G;          // trips: rows 2 + U g .. 9 + U g
+  const int c0 = 1 + j * OW;  // first column of the block
+  auto first_trip = [&](int w) {  // trip in which the diagonal reaches the first column of slice w
+    const int c = c0 + 64 * w;
+    return (c <= 2) ? 0 : (c - 2) / U;
+  };
+  const int g0b = first_trip(0);
+  const bool has_left = j > 0, has_right = j < X.B - 1;
+  if (tid < P) prod_done[tid] = first_trip(tid);
+  if (tid == 0) {
+    pub_done = first_trip(P - 1);
+    edge_ready = has_left ? g0b : 0x7fffffff;
+    s_abort = 0;
+  }
+  __syncthreads();
+  double *table = A.tables + (uint64_t)d * A.tstride;
+  bool aborted = false;
+  auto wait_ge = [&](const int *cnt, int need, unsigned code) {
+    if (aborted || lds_peek(cnt) >= need) return;
+    if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, (unsigned)(j | (d << 16)), wave < P ? 1 : 2))
+      aborted = true;
+  };
+
+  if (wave < P) {
+    // ================= producers =================
+    __builtin_amdgcn_s_setprio(3);
+    const int w = wave;
+    const int g0w = first_trip(w);
+    const int c = c0 + 64 * w + lane;  // my column
+    const double a = A.a[d];
+    const double ca = (double)c * a, cb = (double)(c - 1) * a;
+    // row 1 (and every row above the diagonal): V_1 = +inf by convention, everything else 0
+    double v = (c == 1) ? HUGE_VAL : 0.0;
+    // columns 2..M have a slot; column 1 and the columns past M go to the dump
+    const bool ok = c >= 2 && (unsigned)c <= M;
+    double *dump = reinterpret_cast<double *>(X.edge_e) + lane;  // (64 words the V fill does not use)
+    double *pc = ok ? table + stb_vrow_offset((unsigned)(2 + g0w * U), M) + (c - 2) : dump;
+    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w - 1];
+    const int *next_cnt = (w < P - 1) ? &prod_done[w + 1] : &pub_done;
+    int n_left, n_next;
+    double ne[U];
+    auto load_left = [&](double(&x)[U], int g) {
+      if (w == 0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = edge_in[(g & (RE - 1)) * U + u];
+      } else {
+        x[0] = xedge[w - 1][(g - 1) & (RD - 1)][U - 1];
+#pragma unroll
+        for (int u = 1; u < U; u++) x[u] = xedge[w - 1][g & (RD - 1)][u - 1];
+      }
+    };
+    auto look_ahead = [&](int g) {
+      n_left = lds_peek(left_cnt);
+      n_next = lds_peek(next_cnt);
+      asm volatile("" ::: "memory");
+      load_left(ne, g);
+    };
+    look_ahead(g0w);
+    auto trip = [&](int g, auto partial_tag) {
+      constexpr bool partial = decltype(partial_tag)::value;
+      double e[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) e[u] = ne[u];
+      const int next_need = (w < P - 1) ? g - RD + 2 : g - RD + 1;
+      if (__builtin_expect(n_left < g + 1 || n_next < next_need, 0)) {
+        wait_ge(left_cnt, g + 1, 0x100u + (unsigned)g);
+        wait_ge(next_cnt, next_need, 0x400u + (unsigned)g);
+        asm volatile("" ::: "memory");
+        load_left(e, g);
+      }
+      if (g + 1 < G) look_ahead(g + 1);
+      const int r0 = 2 + g * U;
+      // (rows 2+8g .. 9+8g have lengths 1+8g .. 8+8g: one pitch per trip, as for the S table)
+      const size_t inc = ok ? stb_vrow_pitch((unsigned)r0, M) : 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int n = r0 + u;
+        const double left = wave_shr1(v, e[u]);
+        // lib/stable.c:475-480 (see v_cell), with this lane's constants hoisted
+        double y;
+        {
+#pragma clang fp contract(off)
+          const double nm1 = (double)(n - 1);
+          const double num = 1.0 + ((c < n) ? ((nm1 - ca) * v) : 0.0);
+          const double den = 1.0 / left + (nm1 - cb);
+          y = num / den;
+        }
+        v = (c == 1) ? HUGE_VAL : (c > n) ? 0.0 : y;
+        if (lane == 63) xedge[w][g & (RD - 1)][u] = v;
+        if (partial)
+          *(((unsigned)n <= N) ? pc : dump) = v;
+        else
+          *pc = v;
+        pc += inc;
+      }
+      lds_post(&prod_done[w], g + 1);
+    };
+    const int Gfull = ((int)N >= 1 + U) ? ((int)N - 1) / U : 0;  // trips whose rows all exist
+    int g = g0w;
+    for (; g < Gfull; g++) trip(g, std::false_type{});
+    for (; g < G; g++) trip(g, std::true_type{});
+  } else if (wave == P) {
+    // ================= publisher =================
+    if (has_right) {
+      unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
+      for (int t = first_trip(P - 1); t < G; t++) {
+        wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);
+        if (lane < U) {
+          unsigned long long b = (unsigned long long)__double_as_longlong(xedge[P - 1][t & (RD - 1)][lane]);
+          if ((b << 1) == 0) b = CH_NEGZERO;
+          __hip_atomic_store(ev_out + 2 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_post(&pub_done, t + 1);
+      }
+    } else {
+      // nobody to publish to: only release the ring slots
+      for (int t = first_trip(P - 1); t < G; t++) {
+        wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);
+        lds_post(&pub_done, t + 1);
+      }
+    }
+  } else {
+    // ================= fetcher =================
+    if (has_left) {
+      const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      for (int t = g0b; t < G;) {
+        int lim = lds_peek(&prod_done[0]) + RE;
+        if (lim > G) lim = G;
+        if (lim <= t) {
+          wait_ge(&prod_done[0], t - RE + 1, 0x800u + (unsigned)t);
+          if (aborted) break;
+          continue;
+        }
+        const int nt = min(16, lim - t);
+        const int row0 = 1 + t * U;  // the rows one above the rows of trip t
+        const bool need_a = lane < 8 * nt, need_b = 64 + lane < 8 * nt;
+        unsigned long long va = 0, vb = 0;
+        if (need_a) va = __hip_atomic_load(ev_in + row0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_b) vb = __hip_atomic_load(ev_in + row0 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ma = __ballot(!need_a || va != 0);
+        const unsigned long long mb = __ballot(!need_b || vb != 0);
+        int nr = 0;
+        for (; nr < nt; nr++) {
+          const unsigned long long rows = (nr < 8) ? (ma >> (8 * nr)) : (mb >> (8 * (nr - 8)));
+          if ((rows & 0xffull) != 0xffull) break;
+        }
+        if (nr == 0) {
+          if (!timing) {
+            timing = true;
+            t_begin = wall_clock64();
+          }
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
+            if (lane == 0) {
+              __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (err == 0) {
+                __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 1, 0x900u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+            lds_post(&edge_ready, 0x7fffffff);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        timing = false;
+        const int ka = lane >> 3, kb = 8 + (lane >> 3);
+        // (-0.0 is the granule of an exact zero: the cells it feeds are forced to 0 anyway)
+        const double xa = (va == CH_NEGZERO) ? 0.0 : __longlong_as_double((long long)va);
+        const double xb = (vb == CH_NEGZERO) ? 0.0 : __longlong_as_double((long long)vb);
+        if (ka < nr) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
+        if (kb < nr) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
+        t += nr;
+        lds_post(&edge_ready, t);
+      }
+    }
+  }
 }
 
 static int ensure_logtab() {
@@ -2365,6 +2583,57 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
   const int nlaunch = ((int)N - 1 + R - 1) / R;  // rows 2..N
+  if (mode == STB_MODE_VRATIO && env_int("STB_FILLV_CHAIN", 1) && N >= 2) {
+    // the V table in chain form: P producer waves per block, no consumers (nothing to convert)
+    int Pv = env_int("STB_FILLV_P", 4);
+    if (Pv != 1 && Pv != 2 && Pv != 4) Pv = 4;
+    const unsigned cols = (M < N) ? M : N;  // columns 1..min(M, N) (row n stores m <= n)
+    chain_args X;
+    X.TP = 1;
+    X.G = (int)((N - 1 + CH_U - 1) / CH_U);  // rows 2..N
+    X.D = D;
+    X.B = (int)((cols + 64 * Pv - 1) / (64 * Pv));
+    if (X.B < 1) X.B = 1;
+    X.EV = (uint64_t)2 + (uint64_t)X.G * CH_U + 136;
+    X.NP = 0;
+    X.cnt = nullptr;
+    X.dotp = nullptr;
+    char *cb = (char *)align_up((size_t)((char *)A.fe + (size_t)D * 2 * A.W * sizeof(int)), 256);
+    const size_t vbytes = 256 + 512 + (size_t)D * X.B * X.EV * sizeof(unsigned long long);
+    if ((size_t)(cb - (char *)d_ws) + vbytes > ws_bytes) return fail("%s: workspace too small for the chain form", who);
+    X.hdr = (unsigned *)cb;
+    X.edge_e = (unsigned long long *)(cb + 256);  // (here: the dump for columns without a slot)
+    X.edge_v = (unsigned long long *)(cb + 256 + 512);
+    X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;
+    HIPCHK(hipMemsetAsync(cb, 0, align_up(vbytes, 16), st));
+    g_chain_hdr = X.hdr;
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (g_prof.armed && g_prof.used + 2 <= 2 * 4096) {
+      while (g_prof.made < g_prof.used + 2) {
+        if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) break;
+        g_prof.made++;
+      }
+      if (g_prof.made >= g_prof.used + 2) {
+        p0 = g_prof.ev[g_prof.used];
+        p1 = g_prof.ev[g_prof.used + 1];
+        g_prof.used += 2;
+      }
+    }
+    const dim3 grid((unsigned)X.B * (unsigned)D);
+#define STB_LAUNCH_VCHAIN(PP)                                                                          \
+  do {                                                                                                 \
+    if (p0)                                                                                            \
+      hipExtLaunchKernelGGL((k_fillv_chain<PP>), grid, dim3(64 * (PP + 2)), 0, st, p0, p1, 0, A, X);   \
+    else                                                                                               \
+      hipLaunchKernelGGL((k_fillv_chain<PP>), grid, dim3(64 * (PP + 2)), 0, st, A, X);                 \
+  } while (0)
+    if (Pv == 1) STB_LAUNCH_VCHAIN(1);
+    else if (Pv == 2) STB_LAUNCH_VCHAIN(2);
+    else STB_LAUNCH_VCHAIN(4);
+#undef STB_LAUNCH_VCHAIN
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (mode == STB_MODE_CHAINX) {
     const chainx_geom cg = chainx_geometry(N, M, D);
     int Pc = 1450;
@@ -2397,7 +2666,6 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     Y.NPer = cg.NPer;
     Y.Q = cg.Q;
     X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
-    X.dbg = env_int("STB_CHAIN_DBG", 0);
     HIPCHK(hipMemsetAsync(cb, 0, align_up(cg.zero_bytes, 16), st));
     g_chain_hdr = X.hdr;
     hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
@@ -2480,7 +2748,6 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     X.edge_e = (unsigned long long *)(cb + 256);
     X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
     X.timeout = (unsigned long long)env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // 100 MHz ticks
-    X.dbg = env_int("STB_CHAIN_DBG", 0);
     HIPCHK(hipMemsetAsync(cb, 0, align_up(cg.bytes, 16), st));
     g_chain_hdr = X.hdr;
     hipLaunchKernelGGL(k_s1, dim3((N + 255) / 256 < 64 ? (N + 255) / 256 : 64, D), dim3(256), 0, st, A.a, d_S1, s1_stride, N);
@@ -2506,6 +2773,16 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
         z = h_cdbg;
       }
       HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dbg), &z, sizeof(z), 0, hipMemcpyHostToDevice, st));
+    }
+    static unsigned long long *h_tl = nullptr;
+    {
+      unsigned long long *z = nullptr;
+      if (getenv("STB_TIMELINE_FILE")) {
+        if (!h_tl) HIPCHK(hipMalloc(&h_tl, sizeof(unsigned long long) * 160 * 1280 * 4));
+        HIPCHK(hipMemsetAsync(h_tl, 0, sizeof(unsigned long long) * 160 * 1280 * 4, st));
+        z = h_tl;
+      }
+      HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dbg2), &z, sizeof(z), 0, hipMemcpyHostToDevice, st));
     }
 #endif
     const dim3 grid((unsigned)cg.B * (unsigned)D);
@@ -2540,6 +2817,22 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       default: return fail("%s: no chain kernel for %d producers / %d consumers / %d fetchers", who, cg.P, cg.NC, cg.NF);
     }
 #undef STB_LAUNCH_CHAIN1
+#ifdef STB_STAMPS
+    if (getenv("STB_TIMELINE_FILE") && h_tl) {
+      HIPCHK(hipStreamSynchronize(st));
+      const size_t cnt = (size_t)160 * 1280 * 4;
+      unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+      HIPCHK(hipMemcpy(h, h_tl, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("STB_TIMELINE_FILE"), "w");
+      for (int jj = 0; jj < 160; jj++)
+        for (int t = 0; t < 1280; t++) {
+          unsigned long long *q = h + ((size_t)jj * 1280 + t) * 4;
+          if (q[0] | q[1] | q[2] | q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, t, q[0], q[1], q[2], q[3]);
+        }
+      fclose(f);
+      free(h);
+    }
+#endif
 #undef STB_LAUNCH_CHAIN
 #ifdef STB_STAMPS
     if (getenv("STB_STAMP_FILE") && h_cdbg) {
