@@ -1464,23 +1464,39 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
   } else if (wave == P + NC) {
     // ================= publisher =================
     if (has_right) {
+      __builtin_amdgcn_s_setprio(2);
       unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
       unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
-      for (int t = first_trip(P - 1); t < G; t++) {
-        wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);
+      const int t_first = first_trip(P - 1);
+      int pp = t_first / TP, ptin = t_first - pp * TP;  // period of trip t, tracked without dividing
+      for (int t = t_first; t < G; t++) {
+        // (latency matters here, not issue slots: spin without sleeping)
+        if (!aborted) {
+          const unsigned long long t_begin = wall_clock64();
+          while (lds_peek(&prod_done[P - 1]) < t + 1) {
+            if (lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
+              wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);  // (records the failure)
+              break;
+            }
+          }
+        }
         const int slot = t & (RD - 1);
         if (lane < U) {
           unsigned long long b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][OW - 1]);
           if ((b << 1) == 0) b = CH_NEGZERO;
           __hip_atomic_store(ev_out + 3 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (lane == U) {
-          const long long ex = (long long)ebuf[slot_p[slot][P - 1]][OW - 1] + (long long)CH_EOFF;
+          const long long ex = (long long)ebuf[pp & 3][OW - 1] + (long long)CH_EOFF;
           __hip_atomic_store(ee_out + t, (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef STB_STAMPS
         if (g_dbg2 && d == 0 && lane == 0 && j < 160 && t < 1280) g_dbg2[((size_t)j * 1280 + t) * 4 + 1] = wall_clock64();
 #endif
         lds_post(&pub_done, t + 1);
+        if (++ptin == TP) {
+          ptin = 0;
+          pp++;
+        }
       }
     }
   } else {
@@ -2298,13 +2314,20 @@ struct chain_geom {
 };
 static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   chain_geom g;
-  g.P = env_int("STB_CHAIN_P", 4);
-  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = 4;
+  // block shape: up to ~5 tables of 10^4 columns narrower blocks on more compute units win (the
+  // fill is a latency chain), with three fetcher waves to shorten the hand-off; for more tables in
+  // flight wider blocks with fewer hand-offs do (measured, MI355X: D = 1: 0.96 vs 1.10 ms;
+  // D = 4: 1.08 vs 1.16; D = 8: 1.48 vs 1.36)
+  const bool narrow = (uint64_t)D * M <= 50000;
+  g.P = env_int("STB_CHAIN_P", narrow ? 2 : 4);
+  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = narrow ? 2 : 4;
   g.NC = env_int("STB_CHAIN_NC", g.P == 4 ? 10 : g.P == 2 ? 6 : 3);
   if (g.NC < g.P) g.NC = g.P;
-  g.NF = env_int("STB_CHAIN_NF", 1);
+  g.NF = env_int("STB_CHAIN_NF", narrow ? 3 : 1);
   if (g.NF < 1) g.NF = 1;
   if (g.NF > 3) g.NF = 3;
+  if (g.NF == 2) g.NF = 3;  // (compiled shapes have one or three fetchers)
+  if (g.P + g.NC + 1 + g.NF > 16) g.NF = 1;
   if (g.P + g.NC + 1 + g.NF > 16) g.NC = 15 - g.NF - g.P;
   const unsigned cols = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
   g.B = (int)((cols + 64 * g.P - 1) / (64 * g.P));
@@ -2357,7 +2380,7 @@ static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
 // enough for D tables and for any smaller batch run in the same workspace
 extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
   size_t need = fill_workspace_need(N, M, D);
-  for (int d2 = 1; d2 <= 2 && d2 < D; d2++) {
+  for (int d2 = 1; d2 < D && d2 <= 4096; d2++) {  // (the block shape, hence the edge streams, depends on the batch)
     const size_t n2 = fill_workspace_need(N, M, d2);
     if (n2 > need) need = n2;
   }
@@ -2806,11 +2829,15 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       case 1031: STB_LAUNCH_CHAIN(1, 3, 1); break;
       case 1033: STB_LAUNCH_CHAIN(1, 3, 3); break;
       case 1061: STB_LAUNCH_CHAIN(1, 6, 1); break;
+      case 1063: STB_LAUNCH_CHAIN(1, 6, 3); break;
       case 2041: STB_LAUNCH_CHAIN(2, 4, 1); break;
+      case 2043: STB_LAUNCH_CHAIN(2, 4, 3); break;
       case 2061: STB_LAUNCH_CHAIN(2, 6, 1); break;
       case 2063: STB_LAUNCH_CHAIN(2, 6, 3); break;
       case 2081: STB_LAUNCH_CHAIN(2, 8, 1); break;
+      case 2083: STB_LAUNCH_CHAIN(2, 8, 3); break;
       case 4061: STB_LAUNCH_CHAIN(4, 6, 1); break;
+      case 4063: STB_LAUNCH_CHAIN(4, 6, 3); break;
       case 4081: STB_LAUNCH_CHAIN(4, 8, 1); break;
       case 4083: STB_LAUNCH_CHAIN(4, 8, 3); break;
       case 4101: STB_LAUNCH_CHAIN(4, 10, 1); break;
