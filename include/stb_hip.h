@@ -77,6 +77,9 @@ int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *
  * with stb_last_error() set when a column block gave up waiting for its neighbour (the fill's
  * polls are bounded; STB_CHAIN_TIMEOUT_MS, default 2000).  The other forms cannot fail on the device. */
 int stb_fill_status(void);
+/* release the device buffers the library keeps for reuse between stb_groups_create / samplea calls
+ * (capped at STB_POOL_MB, default 4096) */
+void stb_pool_trim(void);
 /* kernel-only timing of the fills issued by THIS thread between begin and end (the stream must be
  * synchronised before _end): sum of the per-launch device durations in ms and their count */
 void stb_fill_profile_begin(void);

@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -90,6 +92,109 @@ extern "C" int stb_device_name(char *buf, int len) {
   HIPCHK(hipGetDeviceProperties(&p, dev));
   snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A small cache of device buffers.  samplea builds and frees a group set (a dozen buffers, 70 MB at
+// 10^6 pairs) on every call, as the reference builds and frees its table (lib/samplea.c:57-60,223);
+// hipMalloc / hipFree cost ~1 ms each way there.  Freed buffers are kept (up to STB_POOL_MB,
+// default 4096) and handed out again to requests of about the same size on the same device.
+// Callers return a buffer only after the work that used it has completed.
+struct pool_block {
+  void *p;
+  size_t bytes;
+  int dev;
+  bool used;
+};
+static std::mutex g_pool_mu;
+static std::vector<pool_block> g_pool;
+static size_t g_pool_idle = 0;
+
+static hipError_t pool_malloc(void **out, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++) {
+      const pool_block &b = g_pool[i];
+      if (!b.used && b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+          (best < 0 || b.bytes < g_pool[best].bytes))
+        best = (int)i;
+    }
+    if (best >= 0) {
+      g_pool[best].used = true;
+      g_pool_idle -= g_pool[best].bytes;
+      *out = g_pool[best].p;
+      return hipSuccess;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // out of memory: give the idle buffers back and try once more
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      for (size_t i = 0; i < g_pool.size();) {
+        if (!g_pool[i].used) {
+          drop.push_back(g_pool[i].p);
+          g_pool_idle -= g_pool[i].bytes;
+          g_pool.erase(g_pool.begin() + i);
+        } else {
+          i++;
+        }
+      }
+    }
+    for (void *q : drop) (void)hipFree(q);
+    (void)hipGetLastError();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back(pool_block{p, bytes, dev, true});
+  *out = p;
+  return hipSuccess;
+}
+
+static void pool_free(void *p) {
+  if (!p) return;
+  static const size_t cap = (size_t)(getenv("STB_POOL_MB") ? atol(getenv("STB_POOL_MB")) : 4096) << 20;
+  bool release = true;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) {
+      if (g_pool[i].p == p) {
+        if (g_pool_idle + g_pool[i].bytes <= cap) {
+          g_pool[i].used = false;
+          g_pool_idle += g_pool[i].bytes;
+          release = false;
+        } else {
+          g_pool.erase(g_pool.begin() + i);
+        }
+        break;
+      }
+    }
+  }
+  if (release) (void)hipFree(p);
+}
+
+extern "C" void stb_pool_trim(void) {
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();) {
+      if (!g_pool[i].used) {
+        drop.push_back(g_pool[i].p);
+        g_pool.erase(g_pool.begin() + i);
+      } else {
+        i++;
+      }
+    }
+    g_pool_idle = 0;
+  }
+  for (void *q : drop) (void)hipFree(q);
 }
 
 extern "C" void *stb_device_malloc(size_t bytes) {
@@ -3458,7 +3563,7 @@ static int sort_pairs(uint32_t *d_n, uint16_t *d_t, uint64_t G, hipStream_t st) 
   size_t tmp_bytes = 0;
   int rc = 1;
   do {
-    if (hipMalloc(&k0, sizeof(uint64_t) * G) != hipSuccess || hipMalloc(&k1, sizeof(uint64_t) * G) != hipSuccess) {
+    if (pool_malloc((void **)&k0, sizeof(uint64_t) * G) != hipSuccess || pool_malloc((void **)&k1, sizeof(uint64_t) * G) != hipSuccess) {
       fail("sort_pairs: out of device memory");
       break;
     }
@@ -3468,7 +3573,7 @@ static int sort_pairs(uint32_t *d_n, uint16_t *d_t, uint64_t G, hipStream_t st) 
       fail("sort_pairs: radix_sort_keys (size query) failed");
       break;
     }
-    if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
+    if (pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
       fail("sort_pairs: out of device memory");
       break;
     }
@@ -3483,9 +3588,11 @@ static int sort_pairs(uint32_t *d_n, uint16_t *d_t, uint64_t G, hipStream_t st) 
     }
     rc = 0;
   } while (0);
-  if (k0) (void)hipFree(k0);
-  if (k1) (void)hipFree(k1);
-  if (tmp) (void)hipFree(tmp);
+  // (the stream was synchronised above, or nothing was launched on these buffers)
+  if (rc != 0) (void)hipStreamSynchronize(st);
+  pool_free(k0);
+  pool_free(k1);
+  pool_free(tmp);
   return rc;
 }
 
@@ -3494,8 +3601,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   if (!g) return;
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
+  if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
+  for (void *p : ptrs) pool_free(p);
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   if (g->st) (void)hipStreamDestroy(g->st);
@@ -3564,19 +3671,19 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
   g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
   GCHK(hipStreamCreate(&g->st));
   for (auto &e : g->ev) GCHK(hipEventCreate(&e));
-  GCHK(hipMalloc(&g->d_n, sizeof(uint32_t) * (G ? G : 1)));
-  GCHK(hipMalloc(&g->d_t, sizeof(uint16_t) * (G ? G : 1)));
-  GCHK(hipMalloc(&g->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)));
-  GCHK(hipMalloc(&g->d_bpar, sizeof(double) * (I > 0 ? I : 1)));
-  GCHK(hipMalloc(&g->d_tables, sizeof(double) * g->tstride * Dmax));
-  GCHK(hipMalloc(&g->d_S1, sizeof(double) * (size_t)N * Dmax));
-  GCHK(hipMalloc(&g->d_out, sizeof(double) * 2 * Dmax));
+  GCHK(pool_malloc((void **)&g->d_n, sizeof(uint32_t) * (G ? G : 1)));
+  GCHK(pool_malloc((void **)&g->d_t, sizeof(uint16_t) * (G ? G : 1)));
+  GCHK(pool_malloc((void **)&g->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)));
+  GCHK(pool_malloc((void **)&g->d_bpar, sizeof(double) * (I > 0 ? I : 1)));
+  GCHK(pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * Dmax));
+  GCHK(pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)N * Dmax));
+  GCHK(pool_malloc((void **)&g->d_out, sizeof(double) * 2 * Dmax));
   g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
   g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
   g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
-  GCHK(hipMalloc(&g->d_ws_fill, g->ws_fill));
-  GCHK(hipMalloc(&g->d_ws_sweep, g->ws_sweep));
-  GCHK(hipMalloc(&g->d_ws_terms, g->ws_terms));
+  GCHK(pool_malloc((void **)&g->d_ws_fill, g->ws_fill));
+  GCHK(pool_malloc((void **)&g->d_ws_sweep, g->ws_sweep));
+  GCHK(pool_malloc((void **)&g->d_ws_terms, g->ws_terms));
   if (G) {
     GCHK(hipMemcpy(g->d_n, nflat, sizeof(uint32_t) * G, hipMemcpyHostToDevice));
     GCHK(hipMemcpy(g->d_t, tflat, sizeof(uint16_t) * G, hipMemcpyHostToDevice));
@@ -3600,7 +3707,7 @@ static int groups_fused_setup(stb_groups_t *g) {
   const unsigned N = g->N, M = g->M;
   const uint64_t G = g->G;
   const uint64_t elems = stb_table_elems(N, M);
-  HIPCHK(hipMalloc(&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
+  HIPCHK(pool_malloc((void **)&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
   HIPCHK(hipMemsetAsync(g->d_cnt, 0, sizeof(unsigned) * (elems ? elems : 1), g->st));
   if (G)
     hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t, G, N,
@@ -3629,8 +3736,8 @@ static int groups_fused_setup(stb_groups_t *g) {
       }
     }
     g->G2 = G2;
-    e1 = hipMalloc(&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
-    if (e1 == hipSuccess) e2 = hipMalloc(&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
+    e1 = pool_malloc((void **)&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
+    if (e1 == hipSuccess) e2 = pool_malloc((void **)&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
     if (e1 == hipSuccess && e2 == hipSuccess && G2) {
       e1 = hipMemcpy(g->d_n2, hn, sizeof(uint32_t) * G2, hipMemcpyHostToDevice);
       e2 = hipMemcpy(g->d_t2, ht, sizeof(uint16_t) * G2, hipMemcpyHostToDevice);
@@ -3641,7 +3748,7 @@ static int groups_fused_setup(stb_groups_t *g) {
   if (e1 != hipSuccess || e2 != hipSuccess) return fail("stb_groups_aterms: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   // partial sums: at most (column blocks of 64) x 16 waves per table
   g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
-  HIPCHK(hipMalloc(&g->d_dotp, sizeof(double) * g->dotp_elems));
+  HIPCHK(pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems));
   HIPCHK(hipGetLastError());
   g->fused_ready = 1;
   return 0;
