@@ -32,6 +32,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
 
 #include "stb_layout.h"
 #include "../../include/stb_hip.h"
@@ -1270,7 +1271,12 @@ struct chain_args {
   int D, B;                    // tables, column blocks per table
   int TP, G;                   // trips per period, trips in all (rows 3 .. 2 + G*CH_U)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
-  const unsigned *cnt;         // DOT kernels: occurrence count per cell, in the table's own layout
+  unsigned tp_magic;           // ceil(2^32 / TP): trip / TP = umulhi(trip, tp_magic) for trip < 2^26
+  const unsigned *cnt;         // DOT = 1: occurrence count per cell, in the table's own layout
+  const unsigned *item_ptr;    // DOT = 2: [trips * nsg + 1] first entry of every (trip, slice) item
+  const unsigned short *ent_pos;  // DOT = 2: row-in-trip << 6 | column-in-slice of each occurring cell
+  const unsigned *ent_cnt;     // DOT = 2: its occurrence count
+  unsigned nsg;                // DOT = 2: slices per trip in item_ptr
   double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
 };
 
@@ -1287,7 +1293,11 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
 
 // DOT: the logs are not stored; each is multiplied by the cell's occurrence count and summed (the
 // whole of aterms' table part, lib/samplea.c:68-80, without a table in memory or a second pass).
-template <int P, int NC, int NF, bool DOT>
+//   DOT = 1: dense -- a count slab in the table's layout; every cell's log is computed.
+//   DOT = 2: sparse -- per (trip, 64-column slice) item the list of cells that occur at all
+//            (position in the 8 x 64 tile + count): only their logs are computed, empty items are
+//            skipped without even waiting for the producer.
+template <int P, int NC, int NF, int DOT>
 __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args A, chain_args X) {
   constexpr int U = CH_U, RD = CH_RD, RE = CH_RE;
   constexpr int OW = 64 * P;  // columns of a block
@@ -1480,6 +1490,48 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
     int w = ci % P, t = g0b + ci / P;
     int done = 0;
     double acc = 0.0;  // (DOT) this lane's share of the sum
+    if (DOT == 2) {
+      // item (t, w) of block j is slice sg = j P + w of the table: its cells are item_ptr[idx] ..
+      // item_ptr[idx + 1] with idx = t * nsg + sg.  The range of the NEXT item is read while this
+      // one is processed (a wave-uniform load each).
+      auto item_range = [&](int tt, int ww, unsigned &b0, unsigned &b1) {
+        const unsigned idx = (unsigned)tt * X.nsg + (unsigned)(j * P + ww);
+        b0 = X.item_ptr[idx];
+        b1 = X.item_ptr[idx + 1];
+      };
+      unsigned nb = 0, ne = 0;
+      if (t < G) item_range(t, w, nb, ne);
+      for (; t < G;) {
+        const unsigned beg = nb, end = ne;
+        int w2 = w + NC % P, t2 = t + NC / P;
+        if (w2 >= P) {
+          w2 -= P;
+          t2++;
+        }
+        if (t2 < G) item_range(t2, w2, nb, ne);
+        if (beg != end && t >= first_trip(w)) {
+          // the first 64 entries can come in while we wait for the producer
+          unsigned k = beg + lane;
+          unsigned pos = (k < end) ? X.ent_pos[k] : 0u, c = (k < end) ? X.ent_cnt[k] : 0u;
+          wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
+          const int slot = t & (RD - 1);
+          const int pidx = ((TP == 1) ? t : (int)__umulhi((unsigned)t, X.tp_magic)) & 3;  // period of trip t
+          for (;;) {
+            const int col = 64 * w + (int)(pos & 63u);
+            const double val = bfp_log(vbuf[slot][pos >> 6][col], ebuf[pidx][col], lt);
+            acc += (c != 0) ? (double)c * val : 0.0;
+            if (k - lane + 64 >= end) break;  // (wave-uniform)
+            k += 64;
+            pos = (k < end) ? X.ent_pos[k] : 0u;
+            c = (k < end) ? X.ent_cnt[k] : 0u;
+          }
+        }
+        done++;
+        lds_post(&cons_cnt[ci], done);
+        w = w2;
+        t = t2;
+      }
+    }
     for (; t < G;) {
       if (t >= first_trip(w)) {
         wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
@@ -1499,7 +1551,7 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
           double x[U], z[U], kf[U], r[U], pl[U];
           double2 tt[U];
           unsigned cn[U];
-          if (DOT) {
+          if (DOT == 1) {
 #pragma unroll
             for (int u = 0; u < U; u++) cn[u] = cntbase[(size_t)u * pitch + coff];
           }
@@ -2586,7 +2638,11 @@ static thread_local unsigned *g_chain_hdr = nullptr;
 
 // set by stb_groups_aterms around its fill: run the chain form as a DOT kernel (no table stored)
 struct dot_request {
-  const unsigned *cnt = nullptr;
+  const unsigned *cnt = nullptr;             // dense: count slab
+  const unsigned *item_ptr = nullptr;        // sparse: see chain_args
+  const unsigned short *ent_pos = nullptr;
+  const unsigned *ent_cnt = nullptr;
+  unsigned nsg = 0;
   double *dotp = nullptr;
   int parts_per_table = 0;  // out: B * NC
 };
@@ -2718,6 +2774,11 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     const unsigned cols = (M < N) ? M : N;  // columns 1..min(M, N) (row n stores m <= n)
     chain_args X;
     X.TP = 1;
+    X.tp_magic = 0;
+    X.item_ptr = nullptr;
+    X.ent_pos = nullptr;
+    X.ent_cnt = nullptr;
+    X.nsg = 0;
     X.G = (int)((N - 1 + CH_U - 1) / CH_U);  // rows 2..N
     X.D = D;
     X.B = (int)((cols + 64 * Pv - 1) / (64 * Pv));
@@ -2776,6 +2837,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     chainx_args Y;
     X.TP = Pc / CH_U;
     if (X.TP < 1) return fail("%s: renormalisation period %d shorter than a trip", who, Pc);
+    X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
     X.G = cg.G;
     X.D = D;
     X.B = cg.B;
@@ -2865,6 +2927,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     chain_args X;
     X.TP = Pc / CH_U;
     if (X.TP < 1) return fail("%s: renormalisation period %d shorter than a trip", who, Pc);
+    X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
     X.G = cg.G;
     X.D = D;
     X.B = cg.B;
@@ -2915,8 +2978,13 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 #endif
     const dim3 grid((unsigned)cg.B * (unsigned)D);
     X.cnt = g_dot_req ? g_dot_req->cnt : nullptr;
+    X.item_ptr = g_dot_req ? g_dot_req->item_ptr : nullptr;
+    X.ent_pos = g_dot_req ? g_dot_req->ent_pos : nullptr;
+    X.ent_cnt = g_dot_req ? g_dot_req->ent_cnt : nullptr;
+    X.nsg = g_dot_req ? g_dot_req->nsg : 0;
     X.dotp = g_dot_req ? g_dot_req->dotp : nullptr;
     if (g_dot_req) g_dot_req->parts_per_table = cg.B * cg.NC;
+    const int dot = !g_dot_req ? 0 : (g_dot_req->item_ptr ? 2 : 1);
 #define STB_LAUNCH_CHAIN1(PP, NN, FF, DD)                                                                      \
   do {                                                                                                        \
     if (p0)                                                                                                   \
@@ -2924,28 +2992,32 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     else                                                                                                      \
       hipLaunchKernelGGL((k_fill_chain<PP, NN, FF, DD>), grid, dim3(64 * (PP + NN + 1 + FF)), 0, st, A, X);   \
   } while (0)
-#define STB_LAUNCH_CHAIN(PP, NN, FF)               \
-  do {                                             \
-    if (X.cnt) STB_LAUNCH_CHAIN1(PP, NN, FF, true); \
-    else STB_LAUNCH_CHAIN1(PP, NN, FF, false);      \
+#define STB_LAUNCH_CHAIN(PP, NN, FF)                 \
+  do {                                               \
+    if (dot == 2) STB_LAUNCH_CHAIN1(PP, NN, FF, 2);   \
+    else if (dot == 1) STB_LAUNCH_CHAIN1(PP, NN, FF, 1); \
+    else STB_LAUNCH_CHAIN1(PP, NN, FF, 0);            \
   } while (0)
     const int shape = cg.P * 1000 + cg.NC * 10 + cg.NF;
+    // (the summing variants are compiled for the two default block shapes only)
+    if (dot != 0 && shape != 2063 && shape != 4101)
+      return fail("%s: the fused evaluation needs a default block shape (unset STB_CHAIN_P / _NC / _NF)", who);
     switch (shape) {
-      case 1031: STB_LAUNCH_CHAIN(1, 3, 1); break;
-      case 1033: STB_LAUNCH_CHAIN(1, 3, 3); break;
-      case 1061: STB_LAUNCH_CHAIN(1, 6, 1); break;
-      case 1063: STB_LAUNCH_CHAIN(1, 6, 3); break;
-      case 2041: STB_LAUNCH_CHAIN(2, 4, 1); break;
-      case 2043: STB_LAUNCH_CHAIN(2, 4, 3); break;
-      case 2061: STB_LAUNCH_CHAIN(2, 6, 1); break;
       case 2063: STB_LAUNCH_CHAIN(2, 6, 3); break;
-      case 2081: STB_LAUNCH_CHAIN(2, 8, 1); break;
-      case 2083: STB_LAUNCH_CHAIN(2, 8, 3); break;
-      case 4061: STB_LAUNCH_CHAIN(4, 6, 1); break;
-      case 4063: STB_LAUNCH_CHAIN(4, 6, 3); break;
-      case 4081: STB_LAUNCH_CHAIN(4, 8, 1); break;
-      case 4083: STB_LAUNCH_CHAIN(4, 8, 3); break;
       case 4101: STB_LAUNCH_CHAIN(4, 10, 1); break;
+      case 1031: STB_LAUNCH_CHAIN1(1, 3, 1, 0); break;
+      case 1033: STB_LAUNCH_CHAIN1(1, 3, 3, 0); break;
+      case 1061: STB_LAUNCH_CHAIN1(1, 6, 1, 0); break;
+      case 1063: STB_LAUNCH_CHAIN1(1, 6, 3, 0); break;
+      case 2041: STB_LAUNCH_CHAIN1(2, 4, 1, 0); break;
+      case 2043: STB_LAUNCH_CHAIN1(2, 4, 3, 0); break;
+      case 2061: STB_LAUNCH_CHAIN1(2, 6, 1, 0); break;
+      case 2081: STB_LAUNCH_CHAIN1(2, 8, 1, 0); break;
+      case 2083: STB_LAUNCH_CHAIN1(2, 8, 3, 0); break;
+      case 4061: STB_LAUNCH_CHAIN1(4, 6, 1, 0); break;
+      case 4063: STB_LAUNCH_CHAIN1(4, 6, 3, 0); break;
+      case 4081: STB_LAUNCH_CHAIN1(4, 8, 1, 0); break;
+      case 4083: STB_LAUNCH_CHAIN1(4, 8, 3, 0); break;
       default: return fail("%s: no chain kernel for %d producers / %d consumers / %d fetchers", who, cg.P, cg.NC, cg.NF);
     }
 #undef STB_LAUNCH_CHAIN1
@@ -3538,6 +3610,12 @@ struct stb_groups {
   double *d_dotp;
   size_t dotp_elems;
   int fused, fused_ready;
+  // sparse form of the fused evaluation: CSR of the occurring cells per (trip, slice) item
+  unsigned *d_item_ptr;
+  unsigned short *d_ent_pos;
+  unsigned *d_ent_cnt;
+  unsigned nsg;
+  int sparse;
 };
 
 // The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
@@ -3600,7 +3678,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   STB_ENTRY;
   if (!g) return;
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
-                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp};
+                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
+                  g->d_item_ptr, g->d_ent_pos, g->d_ent_cnt};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) pool_free(p);
   for (auto &e : g->ev)
@@ -3700,6 +3779,187 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
   return g;
 }
 
+// ---- sparse set-up of the fused evaluation, all on the device -----------------------------------
+#define STB_KEY_OTHER 0xfffffffffffffffeull  // a pair that addresses no table cell (t = 1, t = n, out of bounds)
+#define STB_KEY_SKIP 0xffffffffffffffffull   // n <= 1: contributes nothing (lib/samplea.c:78)
+
+// key of a pair: (item index << 9) | (row in trip << 6) | column in slice, item = trip * nsg + slice
+__global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, unsigned nsg,
+                            uint64_t *key, uint32_t *payload) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  uint64_t k;
+  if (nn <= 1) k = STB_KEY_SKIP;
+  else if (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
+  else {
+    const unsigned trip = (nn - 3) >> 3, u = (nn - 3) & 7, sg = (tt - 1) >> 6, ln = (tt - 1) & 63;
+    k = (((uint64_t)trip * nsg + sg) << 9) | (u << 6) | ln;
+  }
+  key[g] = k;
+  payload[g] = (uint32_t)g;
+}
+
+// counts[0] = keys below STB_KEY_OTHER (table cells), counts[1] = keys equal to it
+__global__ void k_key_bounds(const uint64_t *key, uint64_t G, uint64_t *counts) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint64_t lo = 0, hi = G;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (key[mid] < STB_KEY_OTHER) lo = mid + 1;
+    else hi = mid;
+  }
+  const uint64_t a = lo;
+  hi = G;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (key[mid] <= STB_KEY_OTHER) lo = mid + 1;
+    else hi = mid;
+  }
+  counts[0] = a;
+  counts[1] = lo - a;
+}
+
+__global__ void k_gather_pairs(const uint32_t *n, const uint16_t *t, const uint32_t *idx, uint64_t cnt, uint32_t *n2,
+                               uint16_t *t2) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < cnt) {
+    n2[g] = n[idx[g]];
+    t2[g] = t[idx[g]];
+  }
+}
+
+__global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigned short *pos, unsigned *item) {
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < *runs) {
+    pos[r] = (unsigned short)(ukey[r] & 511u);
+    item[r] = (unsigned)(ukey[r] >> 9);
+  }
+}
+
+// item_ptr[i] = first run whose item index is >= i
+__global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned nitems, unsigned *ptr) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nitems) return;
+  unsigned lo = 0, hi = *runs;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) / 2;
+    if (item[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  ptr[i] = lo;
+}
+
+// Returns 0 and sets g->sparse = 1 when the sparse form was built, 0 with g->sparse = 0 when the
+// pairs are too dense for it to pay (the caller then builds the count slab), non-zero on error.
+static int groups_fused_setup_sparse(stb_groups_t *g) {
+  const unsigned N = g->N, M = g->M;
+  const uint64_t G = g->G;
+  g->sparse = 0;
+  if (G == 0 || G >= 0xffffffffull) return 0;
+  const unsigned nsg = (M + 63) / 64 + 4;
+  const unsigned trips = (N - 2 + 7) / 8;
+  const uint64_t nitems64 = (uint64_t)trips * nsg;
+  if (nitems64 >= (1ull << 31)) return 0;
+  const unsigned nitems = (unsigned)nitems64;
+  uint64_t *k0 = nullptr, *k1 = nullptr, *uk = nullptr, *d_counts = nullptr;
+  uint32_t *p0 = nullptr, *p1 = nullptr;
+  unsigned *cnt = nullptr, *runs = nullptr, *item = nullptr;
+  void *tmp = nullptr;
+  int rc = 1;
+  const unsigned blocks = (unsigned)((G + 255) / 256);
+  do {
+    if (pool_malloc((void **)&k0, 8 * G) != hipSuccess || pool_malloc((void **)&k1, 8 * G) != hipSuccess ||
+        pool_malloc((void **)&p0, 4 * G) != hipSuccess || pool_malloc((void **)&p1, 4 * G) != hipSuccess ||
+        pool_malloc((void **)&uk, 8 * G) != hipSuccess || pool_malloc((void **)&cnt, 4 * G) != hipSuccess ||
+        pool_malloc((void **)&item, 4 * G) != hipSuccess || pool_malloc((void **)&runs, 64) != hipSuccess ||
+        pool_malloc((void **)&d_counts, 64) != hipSuccess) {
+      fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, k0, p0);
+    size_t b1 = 0, b2 = 0;
+    if (rocprim::radix_sort_pairs(nullptr, b1, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
+    if (rocprim::run_length_encode(nullptr, b2, k1, (unsigned)G, uk, cnt, runs, g->st) != hipSuccess) break;
+    const size_t tmp_bytes = b1 > b2 ? b1 : b2;
+    if (pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
+      fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    size_t bb = tmp_bytes;
+    if (rocprim::radix_sort_pairs(tmp, bb, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
+    hipLaunchKernelGGL(k_key_bounds, dim3(1), dim3(1), 0, g->st, k1, G, d_counts);
+    uint64_t h_counts[2] = {0, 0};
+    if (hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, g->st) != hipSuccess ||
+        hipStreamSynchronize(g->st) != hipSuccess)
+      break;
+    const uint64_t n_in = h_counts[0], n_other = h_counts[1];
+    // dense enough that every cell's log might as well be computed: leave it to the count slab
+    if (n_in * 3 > stb_table_cells(N, M)) {
+      rc = 0;
+      break;
+    }
+    // the pairs outside the table, in their sorted order
+    g->G2 = n_other;
+    if (pool_malloc((void **)&g->d_n2, 4 * (n_other ? n_other : 1)) != hipSuccess ||
+        pool_malloc((void **)&g->d_t2, 2 * (n_other ? n_other : 1)) != hipSuccess) {
+      fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (n_other)
+      hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t,
+                         p1 + n_in, n_other, g->d_n2, g->d_t2);
+    // distinct cells with their counts
+    unsigned h_runs = 0;
+    if (n_in) {
+      bb = tmp_bytes;
+      if (rocprim::run_length_encode(tmp, bb, k1, (unsigned)n_in, uk, cnt, runs, g->st) != hipSuccess) break;
+      if (hipMemcpyAsync(&h_runs, runs, 4, hipMemcpyDeviceToHost, g->st) != hipSuccess ||
+          hipStreamSynchronize(g->st) != hipSuccess)
+        break;
+    } else if (hipMemsetAsync(runs, 0, 4, g->st) != hipSuccess) {
+      break;
+    }
+    if (pool_malloc((void **)&g->d_ent_pos, 2 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        pool_malloc((void **)&g->d_ent_cnt, 4 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        pool_malloc((void **)&g->d_item_ptr, 4 * ((size_t)nitems + 2)) != hipSuccess) {
+      fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (h_runs) {
+      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos, item);
+      if (hipMemcpyAsync(g->d_ent_cnt, cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
+    }
+    hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr);
+    g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+    if (pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
+      fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (hipStreamSynchronize(g->st) != hipSuccess || hipGetLastError() != hipSuccess) break;
+    g->nsg = nsg;
+    g->sparse = 1;
+    g->fused_ready = 1;
+    rc = 0;
+  } while (0);
+  if (rc != 0) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail("stb_groups_aterms: sparse set-up failed: %s", hipGetErrorString(e));
+  }
+  (void)hipStreamSynchronize(g->st);
+  pool_free(k0);
+  pool_free(k1);
+  pool_free(p0);
+  pool_free(p1);
+  pool_free(uk);
+  pool_free(cnt);
+  pool_free(item);
+  pool_free(runs);
+  pool_free(d_counts);
+  pool_free(tmp);
+  return rc;
+}
+
 // Lazy set-up of the fused evaluation (first call with more than one discount): occurrence count
 // per table cell, and the pairs that address no cell.  The pairs come back from the device in their
 // sorted order, so the result does not depend on the order the caller supplied them in.
@@ -3764,13 +4024,23 @@ extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, in
   const int v = stb_default_variant();
   // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
   const bool fuse = g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
-  if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
+  if (fuse && !g->fused_ready) {
+    if (env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) return 1;
+    if (!g->fused_ready && groups_fused_setup(g)) return 1;
+  }
   HIPCHK(hipEventRecord(g->ev[0], g->st));
   if (fuse) {
     // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
     // then the few pairs that address no cell (t = 1 -> S1, t = n -> 0, out of bounds -> -inf)
     dot_request req;
-    req.cnt = g->d_cnt;
+    if (g->sparse) {
+      req.item_ptr = g->d_item_ptr;
+      req.ent_pos = g->d_ent_pos;
+      req.ent_cnt = g->d_ent_cnt;
+      req.nsg = g->nsg;
+    } else {
+      req.cnt = g->d_cnt;
+    }
     req.dotp = g->d_dotp;
     g_dot_req = &req;
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,

@@ -152,7 +152,8 @@ def test_config4_shape_sweep_is_deterministic():
 
 def test_fused_aterms_equals_table_then_sweep(monkeypatch):
     """stb_groups_aterms with the chain form never stores the tables (count * log S summed inside the
-    fill); it must agree with the stored-table + gather path, edge pairs included"""
+    fill, over the occurring cells only or over a count slab); both must agree with the stored-table +
+    gather path, edge pairs included"""
     L = capi.lib()
     g = synth.groups(80, 60, 900, "wide")
     n, t = g.n.copy(), g.t.copy()
@@ -166,8 +167,9 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
     N, M = 900, 900
     x = np.array([0.11, 0.5, 0.83])
     outs = []
-    for fused in ("1", "0"):
+    for fused, sparse in (("1", "1"), ("0", "1"), ("1", "0")):   # sparse DOT, two-pass, dense DOT
         monkeypatch.setenv("STB_ATERMS_FUSED", fused)
+        monkeypatch.setenv("STB_ATERMS_SPARSE", sparse)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar),
                                 N, M, len(x))
         assert h, capi.last_error()
@@ -179,6 +181,8 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
             L.stb_groups_free(h)
     assert np.all(np.isfinite(outs[0]))
     assert orc.close(outs[0], outs[1], 1e-12), (outs[0], outs[1])
+    assert orc.close(outs[2], outs[1], 1e-12), (outs[2], outs[1])
+    monkeypatch.setenv("STB_ATERMS_SPARSE", "1")
     # an out-of-bounds pair makes the whole sum -inf on both paths
     n[7], t[7] = 50, 60
     for fused in ("1", "0"):
@@ -191,3 +195,26 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
             assert np.all(np.isneginf(out))
         finally:
             L.stb_groups_free(h)
+
+
+def test_fused_aterms_dense_pairs_take_the_count_slab(monkeypatch):
+    """more pairs than a third of the table's cells: the fused evaluation uses the count slab (every
+    cell's log) instead of the per-item cell lists; same sums as the stored-table path"""
+    L = capi.lib()
+    g = synth.groups(90, 80, 70, "wide")      # 7200 pairs on a 70 x 70 table
+    N, M = 70, 70
+    x = np.array([0.2, 0.6])
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("STB_ATERMS_FUSED", fused)
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
+                                N, M, len(x))
+        assert h, capi.last_error()
+        try:
+            out = np.zeros(len(x))
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), len(x), capi.dp(out)))
+            outs.append(out)
+        finally:
+            L.stb_groups_free(h)
+    assert np.all(np.isfinite(outs[0]))
+    assert orc.close(outs[0], outs[1], 1e-12), (outs[0], outs[1])
