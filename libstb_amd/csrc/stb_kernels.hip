@@ -96,7 +96,7 @@ extern "C" int stb_device_name(char *buf, int len) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// A small cache of device buffers.  samplea builds and frees a group set (a dozen buffers, 70 MB at
+// A small cache of device (and pinned host) buffers.  samplea builds and frees a group set (a dozen buffers, 70 MB at
 // 10^6 pairs) on every call, as the reference builds and frees its table (lib/samplea.c:57-60,223);
 // hipMalloc / hipFree cost ~1 ms each way there.  Freed buffers are kept (up to STB_POOL_MB,
 // default 4096) and handed out again to requests of about the same size on the same device.
@@ -105,13 +105,22 @@ struct pool_block {
   void *p;
   size_t bytes;
   int dev;
+  int kind;  // 0: device memory, 1: pinned host memory
   bool used;
 };
 static std::mutex g_pool_mu;
 static std::vector<pool_block> g_pool;
 static size_t g_pool_idle = 0;
 
-static hipError_t pool_malloc(void **out, size_t bytes) {
+static hipError_t pool_raw_alloc(void **p, size_t bytes, int kind) {
+  return kind ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+}
+static void pool_raw_free(void *p, int kind) {
+  if (kind) (void)hipHostFree(p);
+  else (void)hipFree(p);
+}
+
+static hipError_t pool_malloc(void **out, size_t bytes, int kind = 0) {
   if (bytes == 0) bytes = 1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -120,7 +129,7 @@ static hipError_t pool_malloc(void **out, size_t bytes) {
     int best = -1;
     for (size_t i = 0; i < g_pool.size(); i++) {
       const pool_block &b = g_pool[i];
-      if (!b.used && b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+      if (!b.used && b.dev == dev && b.kind == kind && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
           (best < 0 || b.bytes < g_pool[best].bytes))
         best = (int)i;
     }
@@ -132,15 +141,15 @@ static hipError_t pool_malloc(void **out, size_t bytes) {
     }
   }
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = pool_raw_alloc(&p, bytes, kind);
   if (e != hipSuccess) {
     // out of memory: give the idle buffers back and try once more
-    std::vector<void *> drop;
+    std::vector<pool_block> drop;
     {
       std::lock_guard<std::mutex> lk(g_pool_mu);
       for (size_t i = 0; i < g_pool.size();) {
         if (!g_pool[i].used) {
-          drop.push_back(g_pool[i].p);
+          drop.push_back(g_pool[i]);
           g_pool_idle -= g_pool[i].bytes;
           g_pool.erase(g_pool.begin() + i);
         } else {
@@ -148,46 +157,50 @@ static hipError_t pool_malloc(void **out, size_t bytes) {
         }
       }
     }
-    for (void *q : drop) (void)hipFree(q);
+    for (const pool_block &q : drop) pool_raw_free(q.p, q.kind);
     (void)hipGetLastError();
-    e = hipMalloc(&p, bytes);
+    e = pool_raw_alloc(&p, bytes, kind);
     if (e != hipSuccess) return e;
   }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_pool.push_back(pool_block{p, bytes, dev, true});
+  g_pool.push_back(pool_block{p, bytes, dev, kind, true});
   *out = p;
   return hipSuccess;
 }
 
-static void pool_free(void *p) {
-  if (!p) return;
+// returns false if p did not come from the pool
+static bool pool_free(void *p) {
+  if (!p) return true;
   static const size_t cap = (size_t)(getenv("STB_POOL_MB") ? atol(getenv("STB_POOL_MB")) : 4096) << 20;
-  bool release = true;
+  int release = -1;  // kind to release with, -1: kept or unknown
+  bool known = false;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (size_t i = 0; i < g_pool.size(); i++) {
       if (g_pool[i].p == p) {
+        known = true;
         if (g_pool_idle + g_pool[i].bytes <= cap) {
           g_pool[i].used = false;
           g_pool_idle += g_pool[i].bytes;
-          release = false;
         } else {
+          release = g_pool[i].kind;
           g_pool.erase(g_pool.begin() + i);
         }
         break;
       }
     }
   }
-  if (release) (void)hipFree(p);
+  if (release >= 0) pool_raw_free(p, release);
+  return known;
 }
 
 extern "C" void stb_pool_trim(void) {
-  std::vector<void *> drop;
+  std::vector<pool_block> drop;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (size_t i = 0; i < g_pool.size();) {
       if (!g_pool[i].used) {
-        drop.push_back(g_pool[i].p);
+        drop.push_back(g_pool[i]);
         g_pool.erase(g_pool.begin() + i);
       } else {
         i++;
@@ -195,13 +208,13 @@ extern "C" void stb_pool_trim(void) {
     }
     g_pool_idle = 0;
   }
-  for (void *q : drop) (void)hipFree(q);
+  for (const pool_block &q : drop) pool_raw_free(q.p, q.kind);
 }
 
 extern "C" void *stb_device_malloc(size_t bytes) {
   STB_ENTRY;
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  hipError_t e = pool_malloc(&p, bytes ? bytes : 1, 0);
   if (e != hipSuccess) {
     fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     (void)hipGetLastError();
@@ -211,12 +224,12 @@ extern "C" void *stb_device_malloc(size_t bytes) {
 }
 extern "C" void stb_device_free(void *p) {
   STB_ENTRY;
-  if (p) (void)hipFree(p);
+  if (p && !pool_free(p)) (void)hipFree(p);
 }
 extern "C" void *stb_host_malloc(size_t bytes) {
   STB_ENTRY;
   void *p = nullptr;
-  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  hipError_t e = pool_malloc(&p, bytes ? bytes : 1, 1);
   if (e != hipSuccess) {
     fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     (void)hipGetLastError();
@@ -226,7 +239,7 @@ extern "C" void *stb_host_malloc(size_t bytes) {
 }
 extern "C" void stb_host_free(void *p) {
   STB_ENTRY;
-  if (p) (void)hipHostFree(p);
+  if (p && !pool_free(p)) (void)hipHostFree(p);
 }
 extern "C" int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
   STB_ENTRY;
