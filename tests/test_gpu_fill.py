@@ -207,3 +207,38 @@ def test_chainx_geometries_agree(monkeypatch, P, N, M):
         assert np.all(np.isfinite(got))
         assert orc.close(got, tab, TOL), (d, orc.max_err(got, tab))
         assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
+
+
+def test_chain_random_shapes_vs_oracle():
+    """chain form (the default) on random shapes, batches and discounts"""
+    rng = np.random.default_rng(20261003)
+    for _ in range(14):
+        N = int(rng.integers(3, 2600))
+        M = int(rng.integers(2, N + 1))
+        D = int(rng.integers(1, 5))
+        a = np.round(rng.uniform(0.0, 0.99, size=D), 6)
+        T = capi.DeviceTables(N, M, D=D)
+        T.tables.fill_(float("nan"))
+        T.fill(a, capi.FILL_CHAIN)
+        T.status()
+        for d in range(D):
+            S1, tab = orc.fill_S(float(a[d]), N, M)
+            got = T.packed_host(d)
+            assert np.all(np.isfinite(got)), (N, M, D, a)
+            assert orc.close(got, tab, TOL), (N, M, D, a, orc.max_err(got, tab))
+            assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
+
+
+def test_chain_gives_up_instead_of_hanging(monkeypatch):
+    """every wait of the chain form is bounded: with the bound set to zero a block that has to wait
+    records an error and runs to its end; the fill returns and stb_fill_status reports it"""
+    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    T = capi.DeviceTables(3000, 3000, D=1)
+    T.fill([0.5], capi.FILL_CHAIN)
+    with pytest.raises(capi.StbError):
+        T.status()
+    monkeypatch.delenv("STB_CHAIN_TIMEOUT_MS")
+    T.fill([0.5], capi.FILL_CHAIN)      # and the next fill is fine again
+    T.status()
+    S1, tab = orc.fill_S(0.5, 3000, 3000)
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
