@@ -179,8 +179,10 @@ def sweep_extra(dev):
             a_ref = R.ref_samplea_flat(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
                                        orc.dp(g.bpar), 1, 0)
             tr = time.perf_counter() - t0
+            ev_ref = R.ref_trace_count()
             out["samplea"]["cpu_reference"] = {"seconds": tr, "cores": 1, "a": a_ref,
-                                               "aterms_evaluations": R.ref_trace_count()}
+                                               "aterms_evaluations": ev_ref,
+                                               "grid_evals_per_s": ev_ref * g.pairs / tr}
     except Exception as e:  # the timing section must never take the contract line down
         out["samplea_error"] = repr(e)
     return out
