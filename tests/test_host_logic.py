@@ -234,3 +234,16 @@ def test_yaps_sink_is_pluggable():
         assert seen == [b"hello %d\n"]
     finally:
         L.yaps_yapper(None)
+
+
+def test_fill_workspace_covers_every_smaller_batch():
+    """a workspace sized for D tables is also used for smaller batches (stb_groups with Dmax): the
+    size query is pure host arithmetic and must not shrink when D grows, whatever block shape the
+    chain form picks for a batch"""
+    L = capi.lib()
+    for (N, M) in ((2, 2), (3, 2), (200, 50), (4000, 4000), (10000, 10000), (20000, 700)):
+        prev = 0
+        for D in (1, 2, 3, 4, 5, 6, 8, 16, 20, 21, 64):
+            need = int(L.stb_fill_workspace_bytes(N, M, D))
+            assert need >= prev, (N, M, D, need, prev)
+            prev = need
