@@ -1,8 +1,14 @@
 // stb_kernels.hip -- gfx950 kernels and the additive C ABI (include/stb_hip.h) of libstb_amd.
 //
 // What runs here, and the reference code it replaces (paths relative to the reference tree):
-//   K1/K2  k_fill_rows      table fill of S_remake_part, double S branch   lib/stable.c:321-388
+//   K1/K2  table fill of S_remake_part, double S branch                    lib/stable.c:321-388
+//            k_fill_chain   default: one launch, column blocks chained through edge granules
+//            k_fill_pc      many tables: producer wave + consumer waves per block, per 128 rows
+//            k_rec+k_logconv / k_fill_bfp / k_fill_rows   earlier forms, kept for ablation
+//            k_fill_chainx  experimental: chain blocks + converter blocks in one launch
+//          k_fillv_chain    V-table fill                                   lib/stable.c:451-482
 //   K3     k_sweep_partial  the S_S gather-sum inside aterms               lib/samplea.c:68-80
+//          k_fill_chain<.., DOT>  the same sum taken inside the fill (grids of discounts)
 //   K4     k_terms_partial  restaurant terms of aterms / lgamma sum of bterms
 //                                                       lib/samplea.c:65-67, lib/sampleb.c:33-41
 //          k_lookup         S_S semantics for a list of (n,m)              lib/stable.c:941-974
@@ -10,11 +16,10 @@
 // Design notes (DESIGN.md has the long form).  A table row depends only on the row above it, and
 // inside a row information moves one column to the right per row (cell (n,m) reads (n-1,m) and
 // (n-1,m-1)).  So the table is cut into column strips, one 64-lane wavefront per strip, every
-// lane holding C adjacent columns in registers; the only cross-lane traffic is one DPP wave shift
-// per row.  A launch advances every strip by R rows; a strip recomputes an R-column halo on its
-// left instead of synchronising with its neighbour, and the kernel boundary publishes the last
-// row (the "frontier", kept in (mantissa, exponent) form) for the next launch.  Stores go
-// straight from registers to the row-major slab, 16 B per lane, 1 KiB per wave-instruction.
+// lane holding 1-4 adjacent columns in registers; inside a wave the left neighbour comes through
+// one DPP wave shift per row.  The forms differ in how a strip gets the column to its left: the
+// launch-per-row-block forms recompute a halo and publish the last row (the "frontier") at the
+// kernel boundary; the chain form hands the edge column on, wave to wave, inside one launch.
 //
 // No CPU fallback exists in this file: without a device every entry point fails with a message.
 
@@ -1401,7 +1406,6 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
     double s = 1.0;
     int ep = 1 + PC_BIAS;
     int p = g0w / TP, tin = g0w - p * TP;
-    // the consumer item that last used the ring slot trip g is about to overwrite
     // the consumer item that last used the ring slot a trip is about to overwrite
     int chk_i = (g0w - RD - g0b) * P + w;
     int chk_c = (chk_i >= 0) ? chk_i % NC : w, chk_k = (chk_i >= 0) ? chk_i / NC : 0;  // (first i >= 0 is w)
