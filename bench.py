@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- S-table fill throughput of libstb_amd on MI355X (BASELINE.json: "S-table cells/s").
+"""bench.py -- libstb_amd on MI355X: "S-table cells/s + sampler grid-evals/s at N=M=10000" (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch of synthetic input: every rank fills the
-log-Stirling tables S^n_{m,a} (N = M = 10000) of ITS discounts through the C ABI
-(stb_fill_S, the device form of the reference's S_make/S_remake, lib/stable.c:321-388), then the
-per-discount probe scalars are all-gathered over RCCL (the path's only exchange: 8 bytes per
-discount).  Per-GPU work is fixed as N grows (weak scaling); value = cells filled by all ranks per
-second of the slowest rank.
+log-Stirling tables S^n_{m,a} (N = M = 10000) of ITS discounts through the C ABI (stb_fill_S, the
+device form of the reference's S_make/S_remake, lib/stable.c:321-388), then the per-discount probe
+scalars are all-gathered over RCCL (the path's only exchange: 8 bytes per discount).  Per-GPU work
+is fixed as N grows (weak scaling); value = cells filled by all ranks per second of the slowest rank.
 
     python bench.py --gpus 1 --steps 20 --warmup 3          # configs[1]: single discount a=0.5
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # one discount per GPU
     python bench.py --discounts-per-gpu 8                    # the batched mode (configs[2] shape)
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_fill_chain) against HBM:
-algorithmic bytes = 8 B per stored cell, duration = device time of the fill kernels
-measured with per-launch HIP start/stop events inside the timed region.  `cpu_baseline` times the
-reference's (or the oracle's) single-core fill of the same table on this box's host CPU.
+One JSON line on stdout (rank 0):
+  value / roofline   configs[1]; the roofline prices the fill kernel against HBM (8 B per stored cell,
+                     SURVEY 8d), kernel time from per-launch HIP start/stop events inside bench.py
+  roofline_sweep     the second half of the metric: the (n,t) gather-sum kernel over 64 tables of
+                     N=M=10000 and 10^6 pairs, (8 + 6/D) B per grid-eval
+  extra.batch64      at EVERY --gpus N: the north-star job -- the 64-discount grid (0.05,0.95) sharded
+                     64/N per rank: batched fill, and the fused grid aterms over 10^6 pairs whose 64
+                     log-posteriors are all-gathered over RCCL.  A 1 -> 8 GPU curve of these numbers
+                     is the strong-scaling speed-up the north star asks for.
+  cpu_baseline       the reference's (or the oracle's) fill of the same table on this box's host CPU
 """
 from __future__ import annotations
 
@@ -35,6 +40,7 @@ import torch
 from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+TRAFFIC_DB = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 
 
 def cpu_baseline(N: int, M: int, a: float):
@@ -55,12 +61,13 @@ def cpu_baseline(N: int, M: int, a: float):
         R.S_free(sp)
         kind = "reference"
         what = f"S_remake of the full N={N} M={M} a={a} table, best of 3 (oracle/_ref/libstb_ref.so)"
-        # the batched case on all host cores of this box, one table per thread (tables
-        # of different discounts are independent; ctypes releases the GIL inside the C call)
+        # the batched case on the host cores this box gives a one-GPU job (16 of them),
+        # one table per thread (tables of different discounts are independent; ctypes releases the GIL)
         try:
             import threading
 
-            nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+            share = len(os.sched_getaffinity(0))
+            nthr = max(1, min(16, share))
             grid = synth.discount_grid(64)[:nthr]
             sps = [None] * nthr
 
@@ -81,10 +88,11 @@ def cpu_baseline(N: int, M: int, a: float):
             for sp2 in sps:
                 if sp2:
                     R.S_free(sp2)
-            all_cores = {"value": cells * nthr / wall, "unit": "cells/s", "cores": nthr, "tables": nthr,
-                         "seconds": wall, "sample": f"{nthr} threads, one S_remake of an N={N} M={M} table each, concurrently"}
+            many = {"value": cells * nthr / wall, "unit": "cells/s", "cores": nthr, "tables": nthr, "seconds": wall,
+                    "cpus_in_affinity_mask": share,
+                    "sample": f"{nthr} threads (the one-GPU job's share of the host), one S_remake of an N={N} M={M} table each, concurrently"}
         except Exception as e:  # never take the contract line down
-            all_cores = {"error": repr(e)}
+            many = {"error": repr(e)}
     else:
         L = orc.oracle()
         S1 = np.zeros(N)
@@ -93,48 +101,70 @@ def cpu_baseline(N: int, M: int, a: float):
         best = L.orc_time_fill(a, N, M, 3, orc.dp(S1), orc.dp(tab))
         kind = "port"
         what = f"orc_fill_S of the full N={N} M={M} a={a} table, best of 3 (oracle/liboracle.so)"
-        all_cores = None
+        many = None
     out = {"value": cells / best, "unit": "cells/s", "cores": 1, "kind": kind, "sample": what,
            "seconds": best, "host_cpus": os.cpu_count()}
-    if all_cores is not None:
-        out["all_cores"] = all_cores
+    if many is not None:
+        out["multi_core"] = many
     return out
 
 
-def sweep_extra(dev):
-    """Second half of the BASELINE metric ("sampler grid-evals/s"), reported beside `value`:
-    configs[3]/[4] shape on ONE GPU -- 10^6 synthetic (n,t) pairs (I=1000 x K=1000, n<4000, wide t)
-    against N=M=4000 tables; one grid-eval = one (discount, pair) term of the log-posterior.
-    D=1 is one aterms() evaluation as samplea's ARMS makes them; D=64 is the batched grid."""
-    import ctypes as C
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    L = capi.lib()
-    g = synth.groups(1000, 1000, 4000, "wide")
+def traffic_lookup(key: str, kernel_prefix: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py:
+    WRITE_SIZE + 2*FETCH_SIZE from separate passes, KiB -> bytes)"""
+    if not os.path.exists(TRAFFIC_DB):
+        return None, None
+    db = json.load(open(TRAFFIC_DB))
+    for kname, rec in db.get(key, {}).items():
+        if kname.startswith(kernel_prefix):
+            return rec["hbm_bytes_per_launch"], f"profiles/{os.path.basename(TRAFFIC_DB)}[{key}][{kname}]"
+    return None, None
+
+
+def groups_handle(L, g, N, M, Dmax):
+    h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
+                            g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p), capi.dp(g.bpar), N, M, Dmax)
+    if not h:
+        raise capi.StbError(capi.last_error())
+    return h
+
+
+def grid_bounds(g):
     M = max(int(g.t.max()) + 1, 10)
-    N = max(int(g.n.max()) + 1, M)
+    return max(int(g.n.max()) + 1, M), M
+
+
+def timed_aterms(L, h, x, reps=4):
+    D = len(x)
+    res = np.zeros(D)
+    mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(res), C.byref(mf), C.byref(ms), C.byref(mt)))
+        wall = time.perf_counter() - t0
+        if best is None or wall < best[0]:
+            best = (wall, mf.value, ms.value, mt.value)
+    return best, res
+
+
+def sweep_section(n_max: int):
+    """sampler grid-evals/s on ONE GPU: 10^6 synthetic (n,t) pairs (I=1000 x K=1000, n < n_max, wide t)
+    against N=M~n_max tables; one grid-eval = one (discount, pair) term of the log-posterior.
+    D=1 is one aterms() evaluation as samplea's ARMS makes them; D=64 is the batched grid."""
+    L = capi.lib()
+    g = synth.groups(1000, 1000, n_max, "wide")
+    N, M = grid_bounds(g)
     out = {"pairs": g.pairs, "N": N, "M": M,
            "note": "fused: the chain fill sums count*log S itself (no table stored, no second pass); "
                    "two_pass: tables stored, then the sorted gather-sum (fill_ms / sweep_ms / terms_ms are device times)"}
     for label, fused in (("fused", "1"), ("two_pass", "0")):
         os.environ["STB_ATERMS_FUSED"] = fused
-        h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
-                                g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p),
-                                capi.dp(g.bpar), N, M, 64)
-        if not h:
-            return {"error": capi.last_error()}
+        h = groups_handle(L, g, N, M, 64)
         try:
             for D in (1, 64):
                 x = np.ascontiguousarray(synth.discount_grid(64)[:D] if D > 1 else np.array([0.45]))
-                res = np.zeros(D)
-                mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
-                best = None
-                for _ in range(4):
-                    t0 = time.perf_counter()
-                    capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(res), C.byref(mf), C.byref(ms), C.byref(mt)))
-                    wall = time.perf_counter() - t0
-                    if best is None or wall < best[0]:
-                        best = (wall, mf.value, ms.value, mt.value)
-                wall, f_ms, s_ms, t_ms = best
+                (wall, f_ms, s_ms, t_ms), _ = timed_aterms(L, h, x)
                 ge = D * g.pairs
                 rec = {"grid_evals": ge, "fill_ms": f_ms, "sweep_ms": s_ms, "terms_ms": t_ms, "wall_ms": wall * 1e3,
                        "grid_evals_per_s_end_to_end": ge / wall}
@@ -145,46 +175,50 @@ def sweep_extra(dev):
         finally:
             L.stb_groups_free(h)
     os.environ.pop("STB_ATERMS_FUSED", None)
-    # one whole samplea() / sampleb() call (host ARMS + device posteriors) on the same groups, and
-    # the reference's own samplea on this box's host CPU when oracle/_ref is present
-    try:
-        import orc
+    return out, g
 
-        NP = C.POINTER(C.c_uint32) * g.I
-        TP = C.POINTER(C.c_uint16) * g.I
-        nn, tt = NP(), TP()
-        off = 0
-        for i in range(g.I):
-            nn[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
-            tt[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
-            off += int(g.K[i])
+
+def sampler_calls(g):
+    """one whole samplea() / sampleb() call (host ARMS + device posteriors) on the groups, and the
+    reference's own samplea on this box's host CPU when oracle/_ref is present"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+
+    L = capi.lib()
+    out = {}
+    NP = C.POINTER(C.c_uint32) * g.I
+    TP = C.POINTER(C.c_uint16) * g.I
+    nn, tt = NP(), TP()
+    off = 0
+    for i in range(g.I):
+        nn[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+        tt[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
+        off += int(g.K[i])
+    best = None
+    for _ in range(3):
         orc.seed_libc(777, 12345)
         t0 = time.perf_counter()
         a_new = L.samplea(0.5, g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p), nn, tt, None,
                           capi.dp(g.bpar), None, 1, 0)
         ta = time.perf_counter() - t0
-        evals = L.stb_sampler_trace_count()
+        best = ta if best is None else min(best, ta)
+    evals = L.stb_sampler_trace_count()
+    orc.seed_libc(777, 12345)
+    t0 = time.perf_counter()
+    b_new = L.sampleb(10.0, g.I, g.shape, g.scale, g.N.ctypes.data_as(capi.c_u32_p), g.T.ctypes.data_as(capi.c_u32_p),
+                      0.5, None, 1, 0)
+    tb = time.perf_counter() - t0
+    out["samplea"] = {"seconds": best, "aterms_evaluations": evals, "a": a_new, "grid_evals_per_s": evals * g.pairs / best}
+    out["sampleb"] = {"seconds": tb, "bterms_evaluations": L.stb_sampler_trace_count(), "b": b_new}
+    if orc.have_ref():
+        R = orc.ref()
         orc.seed_libc(777, 12345)
         t0 = time.perf_counter()
-        b_new = L.sampleb(10.0, g.I, g.shape, g.scale, g.N.ctypes.data_as(capi.c_u32_p), g.T.ctypes.data_as(capi.c_u32_p),
-                          0.5, None, 1, 0)
-        tb = time.perf_counter() - t0
-        out["samplea"] = {"seconds": ta, "aterms_evaluations": evals, "a": a_new,
-                          "grid_evals_per_s": evals * g.pairs / ta}
-        out["sampleb"] = {"seconds": tb, "bterms_evaluations": L.stb_sampler_trace_count(), "b": b_new}
-        if orc.have_ref():
-            R = orc.ref()
-            orc.seed_libc(777, 12345)
-            t0 = time.perf_counter()
-            a_ref = R.ref_samplea_flat(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
-                                       orc.dp(g.bpar), 1, 0)
-            tr = time.perf_counter() - t0
-            ev_ref = R.ref_trace_count()
-            out["samplea"]["cpu_reference"] = {"seconds": tr, "cores": 1, "a": a_ref,
-                                               "aterms_evaluations": ev_ref,
-                                               "grid_evals_per_s": ev_ref * g.pairs / tr}
-    except Exception as e:  # the timing section must never take the contract line down
-        out["samplea_error"] = repr(e)
+        a_ref = R.ref_samplea_flat(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), 1, 0)
+        tr = time.perf_counter() - t0
+        ev_ref = R.ref_trace_count()
+        out["samplea"]["cpu_reference"] = {"seconds": tr, "cores": 1, "a": a_ref, "aterms_evaluations": ev_ref,
+                                           "grid_evals_per_s": ev_ref * g.pairs / tr}
     return out
 
 
@@ -198,7 +232,9 @@ def main():
     ap.add_argument("--discounts-per-gpu", type=int, default=1)
     ap.add_argument("--variant", type=int, default=capi.FILL_SCALED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the sweep (grid-evals/s) section")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sweep (grid-evals/s) sections")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the 64-discount sharded batch")
+    ap.add_argument("--batch-steps", type=int, default=5, help="timed steps of the 64-discount batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,20 +260,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     L = capi.lib()
+    capi.check(L.stb_set_device(local))  # the library's objects go where torch's buffers are
     N, M, Dl = args.n, args.m, args.discounts_per_gpu
     Dg = Dl * world
-    # configs[1] is the single discount a=0.5; any larger job shards the (0.05,0.95) grid
-    grid = np.array([0.5]) if Dg == 1 else synth.discount_grid(Dg)
-    mine = np.ascontiguousarray(grid[shard.my_slice(Dg, rank, world)])
-    T = capi.DeviceTables(N, M, D=Dl, device=dev)
-    cells_rank = T.cells * Dl
-    probe_idx = torch.tensor([T.rowoff(N) + max(M // 2, 2) - 2], device=dev)
-    gathered = torch.empty(Dg, dtype=torch.float64, device=dev)
-
-    def step():
-        T.fill(mine, args.variant)
-        probes = T.tables.index_select(1, probe_idx).reshape(-1)  # log S^N_{M/2} per discount
-        gathered.copy_(shard.gather_scalars(probes, Dg, dist))
 
     def fence():
         torch.cuda.synchronize()
@@ -248,6 +273,27 @@ def main():
                 dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
+    def must_be_clean(what, fb0):
+        """a chain fill that gave up (and was silently refilled) would make the timing meaningless"""
+        capi.check(L.stb_fill_status())
+        if L.stb_fill_fallbacks() != fb0:
+            raise SystemExit(f"bench: {what}: a chain-form fill gave up and fell back to the producer/consumer form")
+
+    # ------------------------------------------------------------------ configs[1] (and --discounts-per-gpu)
+    # configs[1] is the single discount a=0.5; any larger job shards the (0.05,0.95) grid
+    grid = np.array([0.5]) if Dg == 1 else synth.discount_grid(Dg)
+    mine = np.ascontiguousarray(grid[shard.my_slice(Dg, rank, world)])
+    T = capi.DeviceTables(N, M, D=Dl, device=dev)
+    cells_rank = T.cells * Dl
+    probe_idx = torch.tensor([T.rowoff(N) + max(M // 2, 2) - 2], device=dev)
+    gathered = torch.empty(Dg, dtype=torch.float64, device=dev)
+    fb0 = L.stb_fill_fallbacks()
+
+    def step():
+        T.fill(mine, args.variant)
+        probes = T.tables.index_select(1, probe_idx).reshape(-1)  # log S^N_{M/2} per discount
+        gathered.copy_(shard.gather_scalars(probes, Dg, dist))
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -256,52 +302,98 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    must_be_clean("timed steps", fb0)
 
     # Kernel-only durations for the roofline: the same K steps once more, live, with a HIP
-    # start/stop event pair on every fill launch.  Kept out of the timed region above because the
-    # ~200 event-carrying launches per step cost ~5 us of host time each and would understate
-    # `value` by a third; the device durations themselves are unaffected (profiles/ agrees).
+    # start/stop event pair on every fill launch.  Kept out of the timed region above because an
+    # event-carrying launch costs ~5 us of host time; the device durations themselves are unaffected
+    # (profiles/ agrees).
     L.stb_fill_profile_begin()
     for _ in range(args.steps):
         step()
     fence()
     kms, kn = C.c_double(0.0), C.c_int(0)
     capi.check(L.stb_fill_profile_end(C.byref(kms), C.byref(kn)))
+    must_be_clean("profiled steps", fb0)
 
     dt = shard.max_over_ranks(dt, dev, dist)
     total_cells = cells_rank * world * args.steps
     value = total_cells / dt
+    Cc, Rr, nl = C.c_int(), C.c_int(), C.c_int()
+    form = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
+    del T
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ the 64-discount batch, sharded
+    batch64 = None
+    if not args.no_batch64 and 64 % world == 0:
+        D64 = 64 // world
+        grid64 = synth.discount_grid(64)
+        mine64 = np.ascontiguousarray(grid64[shard.my_slice(64, rank, world)])
+        T64 = capi.DeviceTables(N, M, D=D64, device=dev)
+        pidx = torch.tensor([T64.rowoff(N) + max(M // 2, 2) - 2], device=dev)
+        fb0 = L.stb_fill_fallbacks()
+
+        def step64():
+            T64.fill(mine64, capi.FILL_SCALED)
+            pr = T64.tables.index_select(1, pidx).reshape(-1)
+            return shard.gather_scalars(pr, 64, dist)
+
+        step64()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.batch_steps):
+            got = step64()
+        fence()
+        dt64 = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
+        must_be_clean("batch64 fill", fb0)
+        L.stb_fill_profile_begin()
+        step64()
+        fence()
+        k64, n64 = C.c_double(0.0), C.c_int(0)
+        capi.check(L.stb_fill_profile_end(C.byref(k64), C.byref(n64)))
+        k64 = shard.max_over_ranks(k64.value, dev, dist)
+        ranks_seen = int(torch.isfinite(got).sum().item()) // D64
+        cells64 = T64.cells * 64
+        fT = L.stb_fill_tuning(N, M, D64, None, None, None)
+        del T64
+        torch.cuda.empty_cache()
+        # fused grid aterms: 10^6 pairs with n < N, every rank evaluates its share of the grid
+        g = synth.groups(1000, 1000, N, "wide")
+        Ng, Mg = grid_bounds(g)
+        h = groups_handle(L, g, Ng, Mg, D64)
+        post = np.zeros(D64)
+        capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))  # set-up + warm-up
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.batch_steps):
+            capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))
+            allpost = shard.gather_scalars(torch.as_tensor(post, device=dev), 64, dist)
+        fence()
+        dtg = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
+        L.stb_groups_free(h)
+        batch64 = {
+            "discounts_total": 64, "discounts_per_gpu": D64, "ranks": world, "ranks_seen": ranks_seen,
+            "fill": {"ms": dt64 * 1e3, "cells_per_s": cells64 / dt64, "form": {2: "pc", 3: "chain"}.get(fT, str(fT)),
+                     "kernel_ms": k64, "launches": n64.value,
+                     "frac_of_hbm_peak_per_gpu": (8.0 * cells64 / world / (k64 * 1e-3) / 1e9 / HBM_PEAK_GBS) if k64 > 0 else None},
+            "grid_aterms": {"ms": dtg * 1e3, "pairs": g.pairs, "N": Ng, "M": Mg, "grid_evals_per_s": 64 * g.pairs / dtg,
+                            "log_posteriors_finite": int(torch.isfinite(allpost).sum().item()),
+                            "log_posterior_d0_d63": [float(allpost[0]), float(allpost[63])]},
+            "note": "strong scaling: the same 64 tables / 64 x 10^6 grid-evals at every --gpus N; speed-up(N) = ms(1) / ms(N)",
+        }
 
     if rank == 0:
-        Cc, Rr, nl = C.c_int(), C.c_int(), C.c_int()
-        form = L.stb_fill_tuning(N, M, Dl, C.byref(Cc), C.byref(Rr), C.byref(nl))
-        # 0 fused, 1 split, 2 producer/consumer, 3 chain, 4 chain with converter blocks, 5 ablation forms
-        form = {capi.FILL_SPLIT: 1, capi.FILL_PC: 2, capi.FILL_FUSED: 0, capi.FILL_CHAIN: 3,
-                capi.FILL_CHAINX: 4 if Dl <= 2 else 3, capi.FILL_SCALED: form}.get(args.variant, 5)
-        FORMS = ["fused", "split", "pc", "chain", "chainx", "other"]
-        KERNELS = ["k_fill_bfp", "k_rec", "k_fill_pc", "k_fill_chain", "k_fill_chainx", "k_fill_rows"]
-        KERNEL_NOTES = ["k_fill_bfp", "k_rec (recurrence; logs follow in k_logconv on a second stream)",
-                        "k_fill_pc (producer wave + consumer waves per column block)",
-                        "k_fill_chain (one launch per fill: producer, consumer, publisher and fetcher waves per column block)",
-                        "k_fill_chainx (one launch per fill: chain blocks + converter blocks)", "k_fill_rows"]
+        FORMS = {2: ("pc", "k_fill_pc", "k_fill_pc (producer wave + consumer waves per column block, launched per 128 rows)"),
+                 3: ("chain", "k_fill_chain", "k_fill_chain (one launch per fill: producer, consumer and fetcher waves per column block)")}
+        fname, kprefix, knote = FORMS.get(form if args.variant == capi.FILL_SCALED else -1, ("other", "k_fill", f"fill variant {args.variant}"))
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches
         bytes_per_launch = 8.0 * cells_rank * args.steps / launches  # 8 B per stored cell
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         name = bytearray(128)
         L.stb_device_name((C.c_char * 128).from_buffer(name), 128)
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (tools/pmc_traffic.py: WRITE_SIZE + 2*FETCH_SIZE, separate passes, KiB -> bytes)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            db = json.load(open(tpath))
-            key = f"N{N}_M{M}_D{Dl}_{FORMS[form]}"
-            want = KERNELS[form]
-            for kname, rec in db.get(key, {}).items():
-                if kname.startswith(want):
-                    traffic = rec["hbm_bytes_per_launch"]
-                    traffic_src = f"profiles/r01_hbm_traffic.json[{key}][{kname}]"
+        traffic, traffic_src = traffic_lookup(f"N{N}_M{M}_D{Dl}_{fname}", kprefix)
         out = {
             "metric": "S-table cells/s",
             "value": value,
@@ -319,15 +411,15 @@ def main():
                 "workload": ("configs[1]: single-discount S-table N=M=10000 a=0.5" if (Dg == 1 and N == 10000 and M == 10000)
                              else f"{Dl} discount(s) per GPU of the {Dg}-point grid, S-table N={N} M={M}"),
                 "N": N, "M": M, "discounts_per_gpu": Dl, "discounts_total": Dg,
-                "cells_per_table": T.cells, "variant": args.variant,
-                "columns_per_lane": Cc.value, "rows_per_launch": Rr.value,
+                "cells_per_table": cells_rank // Dl, "variant": args.variant,
+                "columns_per_block": Cc.value, "rows_per_launch": Rr.value,
                 "parallelism": f"discount-sharded x{world}, all_gather of {Dg} probe scalars per step",
                 "device": name.split(b"\0")[0].decode(),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": KERNEL_NOTES[form],
-                "form": FORMS[form],
+                "kernel": knote,
+                "form": fname,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -338,15 +430,40 @@ def main():
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_per_step": kms.value / args.steps,
-                "note": "one table per GPU is bound by the N serial row steps of the recurrence (one wave per 64 columns), not by HBM; see DESIGN.md",
+                "note": "one table per GPU is bound by the N serial row steps of the recurrence plus one hand-off per column block, not by HBM; see DESIGN.md",
             },
         }
+        extra = {}
+        if batch64 is not None:
+            extra["batch64"] = batch64
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, float(mine[0]))
         if world == 1 and not args.no_extra:
-            del T
-            torch.cuda.empty_cache()
-            out["extra"] = {"sampler_sweep": sweep_extra(dev)}
+            try:
+                s10k, _ = sweep_section(10000)
+                tp = s10k["D64"]["two_pass"]
+                fu = s10k["D64"]["fused"]
+                alg = tp["grid_evals"] * (8 + 6.0 / 64)
+                tr, tr_src = traffic_lookup("sweep_N10000_D64", "k_sweep_partial")
+                out["roofline_sweep"] = {
+                    "metric": "sampler grid-evals/s", "bound": "hbm",
+                    "kernel": "k_sweep_partial (+ k_reduce_final): sum of S_S(n,t) over 10^6 sorted pairs x 64 stored tables of N=M=10000",
+                    "grid_evals": tp["grid_evals"], "device_ms": tp["sweep_ms"],
+                    "value": tp["grid_evals"] / (tp["sweep_ms"] * 1e-3), "unit": "grid-evals/s",
+                    "algorithmic_bytes": alg, "achieved": alg / (tp["sweep_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "frac": alg / (tp["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
+                    "end_to_end": {"two_pass_grid_evals_per_s": tp["grid_evals_per_s_end_to_end"],
+                                   "fused_grid_evals_per_s": fu["grid_evals_per_s_end_to_end"], "fused_wall_ms": fu["wall_ms"],
+                                   "note": "fused = the table is never stored: k_fill_chain sums count*log S for the occurring cells itself"},
+                }
+                extra["sampler_sweep_N10000"] = s10k
+                s4k, g4k = sweep_section(4000)
+                extra["sampler_sweep"] = s4k
+                extra["sampler_sweep"].update(sampler_calls(g4k))
+            except Exception as e:  # the extras must never take the contract line down
+                extra["sampler_error"] = repr(e)
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -27,6 +27,18 @@ const char *stb_last_error(void);
 int stb_device_count(void);                 /* 0 when no usable GPU */
 int stb_device_name(char *buf, int len);    /* name + gcnArch of the current device */
 
+/* ---- which GPU.  The reference is a host library and has no such notion; SURVEY 5 asks for a
+ * device-id knob.  A thread picks the GPU for the objects it creates (S_make, stb_groups_create) with
+ * stb_set_device(k); without it STB_DEVICE=k in the environment decides; without either the HIP
+ * runtime's current device is used.  Tables and group sets remember their device: every later call
+ * on them (S_remake, growth inside S_S / S_V, S_free, stb_groups_aterms ...) switches to it and puts
+ * the caller's current device back.  stb_device_enter / stb_device_leave are that switch, for
+ * callers of the raw-pointer entry points below (which run on the current device). ---- */
+int stb_set_device(int dev);                /* non-zero if dev is not a usable device */
+int stb_get_device(void);                   /* the device the next S_make / stb_groups_create will use */
+int stb_device_enter(int dev);              /* make dev current; returns what to pass to stb_device_leave */
+void stb_device_leave(int prev);
+
 /* ---- memory and stream helpers, so that C / FFI callers need no HIP headers ---- */
 void *stb_device_malloc(size_t bytes);                 /* hipMalloc; NULL on failure */
 void stb_device_free(void *p);
@@ -57,14 +69,14 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
  * variant              STB_FILL_SCALED (default), STB_FILL_LOGDOMAIN or STB_FILL_SCALED_STEP
  */
-#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks SPLIT or PC */
+#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks CHAIN or PC */
 #define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
-#define STB_FILL_SCALED_STEP 2 /* linear-domain, renormalised every row, libm-grade log (ablation) */
-#define STB_FILL_SPLIT 3       /* recurrence kernel + in-place log conversion kernel on auxiliary streams */
-#define STB_FILL_FUSED 4       /* recurrence and log in one kernel (8 B of HBM traffic per cell) */
+#define STB_FILL_SCALED_STEP 2 /* (ablation build) linear-domain, renormalised every row, libm-grade log */
+#define STB_FILL_SPLIT 3       /* (ablation build) recurrence kernel + in-place log conversion on auxiliary streams */
+#define STB_FILL_FUSED 4       /* (ablation build) recurrence and log in one kernel, launched per row block */
 #define STB_FILL_PC 5          /* one producer wave (recurrence) + consumer waves (logs) per column block, via LDS */
 #define STB_FILL_CHAIN 6       /* one launch: column blocks keep their columns for all rows, edges handed on in HBM */
-#define STB_FILL_CHAINX 7      /* the same chain alone in its blocks; logs by converter blocks of the same launch (D <= 2) */
+#define STB_FILL_CHAINX 7      /* (ablation build) the chain alone in its blocks; logs by converter blocks (D <= 2) */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,
@@ -77,6 +89,13 @@ int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *
  * with stb_last_error() set when a column block gave up waiting for its neighbour (the fill's
  * polls are bounded; STB_CHAIN_TIMEOUT_MS, default 2000).  The other forms cannot fail on the device. */
 int stb_fill_status(void);
+/* A chain-form stb_fill_S whose wait expired is repeated by stb_fill_status with the
+ * producer/consumer form (no waits between workgroups) before it returns 0; this counts how often
+ * that happened on this thread.  STB_CHAIN_NO_FALLBACK=1 turns the repeat off (status then fails). */
+unsigned stb_fill_fallbacks(void);
+/* 1 when the library carries the superseded fill forms (STB_FILL_SCALED_STEP / _SPLIT / _FUSED /
+ * _CHAINX; `make ABLATION=1`); the default build refuses those variants with a message */
+int stb_has_ablation(void);
 /* release the device buffers the library keeps for reuse between stb_groups_create / samplea calls
  * (capped at STB_POOL_MB, default 4096) */
 void stb_pool_trim(void);

@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
     sig("stb_last_error", C.c_char_p, [])
     sig("stb_device_count", i, [])
     sig("stb_device_name", i, [C.c_char_p, i])
+    sig("stb_set_device", i, [i])
+    sig("stb_get_device", i, [])
+    sig("stb_device_enter", i, [i])
+    sig("stb_device_leave", None, [i])
     sig("stb_device_malloc", vp, [sz])
     sig("stb_device_free", None, [vp])
     sig("stb_host_malloc", vp, [sz])
@@ -93,6 +97,8 @@ def lib() -> C.CDLL:
     sig("stb_fill_S", i, [c_double_p, i, u, u, vp, u64, vp, u64, vp, sz, i, vp])
     sig("stb_fill_tuning", i, [u, u, i, c_int_p, c_int_p, c_int_p])
     sig("stb_fill_status", i, [])
+    sig("stb_fill_fallbacks", C.c_uint, [])
+    sig("stb_has_ablation", i, [])
     sig("stb_fill_profile_begin", None, [])
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
@@ -131,6 +137,14 @@ def lib() -> C.CDLL:
         if hasattr(L, name):
             sig(name, res, args)
     return L
+
+
+ABLATION_VARIANTS = (FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_CHAINX)
+
+
+def has_variant(variant: int) -> bool:
+    """the superseded fill forms are only in `make ABLATION=1` builds of the library"""
+    return variant not in ABLATION_VARIANTS or bool(lib().stb_has_ablation())
 
 
 def last_error() -> str:

@@ -1,0 +1,330 @@
+// abi.hip -- the plain-C plumbing of include/stb_hip.h: error text, device selection, the buffer
+// cache, memory and stream helpers, table layout queries.  No kernels here.
+//
+// No CPU fallback exists in this library: without a device every entry point fails with a message.
+
+#include <mutex>
+#include <vector>
+
+#include "stb_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+
+static thread_local char g_err[512] = "";
+
+int stb_fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+extern "C" const char *stb_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// rand() guard (see stb_common.h)
+
+static std::recursive_mutex g_rand_mu;
+static int g_rand_depth = 0;
+static char g_rand_buf[128];
+static char *g_rand_old = nullptr;
+
+stb_rand_guard::stb_rand_guard() {
+  g_rand_mu.lock();
+  if (g_rand_depth++ == 0) g_rand_old = initstate(0x5eedu, g_rand_buf, sizeof g_rand_buf);
+}
+stb_rand_guard::~stb_rand_guard() {
+  if (--g_rand_depth == 0 && g_rand_old) setstate(g_rand_old);
+  g_rand_mu.unlock();
+}
+
+// ------------------------------------------------------------------------------------------------
+// devices.  A thread picks the GPU for the objects it creates with stb_set_device() (or the process
+// does with STB_DEVICE=k); otherwise the HIP runtime's current device is used, which is what a
+// torch caller has already set.  Tables and group sets remember their device and switch to it for
+// the duration of every later call (stb_device_enter / stb_device_leave).
+
+static thread_local int g_dev_choice = -1;
+
+extern "C" int stb_device_count(void) {
+  STB_ENTRY;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int stb_set_device(int dev) {
+  STB_ENTRY;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  if (dev < 0 || dev >= n) return stb_fail("stb_set_device: device %d of %d", dev, n);
+  HIPCHK(hipSetDevice(dev));
+  g_dev_choice = dev;
+  return 0;
+}
+
+extern "C" int stb_get_device(void) {
+  STB_ENTRY;
+  if (g_dev_choice >= 0) return g_dev_choice;
+  const char *s = getenv("STB_DEVICE");
+  if (s && *s) return atoi(s);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return dev;
+}
+
+int stb_use_device(void) {
+  const int want = stb_get_device();
+  int cur = -1;
+  if (want < 0 || hipGetDevice(&cur) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (cur != want && hipSetDevice(want) != hipSuccess) {
+    stb_fail("device %d cannot be selected: %s", want, hipGetErrorString(hipGetLastError()));
+    return -1;
+  }
+  return want;
+}
+
+extern "C" int stb_device_enter(int dev) {
+  STB_ENTRY;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (dev >= 0 && dev != cur) {
+    if (hipSetDevice(dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    return cur;
+  }
+  return -1;  // nothing to undo
+}
+
+extern "C" void stb_device_leave(int prev) {
+  STB_ENTRY;
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+extern "C" int stb_device_name(char *buf, int len) {
+  STB_ENTRY;
+  hipDeviceProp_t p;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A small cache of device (and pinned host) buffers.  samplea builds and frees a group set (a dozen
+// buffers, 70 MB at 10^6 pairs) on every call, as the reference builds and frees its table
+// (lib/samplea.c:57-60,223); hipMalloc / hipFree cost ~1 ms each way there.  Freed buffers are kept
+// (device memory up to STB_POOL_MB, default 4096; pinned host memory up to STB_POOL_HOST_MB,
+// default 1024) and handed out again to requests of about the same size on the same device.
+// Callers return a buffer only after the work that used it has completed.
+struct pool_block {
+  void *p;
+  size_t bytes;
+  int dev;
+  int kind;  // 0: device memory, 1: pinned host memory
+  bool used;
+};
+static std::mutex g_pool_mu;
+static std::vector<pool_block> g_pool;
+static size_t g_pool_idle[2] = {0, 0};
+
+static hipError_t pool_raw_alloc(void **p, size_t bytes, int kind) {
+  return kind ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+}
+static void pool_raw_free(void *p, int kind) {
+  if (kind) (void)hipHostFree(p);
+  else (void)hipFree(p);
+}
+
+hipError_t stb_pool_malloc(void **out, size_t bytes, int kind) {
+  if (bytes == 0) bytes = 1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++) {
+      const pool_block &b = g_pool[i];
+      if (!b.used && b.dev == dev && b.kind == kind && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+          (best < 0 || b.bytes < g_pool[best].bytes))
+        best = (int)i;
+    }
+    if (best >= 0) {
+      g_pool[best].used = true;
+      g_pool_idle[kind] -= g_pool[best].bytes;
+      *out = g_pool[best].p;
+      return hipSuccess;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = pool_raw_alloc(&p, bytes, kind);
+  if (e != hipSuccess) {
+    // out of memory: give the idle buffers back and try once more
+    std::vector<pool_block> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      for (size_t i = 0; i < g_pool.size();) {
+        if (!g_pool[i].used) {
+          drop.push_back(g_pool[i]);
+          g_pool_idle[g_pool[i].kind] -= g_pool[i].bytes;
+          g_pool.erase(g_pool.begin() + i);
+        } else {
+          i++;
+        }
+      }
+    }
+    for (const pool_block &q : drop) pool_raw_free(q.p, q.kind);
+    (void)hipGetLastError();
+    e = pool_raw_alloc(&p, bytes, kind);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back(pool_block{p, bytes, dev, kind, true});
+  *out = p;
+  return hipSuccess;
+}
+
+bool stb_pool_free(void *p) {
+  if (!p) return true;
+  static const size_t cap[2] = {(size_t)stb_env_int("STB_POOL_MB", 4096) << 20,
+                                (size_t)stb_env_int("STB_POOL_HOST_MB", 1024) << 20};
+  int release = -1;  // kind to release with, -1: kept or unknown
+  bool known = false;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) {
+      if (g_pool[i].p == p) {
+        known = true;
+        const int kind = g_pool[i].kind;
+        if (g_pool_idle[kind] + g_pool[i].bytes <= cap[kind]) {
+          g_pool[i].used = false;
+          g_pool_idle[kind] += g_pool[i].bytes;
+        } else {
+          release = kind;
+          g_pool.erase(g_pool.begin() + i);
+        }
+        break;
+      }
+    }
+  }
+  if (release >= 0) pool_raw_free(p, release);
+  return known;
+}
+
+extern "C" void stb_pool_trim(void) {
+  STB_ENTRY;
+  std::vector<pool_block> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size();) {
+      if (!g_pool[i].used) {
+        drop.push_back(g_pool[i]);
+        g_pool.erase(g_pool.begin() + i);
+      } else {
+        i++;
+      }
+    }
+    g_pool_idle[0] = g_pool_idle[1] = 0;
+  }
+  for (const pool_block &q : drop) pool_raw_free(q.p, q.kind);
+}
+
+extern "C" void *stb_device_malloc(size_t bytes) {
+  STB_ENTRY;
+  void *p = nullptr;
+  hipError_t e = stb_pool_malloc(&p, bytes ? bytes : 1, 0);
+  if (e != hipSuccess) {
+    stb_fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void stb_device_free(void *p) {
+  STB_ENTRY;
+  if (p && !stb_pool_free(p)) (void)hipFree(p);
+}
+extern "C" void *stb_host_malloc(size_t bytes) {
+  STB_ENTRY;
+  void *p = nullptr;
+  hipError_t e = stb_pool_malloc(&p, bytes ? bytes : 1, 1);
+  if (e != hipSuccess) {
+    stb_fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void stb_host_free(void *p) {
+  STB_ENTRY;
+  if (p && !stb_pool_free(p)) (void)hipHostFree(p);
+}
+extern "C" int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+  STB_ENTRY;
+  HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int stb_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+  STB_ENTRY;
+  HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int stb_stream_sync(void *stream) {
+  STB_ENTRY;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+extern "C" uint64_t stb_cells(unsigned N, unsigned M) { return stb_table_cells(N, M); }
+extern "C" uint64_t stb_elems(unsigned N, unsigned M) { return stb_table_elems(N, M); }
+extern "C" uint64_t stb_rowoff(unsigned n, unsigned M) { return stb_row_offset(n, M); }
+extern "C" uint64_t stb_vcells(unsigned N, unsigned M) { return stb_vtable_cells(N, M); }
+extern "C" uint64_t stb_velems(unsigned N, unsigned M) { return stb_vtable_elems(N, M); }
+extern "C" uint64_t stb_vrowoff(unsigned n, unsigned M) { return stb_vrow_offset(n, M); }
+
+// ------------------------------------------------------------------------------------------------
+// the table of the stored log: {1/c, -log(1/c)} for c = 1 + (i + 1/2)/128, one copy per device
+
+int stb_logtab(const double2 **out) {
+  static std::mutex mu;
+  static double2 *tab[64] = {nullptr};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return stb_fail("device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tab[dev]) {
+    double2 h[128];
+    for (int i = 0; i < 128; i++) {
+      const long double c = 1.0L + ((long double)i + 0.5L) / 128.0L;
+      const double invc = (double)(1.0L / c);
+      h[i].x = invc;
+      h[i].y = (double)(-logl((long double)invc));
+    }
+    double2 *d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(h)));
+    HIPCHK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+    tab[dev] = d;
+  }
+  *out = tab[dev];
+  return 0;
+}

@@ -1,0 +1,317 @@
+// fill.hip -- stb_fill_S / stb_fill_V: the device form of S_make / S_remake's table fill
+// (reference lib/stable.c:321-388 for S, :451-482 for V).  Chooses the kernel form, lays out the
+// workspace, keeps the status of the last chain-form fill and the optional per-launch timing.
+//
+// Forms (kernels in their own translation units):
+//   chain   k_fill_chain / k_fillv_chain   one launch per fill (default while D*M <= STB_CHAIN_MAX_COLS)
+//   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of the chain)
+//   rows    k_fill_rows                    the reference's own operation order (STB_FILL_LOGDOMAIN)
+//   + the superseded forms of ablation.hip in `make ABLATION=1` builds
+
+#include "stb_common.h"
+
+static unsigned frontier_pitch(unsigned M) { return (unsigned)stb_align_up((size_t)M + 2, 64); }
+
+// A cell grows per row by U^n_m = n - m a + S^n_{m-1}/S^n_m, and the last term reaches n(n-1)/2
+// next to the diagonal, so the bound is N^2 per row, not N.  Significands start a period at 2^-700
+// and may use 1450 bits.
+int stb_period_rows(unsigned N) {
+  int bits = 1;
+  while ((1ull << bits) < (unsigned long long)N) bits++;
+  const int p = 1450 / (2 * bits + 1);
+  return p < 1 ? 1 : p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-launch timing: when armed, every fill kernel is launched with a begin/end event pair
+// (hipExtLaunchKernelGGL stamps them with the dispatch's own start/stop, i.e. what a kernel trace
+// reports), so a caller can obtain the kernel-only time of a fill without a profiler attached.
+struct fill_prof {
+  bool armed = false;
+  int used = 0;
+  hipEvent_t ev[2 * 4096];
+  int made = 0;
+};
+static thread_local fill_prof g_prof;
+
+void stb_prof_events(hipEvent_t *e0, hipEvent_t *e1) {
+  *e0 = *e1 = nullptr;
+  if (!g_prof.armed || g_prof.used + 2 > 2 * 4096) return;
+  while (g_prof.made < g_prof.used + 2) {
+    if (hipEventCreate(&g_prof.ev[g_prof.made]) != hipSuccess) return;
+    g_prof.made++;
+  }
+  *e0 = g_prof.ev[g_prof.used];
+  *e1 = g_prof.ev[g_prof.used + 1];
+  g_prof.used += 2;
+}
+
+extern "C" void stb_fill_profile_begin(void) {
+  g_prof.armed = true;
+  g_prof.used = 0;
+}
+
+extern "C" int stb_fill_profile_end(double *kernel_ms_total, int *launches) {
+  STB_ENTRY;
+  // caller must have synchronised the stream(s) the fills ran on
+  g_prof.armed = false;
+  double tot = 0.0;
+  const int n = g_prof.used / 2;
+  for (int i = 0; i < n; i++) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (kernel_ms_total) *kernel_ms_total = tot;
+  if (launches) *launches = n;
+  g_prof.used = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+
+static size_t ws_head(unsigned M, int D) {  // discounts + frontier
+  const size_t W = frontier_pitch(M);
+  return stb_align_up((size_t)D * sizeof(double), 256) + stb_align_up((size_t)D * 2 * W * (sizeof(double) + sizeof(int)), 256);
+}
+
+static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
+  size_t form = stb_chain_workspace(N, M, D);
+  if (stb_ablation_workspace) {
+    const size_t ab = stb_ablation_workspace(N, M, D);
+    if (ab > form) form = ab;
+  }
+  return ws_head(M, D) + form + 512;
+}
+
+// enough for D tables and for any smaller batch run in the same workspace
+extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
+  size_t need = fill_workspace_need(N, M, D);
+  for (int d2 = 1; d2 < D && d2 <= 4096; d2++) {  // (the block shape, hence the edge streams, depends on the batch)
+    const size_t n2 = fill_workspace_need(N, M, d2);
+    if (n2 > need) need = n2;
+  }
+  return need;
+}
+
+// ------------------------------------------------------------------------------------------------
+// choice of form
+
+extern "C" int stb_default_variant(void) {
+  const int v = stb_env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
+  return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
+          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX)
+             ? v
+             : STB_FILL_SCALED;
+}
+
+extern "C" int stb_has_ablation(void) { return stb_ablation_fill != nullptr; }
+
+// STB_FILL_SCALED picks the form by how many table columns are in flight: the chain form (one
+// launch, no halo) up to STB_CHAIN_MAX_COLS columns over all tables, the producer/consumer form
+// beyond.
+static bool chain_wins(unsigned N, unsigned M, int D) {
+  const uint64_t cap = (uint64_t)stb_env_int("STB_CHAIN_MAX_COLS", 200000);
+  return (uint64_t)D * M <= cap && N >= 3 && N < (1u << 27);
+}
+
+enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION };
+
+static int pick_form(int variant, unsigned N, unsigned M, int D) {
+  switch (variant) {
+    case STB_FILL_LOGDOMAIN: return FORM_ROWS_LOG;
+    case STB_FILL_PC: return (N < (1u << 27)) ? FORM_PC : FORM_ROWS_LOG;
+    case STB_FILL_CHAIN: return (N >= 3 && N < (1u << 27)) ? FORM_CHAIN : (N < 3 ? FORM_PC : FORM_ROWS_LOG);
+    case STB_FILL_CHAINX:  // (its converter blocks need a compute unit per 64-column chunk)
+      if (D > 2) return pick_form(STB_FILL_CHAIN, N, M, D);
+      return (N >= 3 && N < (1u << 27)) ? FORM_ABLATION : pick_form(STB_FILL_CHAIN, N, M, D);
+    case STB_FILL_SCALED_STEP:
+    case STB_FILL_SPLIT:
+    case STB_FILL_FUSED: return FORM_ABLATION;
+    default:
+      // the block-floating forms bound the scale between lanes for N < 2^27 (see k_fill_pc)
+      if (N >= (1u << 27)) return FORM_ROWS_LOG;
+      return chain_wins(N, M, D) ? FORM_CHAIN : FORM_PC;
+  }
+}
+
+extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches) {
+  const int form = pick_form(stb_default_variant(), N, M, D);
+  if (form == FORM_CHAIN) {
+    int P = 0;
+    stb_chain_tuning(N, M, D, &P);
+    if (C_out) *C_out = P;
+    if (R_out) *R_out = (int)N;
+    if (launches) *launches = 1;
+    return 3;
+  }
+  int C = (form == FORM_PC) ? 4 : stb_env_int("STB_FILL_C", 2);
+  int R = stb_env_int("STB_FILL_R", form == FORM_PC ? 128 : 64);
+  if (form == FORM_PC && R > 128) R = 128;
+  if (R < 1) R = 1;
+  if (C_out) *C_out = C;
+  if (R_out) *R_out = R;
+  if (launches) *launches = ((int)N - 1 + R - 1) / R;
+  return form == FORM_PC ? 2 : 5; /* 2 producer/consumer (k_fill_pc), 3 chain, 5 another form */
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fill
+
+// what the last fill of this thread was, so that stb_fill_status can wait for it, report a chain
+// form that gave up, and repeat the fill with the producer/consumer form
+struct last_fill {
+  unsigned *hdr = nullptr;  // chain header (ticket, error code, error detail), or null
+  fill_args A;
+  int D = 0;
+  bool s_table = false, can_fall_back = false;
+  hipStream_t st = nullptr;
+};
+static thread_local last_fill g_last;
+static thread_local unsigned g_fallbacks = 0;
+static thread_local const dot_request *g_dot_req = nullptr;
+
+void stb_set_dot_request(const dot_request *r) { g_dot_req = r; }
+
+extern "C" unsigned stb_fill_fallbacks(void) { return g_fallbacks; }
+
+static void pc_geometry(fill_args &A) {
+  const int ncw = stb_env_int("STB_PC_CONSUMERS", 2) == 3 ? 3 : 2;
+  A.H = 256 - 64 * ncw;
+  A.R = stb_env_int("STB_FILL_R", A.H);
+  if (A.R > A.H) A.R = A.H;
+  if (A.R < 1) A.R = 1;
+  A.Wv = 256 - A.H;
+}
+
+extern "C" int stb_fill_status(void) {
+  STB_ENTRY;
+  if (!g_last.hdr) return 0;
+  unsigned h[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(h, g_last.hdr, sizeof(h), hipMemcpyDeviceToHost));  // waits for the fill
+  if (h[1] == 0) return 0;
+  stb_fail("%s: chain fill gave up waiting for a neighbour block (code 0x%x, block %u of table %u)",
+           g_last.s_table ? "stb_fill_S" : "stb_fill_V", h[1], h[2] & 0xffffu, h[2] >> 16);
+  if (!g_last.can_fall_back || stb_env_int("STB_CHAIN_NO_FALLBACK", 0)) {
+    g_last.hdr = nullptr;
+    return 1;
+  }
+  // the same tables once more with the form that has no waits between workgroups
+  g_last.hdr = nullptr;
+  g_fallbacks++;
+  fill_args A = g_last.A;
+  pc_geometry(A);
+  if (stb_launch_pc(A, g_last.D, g_last.st)) return 1;
+  HIPCHK(hipStreamSynchronize(g_last.st));
+  return 0;
+}
+
+static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables, uint64_t table_stride,
+                       double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, int variant, bool vtable,
+                       hipStream_t st) {
+  const char *who = vtable ? "stb_fill_V" : "stb_fill_S";
+  g_last.hdr = nullptr;  // whatever this thread filled before is no longer "the last fill"
+  if (D < 1) return stb_fail("%s: D=%d", who, D);
+  if (N < 2 || M < 2) return stb_fail("%s: bounds N=%u M=%u too small", who, N, M);
+  if (!a_host || !d_tables || !d_ws || (!vtable && !d_S1)) return stb_fail("%s: null pointer", who);
+  if (ws_bytes < fill_workspace_need(N, M, D))
+    return stb_fail("%s: workspace %zu < %zu", who, ws_bytes, fill_workspace_need(N, M, D));
+  const uint64_t need = vtable ? stb_vtable_elems(N, M) : stb_table_elems(N, M);
+  if (D > 1 && (table_stride < need || (!vtable && s1_stride < N))) return stb_fail("%s: strides too small", who);
+  if (D > 1 && (table_stride & 1)) return stb_fail("%s: table stride must be even", who);
+  for (int d = 0; d < D; d++)
+    if (!(a_host[d] >= 0.0 && a_host[d] < 1.0)) return stb_fail("%s: discount %g outside [0,1)", who, a_host[d]);
+
+  fill_args A;
+  memset(&A, 0, sizeof(A));
+  char *ws = (char *)d_ws;
+  A.a = (const double *)ws;
+  ws += stb_align_up((size_t)D * sizeof(double), 256);
+  A.W = frontier_pitch(M);
+  A.fm = (double *)ws;
+  A.fe = (int *)(ws + (size_t)D * 2 * A.W * sizeof(double));
+  ws = (char *)d_ws + ws_head(M, D);
+  const size_t ws_left = ws_bytes - ws_head(M, D);
+  A.tables = d_tables;
+  A.tstride = table_stride;
+  A.S1 = d_S1;
+  A.s1stride = s1_stride;
+  A.N = N;
+  A.M = M;
+  if (stb_logtab(&A.lt)) return 1;
+  HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+
+  if (vtable) {
+    if (stb_env_int("STB_FILLV_CHAIN", 1)) {
+      unsigned *hdr = nullptr;
+      if (stb_launch_vchain(A, D, ws, ws_left, &hdr, st)) return 1;
+      g_last.hdr = hdr;
+      g_last.s_table = false;
+      g_last.can_fall_back = false;
+      return 0;
+    }
+    const int C = 2;
+    A.R = stb_env_int("STB_FILL_R", 48);
+    if (A.R < 1) A.R = 1;
+    if (A.R > 126) A.R = 126;
+    A.H = (A.R + C - 1) / C * C;
+    A.Wv = 64 * C - A.H;
+    return stb_launch_rows(A, D, C, STB_ROWS_VRATIO, st);
+  }
+
+  const int form = pick_form(variant, N, M, D);
+  if (g_dot_req && form != FORM_CHAIN) return stb_fail("%s: the fused evaluation needs the chain form", who);
+  switch (form) {
+    case FORM_CHAIN: {
+      unsigned *hdr = nullptr;
+      if (stb_launch_chain(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
+      g_last.hdr = hdr;
+      g_last.A = A;
+      g_last.D = D;
+      g_last.st = st;
+      g_last.s_table = true;
+      g_last.can_fall_back = (g_dot_req == nullptr);
+      return 0;
+    }
+    case FORM_PC:
+      pc_geometry(A);
+      return stb_launch_pc(A, D, st);
+    case FORM_ROWS_LOG: {
+      const bool few = (uint64_t)D * M < 40000;
+      int C = stb_env_int("STB_FILL_C", few ? 1 : 2);
+      if (C != 1 && C != 2 && C != 4) return stb_fail("STB_FILL_C must be 1, 2 or 4");
+      A.R = stb_env_int("STB_FILL_R", few ? 48 : 64);
+      if (A.R < 1) A.R = 1;
+      A.H = (A.R + C - 1) / C * C;
+      if (A.H > 64 * C - C) return stb_fail("STB_FILL_R=%d too large for C=%d", A.R, C);
+      A.Wv = 64 * C - A.H;
+      return stb_launch_rows(A, D, C, STB_ROWS_LOGDOM, st);
+    }
+    default: {
+      if (!stb_ablation_fill)
+        return stb_fail("%s: fill variant %d is one of the superseded forms, which this build does not carry "
+                        "(make -C libstb_amd/csrc ABLATION=1)", who, variant);
+      unsigned *hdr = nullptr;
+      if (stb_ablation_fill(A, D, variant, ws, ws_left, &hdr, st)) return 1;
+      g_last.hdr = hdr;
+      g_last.s_table = true;
+      g_last.can_fall_back = false;
+      return 0;
+    }
+  }
+}
+
+extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables, uint64_t table_stride,
+                          double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, int variant, void *stream) {
+  STB_ENTRY;
+  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, variant, false,
+                     (hipStream_t)stream);
+}
+
+extern "C" int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables, uint64_t vtable_stride,
+                          void *d_ws, size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  return fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes, STB_FILL_SCALED, true,
+                     (hipStream_t)stream);
+}

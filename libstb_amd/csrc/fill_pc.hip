@@ -1,0 +1,263 @@
+// fill_pc.hip -- k_fill_pc, the producer/consumer fill launched per 128 rows, and k_s1.
+//
+// Replaces the table part of S_remake_part (reference lib/stable.c:321-388) when many tables are
+// in flight, and is the fallback when a chain-form fill reports that a block gave up waiting: this
+// form has no waits between workgroups at all (the kernel boundary publishes the frontier).
+
+#include "stb_common.h"
+
+// ---- producer/consumer form of the block-floating fill ---------------------------------------
+//
+// One workgroup = one column block of 256 columns = 1 producer wave + NCW consumer waves.
+//  * The producer (wave 0) carries ONLY the recurrence, four columns per lane, and hands the raw
+//    significands of its owned columns (the right-most 64*NCW; the rest is halo) to LDS.
+//  * Each consumer wave turns 64 of them per row into logs and stores them -- 512 contiguous bytes
+//    per row and wave -- so the log work (17 of ~25 instructions per cell) is spread over NCW other
+//    SIMDs of the same CU, costs nothing on halo columns, and the table still moves 8 B per cell.
+// Producer and consumers run PC_U rows apart through a two-slot LDS ring, one barrier per PC_U rows;
+// the PC_U logs a consumer lane owns per trip are evaluated stage-major for ILP.
+// log S^n_1 (the S1 vector) is not produced here: k_s1 evaluates lgamma(n-a) - lgamma(1-a).
+#define PC_U 8
+
+template <int NCW>
+__global__ __launch_bounds__(64 * (1 + NCW)) void k_fill_pc(fill_args A, int k, int P) {
+  constexpr int C = 4;
+  constexpr int OW = 64 * NCW;      // owned (stored) columns per block
+  constexpr int H = 256 - OW;       // halo columns recomputed per block
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(32))) double vbuf[2][PC_U][OW];
+  __shared__ int ebuf[2][OW];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 128) lt[tid] = A.lt[tid];
+
+  const int j = blockIdx.x;
+  const int d = blockIdx.y;
+  const unsigned N = A.N, M = A.M;
+  const int n0 = 2 + k * A.R;
+  const int n1 = min((int)N, n0 + A.R - 1);
+  const int nf = n0 - 1;
+  const int cmin = 2 + j * OW - H;  // first column of the block (halo included)
+  double *table = A.tables + (uint64_t)d * A.tstride;
+
+  // ---- producer state: four columns per lane sharing ONE exponent, so that inside a lane the
+  // left-neighbour term needs no rescaling (value of cell i = v[i] * 2^ep) ----
+  double v[C], ca[C], s = 1.0;
+  int ep = 1 + PC_BIAS;
+  const int c0 = cmin + lane * C;
+  const bool owned = lane * C >= H;
+  if (wave == 0) {
+    const double a = A.a[d];
+    const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+    const double *fm_in = A.fm + fbase + (uint64_t)(k & 1) * A.W;
+    const int *fe_in = A.fe + fbase + (uint64_t)(k & 1) * A.W;
+    const int cmax_f = min(nf, (int)M);
+    double m[C];
+    int e[C], E = STB_EZ;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      m[i] = 0.0;
+      e[i] = STB_EZ;
+      if (k == 0) {
+        if (c == 1) {
+          m[i] = 0.5;
+          e[i] = 1;
+        }
+      } else if (c >= 1 && c <= cmax_f) {
+        m[i] = fm_in[c];
+        e[i] = fe_in[c];
+      }
+      if (m[i] != 0.0) E = max(E, e[i]);
+      ca[i] = (double)c * a;
+    }
+    if (E == STB_EZ) E = 1;  // an all-zero lane: exponent of the 1 the diagonal will bring
+#pragma unroll
+    for (int i = 0; i < C; i++) v[i] = (m[i] != 0.0) ? ldexp(m[i], max(e[i] - E, -1000) - PC_BIAS) : 0.0;
+    ep = E + PC_BIAS;
+  }
+  // ---- consumer state ----
+  const int ridx = (wave - 1) * 64 + lane;     // my slot in vbuf / ebuf (consumers only)
+  const int cc = 2 + j * OW + ridx;            // my column
+
+  int pidx = 0;
+  for (int nb = n0; nb <= n1; nb += P, pidx++) {
+    const int ne = min(n1, nb + P - 1);
+    const int ns = max(nb, max(cmin, 3));  // rows above the block's first column are all zero
+    if (wave == 0) {
+      // period set-up: freeze the scale of the cross-lane input, s = 2^(ep_left - ep).  Adjacent
+      // lanes (4 columns apart) differ by at most (N^2)^4, i.e. 8 log2 N <= 216 bits for N < 2^27,
+      // and v_left <= 2^(-700 + 1450), so v_left * s stays below 2^970: no exponent adoption needed.
+      const int epl = wave_shr1(ep, ep);
+      s = ldexp(1.0, min(max(epl - ep, -1100), 220));
+      if (owned) {
+#pragma unroll
+        for (int i = 0; i < C; i++) ebuf[pidx & 1][lane * C - H + i] = ep;
+      }
+      if (nb == 2 && cmin < 3) {  // row 2 (nothing is stored for it)
+        const double t0 = wave_shr1_zero(v[3]) * s;
+        v[3] = fma(1.0 - ca[3], v[3], v[2]);
+        v[2] = fma(1.0 - ca[2], v[2], v[1]);
+        v[1] = fma(1.0 - ca[1], v[1], v[0]);
+        v[0] = fma(1.0 - ca[0], v[0], t0);
+      }
+    }
+    __syncthreads();  // exponents (and, first time, the log table) visible to the consumers
+    int myep = 0;
+    if (wave > 0) myep = ebuf[pidx & 1][ridx];
+
+    if (ns <= ne) {
+      double coef[C];
+      if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < C; i++) coef[i] = (double)(ns - 1) - ca[i];
+      }
+      // consumers address row r as rowbase(r)[coff]: a wave-uniform row base advanced by the row
+      // pitch, plus a per-lane constant column offset
+      double *rowbase = table + stb_row_offset((unsigned)ns, M);
+      const int coff = cc - 2;
+      const int trips = (ne - ns + 1 + PC_U - 1) / PC_U;
+      // trip q: the producer computes rows ns+U*q.., the consumers emit the rows of trip q-1
+      for (int q = 0; q <= trips; q++) {
+        if (wave == 0) {
+          if (q < trips) {
+            const int r0 = ns + q * PC_U;
+            const int cnt = min(PC_U, ne - r0 + 1);
+            for (int u = 0; u < cnt; u++) {
+              const double t0 = wave_shr1_zero(v[3]) * s;
+              v[3] = fma(coef[3], v[3], v[2]);
+              v[2] = fma(coef[2], v[2], v[1]);
+              v[1] = fma(coef[1], v[1], v[0]);
+              v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+              for (int i = 0; i < C; i++) coef[i] += 1.0;
+              if (owned) {
+                double2 *dst = reinterpret_cast<double2 *>(&vbuf[q & 1][u][lane * C - H]);
+                dst[0] = make_double2(v[0], v[1]);
+                dst[1] = make_double2(v[2], v[3]);
+              }
+            }
+          }
+        } else if (q > 0) {
+          const int r0 = ns + (q - 1) * PC_U;
+          const int cnt = min(PC_U, ne - r0 + 1);
+          if (cnt == PC_U) {
+            // U rows of my column, stage-major
+            double x[PC_U], z[PC_U], kf[PC_U], r[PC_U], pl[PC_U];
+            double2 t[PC_U];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) x[u] = vbuf[(q - 1) & 1][u][ridx];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) {
+              const int hi = __double2hiint(x[u]);
+              z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+              kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+            }
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) r[u] = fma(z[u], t[u].x, -1.0);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0);
+            const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+            if (stb_row_pitch((unsigned)(r0 + PC_U - 1), M) == pitch) {
+#pragma unroll
+              for (int u = 0; u < PC_U; u++)
+                rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+              rowbase += (size_t)PC_U * pitch;
+            } else {
+#pragma unroll
+              for (int u = 0; u < PC_U; u++) {
+                rowbase[coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                rowbase += stb_row_pitch((unsigned)(r0 + u), M);
+              }
+            }
+          } else {
+            for (int u = 0; u < cnt; u++) {
+              rowbase[coff] = bfp_log(vbuf[(q - 1) & 1][u][ridx], myep, lt);
+              rowbase += stb_row_pitch((unsigned)(r0 + u), M);
+            }
+          }
+        }
+        lds_barrier();
+      }
+    }
+    if (wave == 0) {
+      // renormalise the lane: the largest of the four significands back to 2^-PC_BIAS * [0.5,1)
+      int kmax = -4000;
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+      if (kmax > -4000) {
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+        ep += kmax + PC_BIAS;
+      }
+    }
+  }
+
+  if (wave == 0 && n1 < (int)N) {
+    const uint64_t fbase = ((uint64_t)d * 2) * A.W;
+    double *fm_out = A.fm + fbase + (uint64_t)((k + 1) & 1) * A.W;
+    int *fe_out = A.fe + fbase + (uint64_t)((k + 1) & 1) * A.W;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = c0 + i;
+      const bool mine = owned || (j == 0 && c == 1);
+      if (mine && c >= 1 && c <= (int)M) {
+        fm_out[c] = __builtin_amdgcn_frexp_mant(v[i]);
+        fe_out[c] = (v[i] != 0.0) ? ep + __builtin_amdgcn_frexp_exp(v[i]) : STB_EZ;
+      }
+    }
+  }
+}
+
+// S1[n-1] = log S^n_1 = log Gamma(n-a)/Gamma(1-a) for n = 1..N, all tables
+__global__ __launch_bounds__(256) void k_s1(const double *a, double *S1, uint64_t s1stride, unsigned N) {
+  const int d = blockIdx.y;
+  const double ad = a[d];
+  const double lg1 = lgamma(1.0 - ad);
+  for (unsigned n = 1 + blockIdx.x * blockDim.x + threadIdx.x; n <= N; n += gridDim.x * blockDim.x)
+    S1[(uint64_t)d * s1stride + n - 1] = (n == 1) ? 0.0 : lgamma((double)n - ad) - lg1;
+}
+
+int stb_launch_s1(const fill_args &A, int D, hipStream_t st) {
+  const unsigned nb = (A.N + 255) / 256 < 64 ? (A.N + 255) / 256 : 64;
+  hipLaunchKernelGGL(k_s1, dim3(nb, D), dim3(256), 0, st, A.a, A.S1, A.s1stride, A.N);
+  return 0;
+}
+
+// rows 2..N in launches of A.R rows; A.H = 256 - 64 * consumers; A.R <= A.H
+int stb_launch_pc(fill_args &A, int D, hipStream_t st) {
+  const int N = (int)A.N, M = (int)A.M, R = A.R;
+  const int ncw = (256 - A.H) / 64;
+  const int OW = 64 * ncw;
+  const int P = [&] {  // equal-length renormalisation periods inside a launch
+    int p = stb_period_rows(A.N);
+    const int penv = stb_env_int("STB_FILL_P", 0);
+    if (penv > 0 && penv < p) p = penv;
+    if (p >= R) return R;
+    const int per = (R + p - 1) / p;
+    return (R + per - 1) / per;
+  }();
+  stb_launch_s1(A, D, st);
+  const int nlaunch = (N - 1 + R - 1) / R;
+  for (int k = 0; k < nlaunch; k++) {
+    int n1 = 2 + (k + 1) * R - 1;
+    if (n1 > N) n1 = N;
+    int ncols = (n1 < M ? n1 : M) - 1;
+    if (ncols < 1) ncols = 1;
+    const dim3 grid((ncols + OW - 1) / OW, D);
+    if (ncw == 3)
+      STB_LAUNCH((k_fill_pc<3>), grid, dim3(256), st, A, k, P);
+    else
+      STB_LAUNCH((k_fill_pc<2>), grid, dim3(192), st, A, k, P);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,546 @@
+// groups.hip -- stb_groups_*: the (n,t) pairs and per-restaurant totals of one samplea call resident
+// in HBM, and aterms (reference lib/samplea.c:46-83) evaluated on them for one discount or a grid.
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+
+#include "stb_common.h"
+
+#define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
+
+// ------------------------------------------------------------------------------------------------
+// device-resident group set
+
+struct stb_groups {
+  int dev;  // the device everything below lives on
+  int I;
+  uint64_t G;
+  unsigned N, M;
+  int Dmax;
+  uint32_t *d_n, *d_T;
+  uint16_t *d_t;
+  double *d_bpar;
+  double *d_tables, *d_S1, *d_out;  // d_out: [2][Dmax]
+  uint64_t tstride;
+  void *d_ws_fill, *d_ws_sweep, *d_ws_terms;
+  size_t ws_fill, ws_sweep, ws_terms;
+  hipStream_t st;
+  hipEvent_t ev[4];
+  // fused evaluation (stb_groups_aterms with the chain form): occurrence count per table cell, the
+  // pairs that do not address a table cell (t = 1, t = n, out of bounds), partial sums of the fill
+  unsigned *d_cnt;
+  uint32_t *d_n2;
+  uint16_t *d_t2;
+  uint64_t G2;
+  double *d_dotp;
+  size_t dotp_elems;
+  int fused, fused_ready;
+  // sparse form of the fused evaluation: CSR of the occurring cells per (trip, slice) item
+  unsigned *d_item_ptr;
+  unsigned short *d_ent_pos;
+  unsigned *d_ent_cnt;
+  unsigned nsg;
+  int sparse;
+};
+
+// The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
+// random 8-byte gather moves a whole 64-byte sector.  Sorting the pairs once by (n,t) (they are reused
+// for every evaluation of a samplea call and for all D tables of a grid) makes neighbouring threads
+// read neighbouring addresses.  The sum is order-independent up to rounding and stays deterministic.
+__global__ void k_pack_pairs(const uint32_t *n, const uint16_t *t, uint64_t G, uint64_t *key) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) key[g] = ((uint64_t)n[g] << 16) | t[g];
+}
+__global__ void k_unpack_pairs(const uint64_t *key, uint64_t G, uint32_t *n, uint16_t *t) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) {
+    n[g] = (uint32_t)(key[g] >> 16);
+    t[g] = (uint16_t)(key[g] & 0xffff);
+  }
+}
+
+static int sort_pairs(uint32_t *d_n, uint16_t *d_t, uint64_t G, hipStream_t st) {
+  if (G < 2) return 0;
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = 1;
+  do {
+    if (stb_pool_malloc((void **)&k0, sizeof(uint64_t) * G) != hipSuccess || stb_pool_malloc((void **)&k1, sizeof(uint64_t) * G) != hipSuccess) {
+      stb_fail("sort_pairs: out of device memory");
+      break;
+    }
+    const unsigned blocks = (unsigned)((G + 255) / 256);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(blocks), dim3(256), 0, st, d_n, d_t, G, k0);
+    if (rocprim::radix_sort_keys(nullptr, tmp_bytes, k0, k1, (size_t)G, 0, 48, st) != hipSuccess) {
+      stb_fail("sort_pairs: radix_sort_keys (size query) failed");
+      break;
+    }
+    if (stb_pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
+      stb_fail("sort_pairs: out of device memory");
+      break;
+    }
+    if (rocprim::radix_sort_keys(tmp, tmp_bytes, k0, k1, (size_t)G, 0, 48, st) != hipSuccess) {
+      stb_fail("sort_pairs: radix_sort_keys failed");
+      break;
+    }
+    hipLaunchKernelGGL(k_unpack_pairs, dim3(blocks), dim3(256), 0, st, k1, G, d_n, d_t);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+      stb_fail("sort_pairs: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    rc = 0;
+  } while (0);
+  // (the stream was synchronised above, or nothing was launched on these buffers)
+  if (rc != 0) (void)hipStreamSynchronize(st);
+  stb_pool_free(k0);
+  stb_pool_free(k1);
+  stb_pool_free(tmp);
+  return rc;
+}
+
+extern "C" void stb_groups_free(stb_groups_t *g) {
+  STB_ENTRY;
+  if (!g) return;
+  const int prev_dev = stb_device_enter(g->dev);
+  void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
+                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
+                  g->d_item_ptr, g->d_ent_pos, g->d_ent_cnt};
+  if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
+  for (void *p : ptrs) stb_pool_free(p);
+  for (auto &e : g->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (g->st) (void)hipStreamDestroy(g->st);
+  free(g);
+  stb_device_leave(prev_dev);
+}
+
+#define GCHK(expr)                                                                            \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      stb_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);        \
+      stb_groups_free(g);                                                                     \
+      return nullptr;                                                                         \
+    }                                                                                         \
+  } while (0)
+
+// occurrence count of every table cell among the pairs (same classification as k_sweep_partial)
+__global__ void k_count_pairs(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M,
+                              unsigned *cnt) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  if (nn <= 1 || nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) return;
+  atomicAdd(&cnt[stb_row_offset(nn, M) + (tt - 2)], 1u);
+}
+
+// out[d] += sum of the DOT kernel's partial sums of table d, in a fixed order
+__global__ __launch_bounds__(64) void k_dot_reduce(const double *dotp, int parts, double *out) {
+  const int d = blockIdx.x, lane = threadIdx.x;
+  dd_t acc{0.0, 0.0};
+  for (int i = lane; i < parts; i += 64) dd_add(acc, dotp[(size_t)d * parts + i]);
+  // lanes in order, on lane 0
+  dd_t tot{0.0, 0.0};
+  for (int l = 0; l < 64; l++) {
+    const double hi = __shfl(acc.hi, l), lo = __shfl(acc.lo, l);
+    dd_add(tot, hi);
+    dd_add(tot, lo);
+  }
+  if (lane == 0) out[d] += tot.hi + tot.lo;
+}
+
+static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
+                                        const uint16_t *tflat, const double *bpar, unsigned N, unsigned M, int Dmax) {
+  if (stb_device_count() < 1) {
+    stb_fail("stb_groups_create: no HIP device (libstb_amd has no CPU path)");
+    return nullptr;
+  }
+  if (Dmax < 1 || Dmax > STB_TERMS_DMAX) {
+    stb_fail("stb_groups_create: Dmax=%d (1..%d)", Dmax, STB_TERMS_DMAX);
+    return nullptr;
+  }
+  stb_groups_t *g = (stb_groups_t *)calloc(1, sizeof(*g));
+  if (!g) {
+    stb_fail("stb_groups_create: out of host memory");
+    return nullptr;
+  }
+  uint64_t G = 0;
+  for (int i = 0; i < I; i++) G += (uint64_t)(K[i] > 0 ? K[i] : 0);
+  if (hipGetDevice(&g->dev) != hipSuccess) {
+    stb_fail("stb_groups_create: %s", hipGetErrorString(hipGetLastError()));
+    free(g);
+    return nullptr;
+  }
+  g->I = I;
+  g->G = G;
+  g->N = N;
+  g->M = M;
+  g->Dmax = Dmax;
+  g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
+  GCHK(hipStreamCreate(&g->st));
+  for (auto &e : g->ev) GCHK(hipEventCreate(&e));
+  GCHK(stb_pool_malloc((void **)&g->d_n, sizeof(uint32_t) * (G ? G : 1)));
+  GCHK(stb_pool_malloc((void **)&g->d_t, sizeof(uint16_t) * (G ? G : 1)));
+  GCHK(stb_pool_malloc((void **)&g->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)));
+  GCHK(stb_pool_malloc((void **)&g->d_bpar, sizeof(double) * (I > 0 ? I : 1)));
+  GCHK(stb_pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * Dmax));
+  GCHK(stb_pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)N * Dmax));
+  GCHK(stb_pool_malloc((void **)&g->d_out, sizeof(double) * 2 * Dmax));
+  g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
+  g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
+  g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
+  GCHK(stb_pool_malloc((void **)&g->d_ws_fill, g->ws_fill));
+  GCHK(stb_pool_malloc((void **)&g->d_ws_sweep, g->ws_sweep));
+  GCHK(stb_pool_malloc((void **)&g->d_ws_terms, g->ws_terms));
+  if (G) {
+    GCHK(hipMemcpy(g->d_n, nflat, sizeof(uint32_t) * G, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(g->d_t, tflat, sizeof(uint16_t) * G, hipMemcpyHostToDevice));
+  }
+  if (I > 0) {
+    GCHK(hipMemcpy(g->d_T, T, sizeof(uint32_t) * I, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(g->d_bpar, bpar, sizeof(double) * I, hipMemcpyHostToDevice));
+  }
+  if (stb_env_int("STB_SORT_PAIRS", 1) && sort_pairs(g->d_n, g->d_t, G, g->st)) {
+    stb_groups_free(g);
+    return nullptr;
+  }
+  g->fused = stb_env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);  // set up on first use
+  return g;
+}
+
+// The set lives on the device stb_get_device() names (stb_set_device / STB_DEVICE / the runtime's
+// current device); the caller's current device is put back before returning.
+extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
+                                           const uint16_t *tflat, const double *bpar, unsigned N, unsigned M, int Dmax) {
+  STB_ENTRY;
+  const int prev_dev = stb_device_enter(stb_get_device());
+  stb_groups_t *g = groups_create_here(I, K, T, nflat, tflat, bpar, N, M, Dmax);
+  stb_device_leave(prev_dev);
+  return g;
+}
+
+// ---- sparse set-up of the fused evaluation, all on the device -----------------------------------
+#define STB_KEY_OTHER 0xfffffffffffffffeull  // a pair that addresses no table cell (t = 1, t = n, out of bounds)
+#define STB_KEY_SKIP 0xffffffffffffffffull   // n <= 1: contributes nothing (lib/samplea.c:78)
+
+// key of a pair: (item index << 9) | (row in trip << 6) | column in slice, item = trip * nsg + slice
+__global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, unsigned nsg,
+                            uint64_t *key, uint32_t *payload) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  uint64_t k;
+  if (nn <= 1) k = STB_KEY_SKIP;
+  else if (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
+  else {
+    const unsigned trip = (nn - 3) >> 3, u = (nn - 3) & 7, sg = (tt - 1) >> 6, ln = (tt - 1) & 63;
+    k = (((uint64_t)trip * nsg + sg) << 9) | (u << 6) | ln;
+  }
+  key[g] = k;
+  payload[g] = (uint32_t)g;
+}
+
+// counts[0] = keys below STB_KEY_OTHER (table cells), counts[1] = keys equal to it
+__global__ void k_key_bounds(const uint64_t *key, uint64_t G, uint64_t *counts) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint64_t lo = 0, hi = G;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (key[mid] < STB_KEY_OTHER) lo = mid + 1;
+    else hi = mid;
+  }
+  const uint64_t a = lo;
+  hi = G;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (key[mid] <= STB_KEY_OTHER) lo = mid + 1;
+    else hi = mid;
+  }
+  counts[0] = a;
+  counts[1] = lo - a;
+}
+
+__global__ void k_gather_pairs(const uint32_t *n, const uint16_t *t, const uint32_t *idx, uint64_t cnt, uint32_t *n2,
+                               uint16_t *t2) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < cnt) {
+    n2[g] = n[idx[g]];
+    t2[g] = t[idx[g]];
+  }
+}
+
+__global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigned short *pos, unsigned *item) {
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < *runs) {
+    pos[r] = (unsigned short)(ukey[r] & 511u);
+    item[r] = (unsigned)(ukey[r] >> 9);
+  }
+}
+
+// item_ptr[i] = first run whose item index is >= i
+__global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned nitems, unsigned *ptr) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nitems) return;
+  unsigned lo = 0, hi = *runs;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) / 2;
+    if (item[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  ptr[i] = lo;
+}
+
+// Returns 0 and sets g->sparse = 1 when the sparse form was built, 0 with g->sparse = 0 when the
+// pairs are too dense for it to pay (the caller then builds the count slab), non-zero on error.
+static int groups_fused_setup_sparse(stb_groups_t *g) {
+  const unsigned N = g->N, M = g->M;
+  const uint64_t G = g->G;
+  g->sparse = 0;
+  if (G == 0 || G >= 0xffffffffull) return 0;
+  const unsigned nsg = (M + 63) / 64 + 4;
+  const unsigned trips = (N - 2 + 7) / 8;
+  const uint64_t nitems64 = (uint64_t)trips * nsg;
+  if (nitems64 >= (1ull << 31)) return 0;
+  const unsigned nitems = (unsigned)nitems64;
+  uint64_t *k0 = nullptr, *k1 = nullptr, *uk = nullptr, *d_counts = nullptr;
+  uint32_t *p0 = nullptr, *p1 = nullptr;
+  unsigned *cnt = nullptr, *runs = nullptr, *item = nullptr;
+  void *tmp = nullptr;
+  int rc = 1;
+  const unsigned blocks = (unsigned)((G + 255) / 256);
+  do {
+    if (stb_pool_malloc((void **)&k0, 8 * G) != hipSuccess || stb_pool_malloc((void **)&k1, 8 * G) != hipSuccess ||
+        stb_pool_malloc((void **)&p0, 4 * G) != hipSuccess || stb_pool_malloc((void **)&p1, 4 * G) != hipSuccess ||
+        stb_pool_malloc((void **)&uk, 8 * G) != hipSuccess || stb_pool_malloc((void **)&cnt, 4 * G) != hipSuccess ||
+        stb_pool_malloc((void **)&item, 4 * G) != hipSuccess || stb_pool_malloc((void **)&runs, 64) != hipSuccess ||
+        stb_pool_malloc((void **)&d_counts, 64) != hipSuccess) {
+      stb_fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, k0, p0);
+    size_t b1 = 0, b2 = 0;
+    if (rocprim::radix_sort_pairs(nullptr, b1, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
+    if (rocprim::run_length_encode(nullptr, b2, k1, (unsigned)G, uk, cnt, runs, g->st) != hipSuccess) break;
+    const size_t tmp_bytes = b1 > b2 ? b1 : b2;
+    if (stb_pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) {
+      stb_fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    size_t bb = tmp_bytes;
+    if (rocprim::radix_sort_pairs(tmp, bb, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
+    hipLaunchKernelGGL(k_key_bounds, dim3(1), dim3(1), 0, g->st, k1, G, d_counts);
+    uint64_t h_counts[2] = {0, 0};
+    if (hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, g->st) != hipSuccess ||
+        hipStreamSynchronize(g->st) != hipSuccess)
+      break;
+    const uint64_t n_in = h_counts[0], n_other = h_counts[1];
+    // dense enough that every cell's log might as well be computed: leave it to the count slab
+    if (n_in * 3 > stb_table_cells(N, M)) {
+      rc = 0;
+      break;
+    }
+    // the pairs outside the table, in their sorted order
+    g->G2 = n_other;
+    if (stb_pool_malloc((void **)&g->d_n2, 4 * (n_other ? n_other : 1)) != hipSuccess ||
+        stb_pool_malloc((void **)&g->d_t2, 2 * (n_other ? n_other : 1)) != hipSuccess) {
+      stb_fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (n_other)
+      hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t,
+                         p1 + n_in, n_other, g->d_n2, g->d_t2);
+    // distinct cells with their counts
+    unsigned h_runs = 0;
+    if (n_in) {
+      bb = tmp_bytes;
+      if (rocprim::run_length_encode(tmp, bb, k1, (unsigned)n_in, uk, cnt, runs, g->st) != hipSuccess) break;
+      if (hipMemcpyAsync(&h_runs, runs, 4, hipMemcpyDeviceToHost, g->st) != hipSuccess ||
+          hipStreamSynchronize(g->st) != hipSuccess)
+        break;
+    } else if (hipMemsetAsync(runs, 0, 4, g->st) != hipSuccess) {
+      break;
+    }
+    if (stb_pool_malloc((void **)&g->d_ent_pos, 2 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        stb_pool_malloc((void **)&g->d_ent_cnt, 4 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        stb_pool_malloc((void **)&g->d_item_ptr, 4 * ((size_t)nitems + 2)) != hipSuccess) {
+      stb_fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (h_runs) {
+      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos, item);
+      if (hipMemcpyAsync(g->d_ent_cnt, cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
+    }
+    hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr);
+    g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+    if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
+      stb_fail("stb_groups_aterms: out of device memory");
+      break;
+    }
+    if (hipStreamSynchronize(g->st) != hipSuccess || hipGetLastError() != hipSuccess) break;
+    g->nsg = nsg;
+    g->sparse = 1;
+    g->fused_ready = 1;
+    rc = 0;
+  } while (0);
+  if (rc != 0) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) stb_fail("stb_groups_aterms: sparse set-up failed: %s", hipGetErrorString(e));
+  }
+  (void)hipStreamSynchronize(g->st);
+  stb_pool_free(k0);
+  stb_pool_free(k1);
+  stb_pool_free(p0);
+  stb_pool_free(p1);
+  stb_pool_free(uk);
+  stb_pool_free(cnt);
+  stb_pool_free(item);
+  stb_pool_free(runs);
+  stb_pool_free(d_counts);
+  stb_pool_free(tmp);
+  return rc;
+}
+
+// Lazy set-up of the fused evaluation (first call with more than one discount): occurrence count
+// per table cell, and the pairs that address no cell.  The pairs come back from the device in their
+// sorted order, so the result does not depend on the order the caller supplied them in.
+static int groups_fused_setup(stb_groups_t *g) {
+  const unsigned N = g->N, M = g->M;
+  const uint64_t G = g->G;
+  const uint64_t elems = stb_table_elems(N, M);
+  HIPCHK(stb_pool_malloc((void **)&g->d_cnt, sizeof(unsigned) * (elems ? elems : 1)));
+  HIPCHK(hipMemsetAsync(g->d_cnt, 0, sizeof(unsigned) * (elems ? elems : 1), g->st));
+  if (G)
+    hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t, G, N,
+                       M, g->d_cnt);
+  uint32_t *hn = (uint32_t *)malloc(sizeof(uint32_t) * (G ? G : 1));
+  uint16_t *ht = (uint16_t *)malloc(sizeof(uint16_t) * (G ? G : 1));
+  if (!hn || !ht) {
+    free(hn);
+    free(ht);
+    return stb_fail("stb_groups_aterms: out of host memory");
+  }
+  hipError_t e1 = hipSuccess, e2 = hipSuccess;
+  if (G) {
+    e1 = hipMemcpyAsync(hn, g->d_n, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, g->st);
+    e2 = hipMemcpyAsync(ht, g->d_t, sizeof(uint16_t) * G, hipMemcpyDeviceToHost, g->st);
+  }
+  if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(g->st);
+  uint64_t G2 = 0;
+  if (e1 == hipSuccess && e2 == hipSuccess) {
+    for (uint64_t q = 0; q < G; q++) {  // compact in place: the pairs outside the table
+      const unsigned nn = hn[q], tt = ht[q];
+      if (nn > 1 && (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N)) {
+        hn[G2] = nn;
+        ht[G2] = (uint16_t)tt;
+        G2++;
+      }
+    }
+    g->G2 = G2;
+    e1 = stb_pool_malloc((void **)&g->d_n2, sizeof(uint32_t) * (G2 ? G2 : 1));
+    if (e1 == hipSuccess) e2 = stb_pool_malloc((void **)&g->d_t2, sizeof(uint16_t) * (G2 ? G2 : 1));
+    if (e1 == hipSuccess && e2 == hipSuccess && G2) {
+      e1 = hipMemcpy(g->d_n2, hn, sizeof(uint32_t) * G2, hipMemcpyHostToDevice);
+      e2 = hipMemcpy(g->d_t2, ht, sizeof(uint16_t) * G2, hipMemcpyHostToDevice);
+    }
+  }
+  free(hn);
+  free(ht);
+  if (e1 != hipSuccess || e2 != hipSuccess) return stb_fail("stb_groups_aterms: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  // partial sums: at most (column blocks of 64) x 16 waves per table
+  g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+  HIPCHK(stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems));
+  HIPCHK(hipGetLastError());
+  g->fused_ready = 1;
+  return 0;
+}
+
+// one evaluation; returns 0, 1 (error) or 2 (the fused chain fill gave up waiting: the caller
+// repeats the evaluation through stored tables)
+static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v,
+                       float *ms_fill, float *ms_sweep, float *ms_terms) {
+  double h[2 * STB_TERMS_DMAX];
+  const unsigned fb0 = stb_fill_fallbacks();
+  HIPCHK(hipEventRecord(g->ev[0], g->st));
+  if (fuse) {
+    // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
+    // then the few pairs that address no cell (t = 1 -> S1, t = n -> 0, out of bounds -> -inf)
+    dot_request req;
+    if (g->sparse) {
+      req.item_ptr = g->d_item_ptr;
+      req.ent_pos = g->d_ent_pos;
+      req.ent_cnt = g->d_ent_cnt;
+      req.nsg = g->nsg;
+    } else {
+      req.cnt = g->d_cnt;
+    }
+    req.dotp = g->d_dotp;
+    stb_set_dot_request(&req);
+    const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
+                              g->ws_fill, STB_FILL_CHAIN, g->st);
+    stb_set_dot_request(nullptr);
+    if (rc) return 1;
+    if ((size_t)D * req.parts_per_table > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+    HIPCHK(hipEventRecord(g->ev[1], g->st));
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+    hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(64), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
+  } else {
+    if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
+                   g->ws_fill, v, g->st))
+      return 1;
+    HIPCHK(hipEventRecord(g->ev[1], g->st));
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+  }
+  HIPCHK(hipEventRecord(g->ev[2], g->st));
+  if (stb_restaurant_terms(x_host, D, g->d_T, g->d_bpar, (uint64_t)g->I, g->d_out + g->Dmax,
+                           g->d_ws_terms, g->ws_terms, g->st))
+    return 1;
+  HIPCHK(hipEventRecord(g->ev[3], g->st));
+  HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * 2 * g->Dmax, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipStreamSynchronize(g->st));
+  if (stb_fill_status()) return fuse ? 2 : 1;
+  if (stb_fill_fallbacks() != fb0) {
+    // the chain fill gave up and stb_fill_status refilled the tables with the producer/consumer
+    // form: the sum above read unfinished tables, take it again
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+    HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * g->Dmax, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipStreamSynchronize(g->st));
+  }
+  for (int d = 0; d < D; d++) out_host[d] = h[g->Dmax + d] + h[d];
+  if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
+  if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));
+  if (ms_terms) HIPCHK(hipEventElapsedTime(ms_terms, g->ev[2], g->ev[3]));
+  return 0;
+}
+
+extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D,
+                                       double *out_host, float *ms_fill, float *ms_sweep,
+                                       float *ms_terms) {
+  STB_ENTRY;
+  if (!g) return stb_fail("stb_groups_aterms: null group set");
+  if (D < 1 || D > g->Dmax) return stb_fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
+  const int prev_dev = stb_device_enter(g->dev);
+  const int v = stb_default_variant();
+  // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
+  const bool fuse = g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
+  int rc = 0;
+  if (fuse && !g->fused_ready) {
+    if (stb_env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) rc = 1;
+    if (!rc && !g->fused_ready && groups_fused_setup(g)) rc = 1;
+  }
+  if (!rc) rc = aterms_once(g, x_host, D, out_host, fuse, v, ms_fill, ms_sweep, ms_terms);
+  if (rc == 2)  // no waits between workgroups in this form
+    rc = aterms_once(g, x_host, D, out_host, false, STB_FILL_PC, ms_fill, ms_sweep, ms_terms) ? 1 : 0;
+  stb_device_leave(prev_dev);
+  return rc;
+}
+
+extern "C" int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host) {
+  return stb_groups_aterms_timed(g, x_host, D, out_host, nullptr, nullptr, nullptr);
+}

@@ -48,6 +48,7 @@ typedef struct mirror_gen {
 
 typedef struct stb_impl {
   /* device */
+  int dev; /* the GPU the table lives on (stb_get_device() at S_make time) */
   double *d_S, *d_V, *d_S1;
   float *d_Sf, *d_Vf; /* S_FLOAT: narrowed copies of the double slabs, same element offsets */
   void *d_ws;
@@ -235,6 +236,7 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void 
       if (stb_memcpy_d2h(hV, im->d_Vf, sizeof(float) * stb_vtable_elems(N, M), NULL)) return 1;
     } else if (stb_memcpy_d2h(hV, im->d_V, sizeof(double) * stb_vtable_elems(N, M), NULL))
       return 1;
+    if (stb_fill_status()) return 1; /* before any later fill reuses the workspace and its header */
   }
   if (!(sp->flags & S_STABLE)) {
     /* U/V-only tables still keep S1 (lib/stable.c:155, :337-348): take it from a width-2 S fill
@@ -323,6 +325,13 @@ stable_t *S_make(unsigned initN, unsigned initM, unsigned maxN, unsigned maxM, d
     return NULL;
   }
   sp->impl = im;
+  im->dev = stb_get_device();
+  if (im->dev < 0 || im->dev >= stb_device_count()) {
+    yaps_message("S_make: device %d does not exist (stb_set_device / STB_DEVICE)\n", im->dev);
+    free(sp);
+    free(im);
+    return NULL;
+  }
   sp->flags = flags;
   sp->maxN = maxN;
   sp->maxM = maxM;
@@ -341,13 +350,16 @@ stable_t *S_make(unsigned initN, unsigned initM, unsigned maxN, unsigned maxM, d
   sp->lga = lgamma(1.0 - a); /* lib/stable.c:329 */
   {
     pending p;
+    const int prev_dev = stb_device_enter(im->dev);
     if (provision(sp, initN, initM, 0, &p) || build(sp, a, initN, initM, p.hS, p.hV)) {
       yaps_message("S_make: %s\n", stb_last_error());
       pending_drop(&p);
+      stb_device_leave(prev_dev);
       S_free(sp);
       return NULL;
     }
     publish(sp, &p, initN, initM);
+    stb_device_leave(prev_dev);
   }
   if (flags & S_VERBOSE) S_report(sp, stderr);
   return sp;
@@ -363,15 +375,19 @@ int S_remake(stable_t *sp, double a) {
   unsigned n;
   if (!sp || !sp->impl) return 1;
   if (!(a >= 0.0 && a < 1.0)) return 1;
-  sp->a = a;
-  sp->lga = lgamma(1.0 - a); /* lib/stable.c:328-329 */
   {
     stb_impl *im = sp->impl;
-    if (build(sp, a, sp->usedN, sp->usedM, im->h_S, im->h_V)) {
+    const int prev_dev = stb_device_enter(im->dev);
+    const int rc = build(sp, a, sp->usedN, sp->usedM, im->h_S, im->h_V);
+    stb_device_leave(prev_dev);
+    if (rc) {
+      /* the table keeps its old discount (the mirrors may be partly overwritten: remake again) */
       yaps_message("S_remake: %s\n", stb_last_error());
       return 1;
     }
   }
+  sp->a = a;
+  sp->lga = lgamma(1.0 - a); /* lib/stable.c:328-329 */
   /* the discount changed, so lazily cached S1 entries past usedN are void (lib/stable.c:350-353) */
   for (n = sp->usedN; n < sp->usedN1; n++) sp->S1[n] = 0;
   if (sp->flags & S_VERBOSE) S_report(sp, stderr);
@@ -438,11 +454,13 @@ static int extend(stable_t *sp, int N, int M) {
     }
     {
       pending p;
+      const int prev_dev = stb_device_enter(im->dev);
       rc = provision(sp, newN, newM, 1, &p) || build(sp, sp->a, newN, newM, p.hS, p.hV);
       if (!rc)
         publish(sp, &p, newN, newM);
       else
         pending_drop(&p);
+      stb_device_leave(prev_dev);
     }
   }
   unlock(sp);
@@ -589,6 +607,7 @@ void S_free(stable_t *sp) {
   free(sp->Sf);
   free(sp->Vf);
   if (im) {
+    const int prev_dev = stb_device_enter(im->dev);
     mirror_gen *g = im->retired;
     while (g) {
       mirror_gen *nx = g->next;
@@ -605,6 +624,7 @@ void S_free(stable_t *sp) {
     stb_device_free(im->d_Vf);
     stb_device_free(im->d_S1);
     stb_device_free(im->d_ws);
+    stb_device_leave(prev_dev);
     free(im);
   }
   if (sp->flags & S_THREADS) pthread_mutex_destroy(&sp->mutex);

@@ -1,0 +1,222 @@
+// stb_common.h -- what the HIP translation units of libstb_amd share: error plumbing, the guard
+// around libc's rand() state, the buffer cache, the arguments of the fill kernels, and the device
+// helpers for cell arithmetic, table logs and deterministic double-double sums.
+//
+//   abi.hip          error text, device selection, buffer cache, memory helpers, layout exports
+//   fill.hip         stb_fill_S / stb_fill_V: choice of form, workspace, status, per-launch timing
+//   fill_chain.hip   k_fill_chain (default S fill, also the fused aterms sum), k_fillv_chain (V)
+//   fill_pc.hip      k_fill_pc (launch-per-128-rows form: many tables, and the fallback), k_s1
+//   fill_rows.hip    k_fill_rows: the reference's own operation order (log domain / V ratios)
+//   sweep_terms.hip  k_lookup, k_to_float, k_sweep_partial, k_terms_partial, reductions
+//   groups.hip       stb_groups_*: device-resident (n,t) pairs and the aterms evaluation
+//   ablation.hip     superseded fill forms, only in `make ABLATION=1` builds
+#ifndef STB_COMMON_H
+#define STB_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "stb_layout.h"
+#include "../../include/stb_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+int stb_fail(const char *fmt, ...);  // records the message for stb_last_error(), returns 1
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return stb_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// The HIP runtime draws from libc's rand() while it initialises (first stream, first module load:
+// observed on ROCm 7.2), which would shift the rand() stream the caller's ARMS sampler is about to
+// consume (reference lib/arms.c:913-918).  Every entry point that can reach the runtime runs with
+// rand()'s state swapped to a private buffer (glibc: rand() and random() share the state that
+// initstate/setstate switch) and puts the caller's state back on exit.  That state is one per
+// process, so the swap is too: entry points nest and may come from several threads, hence one
+// recursive lock, a depth count, and a buffer that is not on anybody's stack; the state changes
+// hands only at depth 0 <-> 1.
+struct stb_rand_guard {
+  stb_rand_guard();
+  ~stb_rand_guard();
+  stb_rand_guard(const stb_rand_guard &) = delete;
+  stb_rand_guard &operator=(const stb_rand_guard &) = delete;
+};
+#define STB_ENTRY stb_rand_guard stb_rand_guard_
+
+// buffer cache (abi.hip): kind 0 device memory, 1 pinned host memory
+hipError_t stb_pool_malloc(void **out, size_t bytes, int kind = 0);
+bool stb_pool_free(void *p);  // false if p did not come from the cache
+
+// the device this thread's calls go to (stb_set_device / STB_DEVICE), made current
+int stb_use_device(void);
+
+// 128-entry {1/c, -log(1/c)} table of the stored log, on the current device
+int stb_logtab(const double2 **out);
+
+static inline size_t stb_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int stb_env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  if (!s || !*s) return dflt;
+  return atoi(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fill kernels: common arguments
+
+struct fill_args {
+  const double *a;    // [D] discounts (device)
+  double *tables;     // D slabs (S or V layout)
+  uint64_t tstride;   // elements between slabs
+  double *S1;         // D vectors of N (S modes only)
+  uint64_t s1stride;
+  double *fm;         // frontier mantissas / plain values: [D][2][W]   (launch-per-row-block forms)
+  int *fe;            // frontier exponents:                 [D][2][W]
+  const double2 *lt;  // log table (stb_logtab)
+  unsigned W;         // frontier row pitch (>= M+2)
+  unsigned N, M;
+  int R;              // rows advanced per launch
+  int H;              // halo columns (>= R, multiple of C)
+  int Wv;             // owned columns per strip = 64*C - H
+};
+
+// per-launch timing (fill.hip): when armed, a launch gets a begin/end event pair
+void stb_prof_events(hipEvent_t *e0, hipEvent_t *e1);
+#define STB_LAUNCH(KERN, GRID, BLOCK, ST, ...)                                          \
+  do {                                                                                  \
+    hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                          \
+    stb_prof_events(&pe0_, &pe1_);                                                      \
+    if (pe0_)                                                                           \
+      hipExtLaunchKernelGGL(KERN, GRID, BLOCK, 0, ST, pe0_, pe1_, 0, __VA_ARGS__);      \
+    else                                                                                \
+      hipLaunchKernelGGL(KERN, GRID, BLOCK, 0, ST, __VA_ARGS__);                        \
+  } while (0)
+
+// rows per renormalisation period of the block-floating forms that start a period at 2^-700
+int stb_period_rows(unsigned N);
+
+// the forms (each in its own translation unit); all return 0 or stb_fail(...)
+struct dot_request {  // set by stb_groups_aterms around its fill: the chain form sums count * log S
+  const unsigned *cnt = nullptr;           // dense: occurrence count per cell, table layout
+  const unsigned *item_ptr = nullptr;      // sparse: CSR over (trip, slice) items
+  const unsigned short *ent_pos = nullptr; //         row-in-trip << 6 | column-in-slice
+  const unsigned *ent_cnt = nullptr;       //         occurrence count
+  unsigned nsg = 0;                        //         slices per trip in item_ptr
+  double *dotp = nullptr;                  // partial sums [D][parts_per_table]
+  int parts_per_table = 0;                 // out
+};
+void stb_set_dot_request(const dot_request *r);  // for the next stb_fill_S of this thread
+size_t stb_chain_workspace(unsigned N, unsigned M, int D);
+int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out,
+                     hipStream_t st);
+int stb_launch_vchain(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
+int stb_chain_tuning(unsigned N, unsigned M, int D, int *P_out);
+int stb_launch_pc(fill_args &A, int D, hipStream_t st);
+int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
+#define STB_ROWS_LOGDOM 1
+#define STB_ROWS_VRATIO 2
+int stb_launch_rows(fill_args &A, int D, int C, int what, hipStream_t st);
+// superseded forms (ablation.hip); absent from the default build
+#define STB_HAVE_ABLATION_SYM stb_ablation_fill
+extern "C" int stb_ablation_fill(fill_args &A, int D, int variant, char *ws, size_t ws_left, unsigned **hdr_out,
+                                 hipStream_t st) __attribute__((weak));
+extern "C" size_t stb_ablation_workspace(unsigned N, unsigned M, int D) __attribute__((weak));
+
+// ------------------------------------------------------------------------------------------------
+// device side
+#if defined(__HIPCC__)
+
+// one lane shifted up by one across the whole 64-lane wave (lane l receives lane l-1's value,
+// lane 0 receives `fill`): DPP wave_shr:1, no LDS traffic
+__device__ __forceinline__ int wave_shr1(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+// same with 0 shifted into lane 0 (bound_ctrl: no register has to be preset with the fill value)
+__device__ __forceinline__ double wave_shr1_zero(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shr1(double v, double fill) {
+  int lo = wave_shr1(__double2loint(v), __double2loint(fill));
+  int hi = wave_shr1(__double2hiint(v), __double2hiint(fill));
+  return __hiloint2double(hi, lo);
+}
+
+// log(v 2^ep) from the bits of v: exponent field + 7 leading mantissa bits index a 128-entry table
+// {1/c, -log(1/c)} (held in LDS by the callers), then a degree-5 polynomial in r = z/c - 1,
+// |r| < 2^-8 (the construction used by table-driven libm logs).  Absolute error a few 1e-16.
+__device__ __forceinline__ double bfp_log(double v, int ep, const double2 *lt) {
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const int hi = __double2hiint(v), lo = __double2loint(v);
+  const int kexp = ((hi >> 20) & 0x7ff) - 1023;
+  const int idx = (hi >> 13) & 127;
+  const double z = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);  // [1,2)
+  const double2 t = lt[idx];
+  const double r = fma(z, t.x, -1.0);
+  double p = fma(r, 0.2, -0.25);  // r^6/6 <= 2^-48/6 = 6e-16 is dropped
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  const double kf = (double)(kexp + ep);
+  return fma(kf, LN2_HI, fma(kf, LN2_LO, fma(r, p, t.y)));
+}
+
+// LDS-only barrier: waits for this wave's LDS traffic, NOT for its global stores (a __syncthreads()
+// would add s_waitcnt vmcnt(0) and stall every consumer on its stores' round trip once per trip)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// significands of the producer/consumer and chain forms start a period at 2^-PC_BIAS * [0.5,1)
+#define PC_BIAS 700
+#define STB_EZ (-(1 << 28))  // exponent standing for an exact zero in a frontier
+
+// ---- deterministic double-double sums ----
+struct dd_t {
+  double hi, lo;
+};
+__device__ __forceinline__ void dd_add(dd_t &s, double x) {
+  double t = s.hi + x;
+  if (isfinite(t)) {
+    double bb = t - s.hi;
+    s.lo += (s.hi - (t - bb)) + (x - bb);
+  }
+  s.hi = t;
+}
+__device__ __forceinline__ void dd_merge(dd_t &s, dd_t o) {
+  dd_add(s, o.hi);
+  s.lo += o.lo;
+}
+// reduce one dd per thread over a block of up to 256 threads in a fixed order; valid in thread 0
+__device__ __forceinline__ dd_t block_reduce_dd(dd_t v, dd_t *lds /* [4] */) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    dd_t o;
+    o.hi = __shfl_down(v.hi, off, 64);
+    o.lo = __shfl_down(v.lo, off, 64);
+    dd_merge(v, o);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) dd_merge(v, lds[w]);
+  }
+  __syncthreads();
+  return v;
+}
+#endif  // __HIPCC__
+
+#endif

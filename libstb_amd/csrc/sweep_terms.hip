@@ -1,0 +1,277 @@
+// sweep_terms.hip -- the reductions of the hyper-parameter posteriors and the small table utilities.
+//
+//   K3  k_sweep_partial   sum of S_S(n,t) over the (n,t) pairs of aterms    lib/samplea.c:68-80
+//   K4  k_terms_partial   restaurant terms of aterms / lgamma sum of bterms  lib/samplea.c:65-67,
+//                                                                            lib/sampleb.c:33-41
+//       k_lookup          S_S semantics for a list of (n,m)                  lib/stable.c:941-974
+//       k_to_float        S_FLOAT storage: narrow a slab                     lib/stable.h:31-33
+// Sums are double-double per thread, then a fixed-shape tree: the same bits on every run.
+
+#include "stb_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// S_FLOAT storage: narrow a slab
+
+__global__ __launch_bounds__(256) void k_to_float(const double *src, float *dst, uint64_t n2) {
+  // two elements per thread: one 16-byte load, one 8-byte store
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n2; i += step) {
+    const double2 v = reinterpret_cast<const double2 *>(src)[i];
+    reinterpret_cast<float2 *>(dst)[i] = make_float2((float)v.x, (float)v.y);
+  }
+}
+
+extern "C" int stb_table_to_float(const double *d_src, float *d_dst, uint64_t elems, void *stream) {
+  STB_ENTRY;
+  if (elems == 0) return 0;
+  if (elems & 1) return stb_fail("stb_table_to_float: element count must be even (slabs are)");
+  const uint64_t n2 = elems / 2;
+  uint64_t blocks = (n2 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_to_float, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, n2);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lookups with S_S semantics
+
+__device__ __forceinline__ double dev_S_S(const double *table, const double *S1, unsigned N,
+                                          unsigned M, unsigned n, unsigned m) {
+  // test order of lib/stable.c:941-974 for a table that cannot grow
+  if (n == m) return 0.0;
+  if (m == 1) return (n >= 1 && n <= N) ? S1[n - 1] : -HUGE_VAL;
+  if (n < m || m == 0) return -HUGE_VAL;
+  if (m > M || n > N) return -HUGE_VAL;
+  return table[stb_row_offset(n, M) + (m - 2)];
+}
+
+__global__ void k_lookup(const double *table, const double *S1, unsigned N, unsigned M,
+                         const uint32_t *n, const uint32_t *m, uint64_t G, double *out) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < G; g += step) out[g] = dev_S_S(table, S1, N, M, n[g], m[g]);
+}
+
+extern "C" int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
+                            const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
+                            void *stream) {
+  STB_ENTRY;
+  if (G == 0) return 0;
+  uint64_t blocks = (G + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_lookup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_table,
+                     d_S1, N, M, d_n, d_m, G, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// second stage: out[d] = base[d] + sum_b partial[d][b], one block per d, fixed order
+__global__ __launch_bounds__(256) void k_reduce_final(const dd_t *partial, int nb, double *out,
+                                                      const double *base) {
+  __shared__ dd_t lds[4];
+  const int d = blockIdx.x;
+  dd_t v{0.0, 0.0};
+  for (int b = threadIdx.x; b < nb; b += 256) dd_merge(v, partial[(size_t)d * nb + b]);
+  v = block_reduce_dd(v, lds);
+  if (threadIdx.x == 0) {
+    if (base) dd_add(v, base[d]);
+    out[d] = v.hi + v.lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: sweep.  Each block takes a contiguous chunk of pairs and DT discounts; the (n,t) pair is read
+// once per DT tables, the row offset computed once, and DT gathers issued.
+
+#define STB_SWEEP_DT 8
+#define STB_SWEEP_CHUNK 4096
+
+__global__ __launch_bounds__(256) void k_sweep_partial(const double *tables, uint64_t tstride,
+                                                       const double *S1, uint64_t s1stride, int D,
+                                                       unsigned N, unsigned M, const uint32_t *n,
+                                                       const uint16_t *t, uint64_t G, dd_t *partial,
+                                                       int nb) {
+  __shared__ dd_t lds[4];
+  const int d0 = blockIdx.y * STB_SWEEP_DT;
+  const uint64_t g0 = (uint64_t)blockIdx.x * STB_SWEEP_CHUNK;
+  const uint64_t g1 = (g0 + STB_SWEEP_CHUNK < G) ? g0 + STB_SWEEP_CHUNK : G;
+  dd_t acc[STB_SWEEP_DT];
+#pragma unroll
+  for (int q = 0; q < STB_SWEEP_DT; q++) acc[q] = dd_t{0.0, 0.0};
+  for (uint64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+    const unsigned nn = n[g], tt = t[g];
+    if (nn <= 1) continue;  // lib/samplea.c:78: only n>1 contributes
+    // classify once (lib/stable.c:944-949), then the gather differs per table only by base
+    int kind;  // 0: zero, 1: S1, 2: -inf, 3: table
+    uint64_t off = 0;
+    if (nn == tt) kind = 0;
+    else if (tt == 1) kind = (nn <= N) ? 1 : 2;
+    else if (nn < tt || tt == 0) kind = 2;
+    else if (tt > M || nn > N) kind = 2;
+    else {
+      kind = 3;
+      off = stb_row_offset(nn, M) + (tt - 2);
+    }
+#pragma unroll
+    for (int q = 0; q < STB_SWEEP_DT; q++) {
+      const int d = d0 + q;
+      if (d < D) {
+        double v;
+        if (kind == 3) v = tables[(uint64_t)d * tstride + off];
+        else if (kind == 1) v = S1[(uint64_t)d * s1stride + nn - 1];
+        else v = (kind == 0) ? 0.0 : -HUGE_VAL;
+        dd_add(acc[q], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < STB_SWEEP_DT; q++) {
+    dd_t r = block_reduce_dd(acc[q], lds);
+    if (threadIdx.x == 0 && d0 + q < D) partial[(size_t)(d0 + q) * nb + blockIdx.x] = r;
+  }
+}
+
+static int sweep_blocks(uint64_t G) { return (int)((G + STB_SWEEP_CHUNK - 1) / STB_SWEEP_CHUNK); }
+
+extern "C" size_t stb_sweep_workspace_bytes(uint64_t G, int D) {
+  int nb = sweep_blocks(G);
+  if (nb < 1) nb = 1;
+  return (size_t)D * nb * sizeof(dd_t) + 256;
+}
+
+extern "C" int stb_sweep_S(const double *d_tables, uint64_t table_stride, const double *d_S1,
+                           uint64_t s1_stride, int D, unsigned N, unsigned M, const uint32_t *d_n,
+                           const uint16_t *d_t, uint64_t G, double *d_out, void *d_ws,
+                           size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  hipStream_t st = (hipStream_t)stream;
+  if (D < 1) return stb_fail("stb_sweep_S: D=%d", D);
+  if (ws_bytes < stb_sweep_workspace_bytes(G, D)) return stb_fail("stb_sweep_S: workspace too small");
+  int nb = sweep_blocks(G);
+  dd_t *partial = (dd_t *)d_ws;
+  if (nb == 0) {
+    HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * D, st));
+    return 0;
+  }
+  dim3 grid(nb, (D + STB_SWEEP_DT - 1) / STB_SWEEP_DT);
+  hipLaunchKernelGGL(k_sweep_partial, grid, dim3(256), 0, st, d_tables, table_stride, d_S1,
+                     s1_stride, D, N, M, d_n, d_t, G, partial, nb);
+  hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, st, partial, nb, d_out,
+                     (const double *)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-restaurant terms
+
+#define STB_TERMS_CHUNK 2048
+#define STB_TERMS_DMAX 64
+
+struct terms_args {
+  double x[STB_TERMS_DMAX];  // abscissae
+  double p[STB_TERMS_DMAX];  // restaurant: log(x) ; bterms: lgamma(x/apar)
+  double q[STB_TERMS_DMAX];  // bterms: x/apar
+  int D;
+  int mode;  // 0 restaurant (aterms head), 1 bterms
+};
+
+__global__ __launch_bounds__(256) void k_terms_partial(terms_args A, const uint32_t *T,
+                                                       const double *bpar, uint64_t I, dd_t *partial,
+                                                       int nb) {
+  __shared__ dd_t lds[4];
+  const uint64_t i0 = (uint64_t)blockIdx.x * STB_TERMS_CHUNK;
+  const uint64_t i1 = (i0 + STB_TERMS_CHUNK < I) ? i0 + STB_TERMS_CHUNK : I;
+  const int d = blockIdx.y;
+  dd_t acc{0.0, 0.0};
+  if (A.mode == 0) {
+    const double x = A.x[d], lx = A.p[d];
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+#pragma clang fp contract(off)
+      // lib/samplea.c:66-67: T*log(x) + lgamma(T + b/x) - lgamma(b/x), association as written
+      const double Ti = (double)T[i];
+      const double bx = bpar[i] / x;
+      const double term = (Ti * lx + lgamma(Ti + bx)) - lgamma(bx);
+      dd_add(acc, term);
+    }
+  } else {
+    const double lg = A.p[d], xa = A.q[d];
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      // lib/sampleb.c:38-39: lgamma(T + x/a) - lgamma(x/a)
+      dd_add(acc, lgamma((double)T[i] + xa) - lg);
+  }
+  dd_t r = block_reduce_dd(acc, lds);
+  if (threadIdx.x == 0) partial[(size_t)d * nb + blockIdx.x] = r;
+}
+
+static int terms_blocks(uint64_t I) { return (int)((I + STB_TERMS_CHUNK - 1) / STB_TERMS_CHUNK); }
+
+extern "C" size_t stb_terms_workspace_bytes(uint64_t I, int D) {
+  int nb = terms_blocks(I);
+  if (nb < 1) nb = 1;
+  return (size_t)D * nb * sizeof(dd_t) + (size_t)D * sizeof(double) + 512;
+}
+
+static int run_terms(terms_args &A, const double *base_host, const uint32_t *d_T,
+                     const double *d_bpar, uint64_t I, double *d_out, void *d_ws, size_t ws_bytes,
+                     hipStream_t st) {
+  const int D = A.D;
+  if (ws_bytes < stb_terms_workspace_bytes(I, D)) return stb_fail("terms: workspace too small");
+  int nb = terms_blocks(I);
+  double *d_base = (double *)d_ws;
+  dd_t *partial = (dd_t *)((char *)d_ws + stb_align_up((size_t)D * sizeof(double), 256));
+  if (base_host)
+    HIPCHK(hipMemcpyAsync(d_base, base_host, sizeof(double) * D, hipMemcpyHostToDevice, st));
+  if (nb == 0) {
+    if (base_host)
+      HIPCHK(hipMemcpyAsync(d_out, d_base, sizeof(double) * D, hipMemcpyDeviceToDevice, st));
+    else
+      HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * D, st));
+    return 0;
+  }
+  hipLaunchKernelGGL(k_terms_partial, dim3(nb, D), dim3(256), 0, st, A, d_T, d_bpar, I, partial, nb);
+  hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, st, partial, nb, d_out,
+                     base_host ? (const double *)d_base : (const double *)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int stb_restaurant_terms(const double *x_host, int D, const uint32_t *d_T,
+                                    const double *d_bpar, uint64_t I, double *d_out, void *d_ws,
+                                    size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  if (D < 1 || D > STB_TERMS_DMAX) return stb_fail("stb_restaurant_terms: D=%d (max %d)", D, STB_TERMS_DMAX);
+  terms_args A;
+  memset(&A, 0, sizeof(A));
+  A.D = D;
+  A.mode = 0;
+  for (int d = 0; d < D; d++) {
+    if (!(x_host[d] > 0)) return stb_fail("stb_restaurant_terms: x=%g", x_host[d]);
+    A.x[d] = x_host[d];
+    A.p[d] = log(x_host[d]);  // host libm: one scalar per abscissa, same call as samplea.c:66
+  }
+  return run_terms(A, nullptr, d_T, d_bpar, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
+                          const uint32_t *d_T, uint64_t I, double *d_out, void *d_ws,
+                          size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  if (J < 1 || J > STB_TERMS_DMAX) return stb_fail("stb_bterms: J=%d (max %d)", J, STB_TERMS_DMAX);
+  if (!(apar > 0)) return stb_fail("stb_bterms: apar=%g", apar);
+  terms_args A;
+  double base[STB_TERMS_DMAX];
+  memset(&A, 0, sizeof(A));
+  A.D = J;
+  A.mode = 1;
+  for (int j = 0; j < J; j++) {
+    if (!(x_host[j] > 0)) return stb_fail("stb_bterms: x=%g", x_host[j]);
+    A.x[j] = x_host[j];
+    A.q[j] = x_host[j] / apar;
+    A.p[j] = lgamma(A.q[j]);                                   // lib/sampleb.c:36
+    base[j] = -Q * x_host[j] + (shape - 1) * log(x_host[j]);   // lib/sampleb.c:37
+  }
+  return run_terms(A, base, d_T, nullptr, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
+}

@@ -353,12 +353,66 @@ def g12_rng(R):
     dump("rng.json", out)
 
 
+GRID_PROBE_D = (0, 7, 31, 63)  # members of the 64-point grid a_d = 0.05 + 0.9 (d + 1/2) / 64
+
+
+def g13_grid_tables(R):
+    """configs[2]: the 64-discount batch at N=M=10000.  For four members of the grid (first and last
+    of rank 0's share of eight, last of rank 3's, last of rank 7's): every row's sum, two full rows,
+    S1 and sparse probes."""
+    N = 10000
+    grid = synth.discount_grid(64)
+    arrays, probes = {}, []
+    for d in GRID_PROBE_D:
+        a = float(grid[d])
+        sp = R.S_make(N, N, N, N, a, S_STABLE)
+        buf = np.zeros(N, dtype=np.float64)
+        rowsum = np.zeros(N + 1, dtype=np.float64)
+        for n in range(3, N + 1):
+            k = R.ref_copy_S_row(sp, n, orc.dp(buf))
+            rowsum[n] = np.sum(buf[:k])
+        key = f"d{d}"
+        arrays[key + "_a"] = np.array([a])
+        arrays[key + "_rowsum"] = rowsum
+        for n in (N // 3, N):
+            k = R.ref_copy_S_row(sp, n, orc.dp(buf))
+            arrays[key + f"_row{n}"] = buf[:k].copy()
+        s1 = np.zeros(N)
+        R.ref_copy_S1(sp, orc.dp(s1), N)
+        arrays[key + "_S1"] = s1
+        for n in sorted({3, 4, 5, 10, 100, 1000, N // 2, N - 1, N}):
+            for m in sorted({m for m in (1, 2, 3, 4, n // 2, n - 2, n - 1, n) if 1 <= m <= n}):
+                probes.append({"d": d, "a": hx(a), "n": n, "m": m, "S": hx(R.S_S(sp, n, m))})
+        R.S_free(sp)
+    np.savez_compressed(os.path.join(HERE, "stable_grid10k.npz"), **arrays)
+    print("wrote stable_grid10k.npz")
+    dump("stable_grid10k_probes.json", probes)
+
+
+def g14_grid_aterms(R):
+    """configs[4]: aterms at ALL 64 grid discounts for the 10^6-pair set of config 3/4 (n < 4000, wide
+    t), and at four of them for the same shape with n < 10000 (the bench's N=M=10000 grid)."""
+    grid = synth.discount_grid(64)
+    out = {}
+    for name, (I, K, nmax, prof), ds in (("big_wide", GROUP_SETS["big_wide"], range(64)),
+                                        ("big10k_wide", (1000, 1000, 10000, "wide"), GRID_PROBE_D)):
+        g = synth.groups(I, K, nmax, prof)
+        h = R.ref_aterms_open(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar))
+        ds = list(ds)
+        vals = [hx(R.ref_aterms_eval(h, float(grid[d]))) for d in ds]
+        out[name] = {"I": I, "K": K, "n_max": nmax, "profile": prof, "sha256": group_hash(g),
+                     "maxn": R.ref_aterms_maxn(h), "maxt": R.ref_aterms_maxt(h), "d": ds,
+                     "x": [hx(float(grid[d])) for d in ds], "aterms": vals}
+        R.ref_aterms_close(h)
+    dump("aterms_grid64.json", out)
+
+
 def main():
     if not orc.have_ref():
         sys.exit("oracle/_ref/libstb_ref.so missing: run `make -C oracle` where /root/reference exists")
     R = orc.ref()
     gens = [g1_small_tables, g2_big_probes, g3_asympt, g4_extend, g5_aterms, g6_bterms,
-            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng]
+            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng, g13_grid_tables, g14_grid_aterms]
     want = sys.argv[1:]
     for g in gens:
         if not want or g.__name__.split("_")[0] in want:

@@ -22,6 +22,8 @@ def test_library_sees_gpu():
 @pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
 def test_small_tables_batched_vs_golden(golden_dir, variant):
     """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
+    if not capi.has_variant(variant):
+        pytest.skip("superseded form: needs `make ABLATION=1`")
     z = np.load(os.path.join(golden_dir, "stable_200x50.npz"))
     keys = ["a0.5", "a0.125", "a0.05", "a0.95", "a2_3"]
     a = np.array([float(z[k + "_a"][0]) for k in keys])
@@ -39,6 +41,8 @@ def test_small_tables_batched_vs_golden(golden_dir, variant):
                                  (1000, 1000), (1500, 260)])
 def test_ragged_shapes_vs_oracle(N, M, variant):
     """edge shapes: tiny, one strip / several strips, diagonal inside a strip, M << N"""
+    if not capi.has_variant(variant):
+        pytest.skip("superseded form: needs `make ABLATION=1`")
     a = np.array([0.31, 0.77])
     T = capi.DeviceTables(N, M, D=2)
     T.fill(a, variant)
@@ -64,6 +68,8 @@ def test_tunings_agree(monkeypatch, C, R):
 @pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
 @pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
 def test_4000_full_table_vs_oracle(golden_dir, a, variant):
+    if not capi.has_variant(variant):
+        pytest.skip("superseded form: needs `make ABLATION=1`")
     N = 4000
     T = capi.DeviceTables(N, N, D=1)
     T.fill([a], variant)
@@ -107,6 +113,73 @@ def test_10000_config2_vs_golden(golden_dir, a):
     assert orc.close(got, [fh(p["S"]) for p in probes], TOL)
 
 
+def _check_against_grid_fixture(T, dl, d, z, probes):
+    """table dl of T is member d of the 64-discount grid: row sums, two rows, S1, probes"""
+    N = 10000
+    t = T.tables[dl].cpu().numpy()
+    rowsum = np.zeros(N + 1)
+    absmax = np.zeros(N + 1)
+    for n in range(3, N + 1):
+        o = T.rowoff(n)
+        r = t[o:o + n - 2]
+        rowsum[n] = np.sum(r)
+        absmax[n] = (n - 2) * max(1.0, np.max(np.abs(r)))
+    assert np.all(np.isfinite(rowsum))
+    assert np.all(np.abs(rowsum - z[f"d{d}_rowsum"]) <= TOL * np.maximum(absmax, 1.0)), d
+    for n in (N // 3, N):
+        o = T.rowoff(n)
+        assert orc.close(t[o:o + n - 2], z[f"d{d}_row{n}"], TOL), (d, n)
+    assert orc.close(T.S1[dl].cpu().numpy(), z[f"d{d}_S1"], TOL)
+    mine = [p for p in probes if p["d"] == d]
+    assert len(mine) > 40
+    got = T.lookup([p["n"] for p in mine], [p["m"] for p in mine], d=dl)
+    assert orc.close(got, [fh(p["S"]) for p in mine], TOL), d
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_10000_batched_config3_eight_per_gpu(golden_dir, rank):
+    """configs[2] as one GPU of eight sees it: its 8 consecutive members of the 64-discount grid at
+    N=M=10000 in one batched fill (the form stb_fill_S picks by itself: the chain), status checked,
+    no fallback taken, against the reference's tables for the grid members 0, 7, 31, 63."""
+    L = capi.lib()
+    z = np.load(os.path.join(golden_dir, "stable_grid10k.npz"))
+    with open(os.path.join(golden_dir, "stable_grid10k_probes.json")) as f:
+        probes = json.load(f)
+    grid = synth.discount_grid(64)
+    mine = np.ascontiguousarray(grid[8 * rank:8 * rank + 8])
+    T = capi.DeviceTables(10000, 10000, D=8)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    assert L.stb_fill_tuning(10000, 10000, 8, None, None, None) == 3      # chain form
+    T.fill(mine)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    for d in (0, 7, 31, 63):
+        if 8 * rank <= d < 8 * rank + 8:
+            assert float(z[f"d{d}_a"][0]) == mine[d - 8 * rank]
+            _check_against_grid_fixture(T, d - 8 * rank, d, z, probes)
+
+
+def test_10000_batched_config3_all_64_on_one_gpu(golden_dir):
+    """configs[2] on ONE GPU: all 64 discounts in one batched fill at N=M=10000 (27 GB of tables),
+    in the form stb_fill_S picks for that many columns in flight"""
+    L = capi.lib()
+    z = np.load(os.path.join(golden_dir, "stable_grid10k.npz"))
+    with open(os.path.join(golden_dir, "stable_grid10k_probes.json")) as f:
+        probes = json.load(f)
+    grid = synth.discount_grid(64)
+    T = capi.DeviceTables(10000, 10000, D=64)
+    before = L.stb_fill_fallbacks()
+    T.fill(grid)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    for d in (0, 7, 31, 63):
+        _check_against_grid_fixture(T, d, d, z, probes)
+    # the other 60: finite everywhere and monotone in the discount at a probe cell
+    probe = T.tables[:, T.rowoff(10000) + 4998].cpu().numpy()       # log S^10000_5000 per discount
+    assert np.all(np.isfinite(probe)) and np.all(np.diff(probe) < 0)
+
+
 def test_10000_round_trip_property():
     """size-independent property at full size: the last row satisfies the recurrence
     S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1} in the log domain, row by row sampled."""
@@ -146,6 +219,8 @@ def test_v_table_big_vs_oracle():
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the
     renormalisation period must be sized for that, at every discount, with the longest launches"""
+    if not capi.has_variant(variant):
+        pytest.skip("superseded form: needs `make ABLATION=1`")
     monkeypatch.setenv("STB_FILL_R", "120")
     monkeypatch.setenv("STB_FILL_C", "2")
     N = 6000
@@ -195,6 +270,8 @@ def test_chain_more_blocks_than_fit_at_once():
 @pytest.mark.parametrize("N,M", [(900, 700), (2500, 2500), (3000, 130)])
 def test_chainx_geometries_agree(monkeypatch, P, N, M):
     """chain form with converter blocks: every producer-block width computes the same tables"""
+    if not capi.has_variant(capi.FILL_CHAINX):
+        pytest.skip("superseded form: needs `make ABLATION=1`")
     monkeypatch.setenv("STB_CHAINX_P", str(P))
     a = np.array([0.07, 0.6])
     T = capi.DeviceTables(N, M, D=2)
@@ -231,14 +308,52 @@ def test_chain_random_shapes_vs_oracle():
 
 def test_chain_gives_up_instead_of_hanging(monkeypatch):
     """every wait of the chain form is bounded: with the bound set to zero a block that has to wait
-    records an error and runs to its end; the fill returns and stb_fill_status reports it"""
+    records an error and runs to its end; the fill returns.  stb_fill_status then repeats the fill
+    with the producer/consumer form (no waits between workgroups) -- or, with the repeat switched
+    off, reports the failure."""
+    L = capi.lib()
+    S1, tab = orc.fill_S(0.5, 3000, 3000)
     monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    monkeypatch.setenv("STB_CHAIN_NO_FALLBACK", "1")
     T = capi.DeviceTables(3000, 3000, D=1)
     T.fill([0.5], capi.FILL_CHAIN)
     with pytest.raises(capi.StbError):
         T.status()
+    monkeypatch.delenv("STB_CHAIN_NO_FALLBACK")
+    before = L.stb_fill_fallbacks()
+    T.tables.fill_(float("nan"))
+    T.fill([0.5], capi.FILL_CHAIN)
+    T.status()                          # gave up -> refilled by k_fill_pc
+    assert L.stb_fill_fallbacks() == before + 1
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
     monkeypatch.delenv("STB_CHAIN_TIMEOUT_MS")
+    T.tables.fill_(float("nan"))
     T.fill([0.5], capi.FILL_CHAIN)      # and the next fill is fine again
     T.status()
-    S1, tab = orc.fill_S(0.5, 3000, 3000)
+    assert L.stb_fill_fallbacks() == before + 1
     assert orc.max_err(T.packed_host(0), tab) <= TOL
+
+
+def test_status_after_a_non_chain_fill_is_clean():
+    """stb_fill_status refers to the LAST fill of the thread: a chain fill that gave up, followed by
+    a fill of another form in the same workspace, must not report (or read) the old header"""
+    T = capi.DeviceTables(3000, 3000, D=1)
+    T.fill([0.5], capi.FILL_CHAIN)
+    T.fill([0.5], capi.FILL_PC)
+    T.status()
+    T.fill([0.5], capi.FILL_LOGDOMAIN)
+    T.status()
+
+
+def test_set_device_is_recorded_by_tables():
+    """stb_set_device / stb_get_device: objects are created on the chosen GPU and keep using it"""
+    L = capi.lib()
+    n = L.stb_device_count()
+    assert L.stb_set_device(n) != 0 and b"stb_set_device" in L.stb_last_error()
+    assert L.stb_set_device(0) == 0
+    assert L.stb_get_device() == 0
+    t = capi.Table(300, 50, 300, 50, 0.5, capi.S_STABLE)
+    assert abs(t.S(300, 25) - orc.fill_S(0.5, 300, 50)[1][orc.row_offset(300, 50) + 23]) < 1e-9
+    prev = L.stb_device_enter(0)
+    L.stb_device_leave(prev)
+    t.free()

@@ -60,6 +60,64 @@ def test_aterms_vs_reference_golden(golden_dir, name):
         L.stb_groups_free(h)
 
 
+def test_config5_grid64_vs_reference(golden_dir):
+    """configs[4]: the 64-discount grid x 10^6 pairs in ONE call (the fused evaluation: the chain fill
+    sums count * log S itself) against the reference's aterms at all 64 discounts; then the same grid
+    through stored tables + gather (two-pass), which must agree with both."""
+    L = capi.lib()
+    spec = load(golden_dir, "aterms_grid64.json")["big_wide"]
+    g = groups_of(spec)
+    N, M = bounds(spec)
+    x = np.ascontiguousarray(synth.discount_grid(64))
+    assert [fh(v) for v in spec["x"]] == list(x)
+    want = np.array([fh(v) for v in spec["aterms"]])
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, 64)
+    assert h, capi.last_error()
+    try:
+        before = L.stb_fill_fallbacks()
+        out = np.zeros(64)
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 64, capi.dp(out)))
+        assert L.stb_fill_fallbacks() == before
+        assert orc.close(out, want, TOL), np.max(np.abs(out - want) / np.abs(want))
+    finally:
+        L.stb_groups_free(h)
+    os.environ["STB_ATERMS_FUSED"] = "0"
+    try:
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, 64)
+        assert h, capi.last_error()
+        two = np.zeros(64)
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 64, capi.dp(two)))
+        L.stb_groups_free(h)
+    finally:
+        os.environ.pop("STB_ATERMS_FUSED", None)
+    assert orc.close(two, want, TOL)
+    assert orc.close(two, out, 1e-12)
+
+
+def test_grid_at_10000_vs_reference(golden_dir):
+    """the bench's second metric at N=M=10000: 10^6 pairs with n < 10000 against four members of the
+    64-discount grid, evaluated as part of the full 64-point grid call"""
+    L = capi.lib()
+    spec = load(golden_dir, "aterms_grid64.json")["big10k_wide"]
+    g = groups_of(spec)
+    N, M = bounds(spec)
+    assert N == 10000
+    x = np.ascontiguousarray(synth.discount_grid(64))
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, 64)
+    assert h, capi.last_error()
+    try:
+        out = np.zeros(64)
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 64, capi.dp(out)))
+        for d, xs, want in zip(spec["d"], spec["x"], spec["aterms"]):
+            assert fh(xs) == x[d]
+            assert orc.close(out[d], fh(want), TOL), (d, out[d], fh(want))
+        one = np.zeros(1)
+        capi.check(L.stb_groups_aterms(h, capi.dp(x[31:32].copy()), 1, capi.dp(one)))   # stored table + gather
+        assert orc.close(one[0], fh(spec["aterms"][spec["d"].index(31)]), TOL)
+    finally:
+        L.stb_groups_free(h)
+
+
 def test_sweep_and_terms_separately_vs_oracle():
     O = orc.oracle()
     g = synth.groups(60, 50, 600, "wide")

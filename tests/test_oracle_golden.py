@@ -198,3 +198,46 @@ def test_identities():
         assert abs(S(600, 1) - (lgamma(600 - a) - lgamma(1 - a))) < 1e-9
         assert abs(S(3, 2) - log(3 - 3 * a)) < 1e-14
         assert S(5, 7) == -np.inf and S(5, 0) == -np.inf
+
+
+@pytest.mark.parametrize("d", [0, 63])
+def test_grid_table_config3(golden_dir, d):
+    """configs[2]: members of the 64-discount grid at N=M=10000 (two of the four fixtures here; the
+    GPU suite checks all four)."""
+    N = 10000
+    z = np.load(os.path.join(golden_dir, "stable_grid10k.npz"))
+    a = float(z[f"d{d}_a"][0])
+    assert a == float(synth.discount_grid(64)[d])
+    S1, tab = orc.fill_S(a, N, N)
+    rowsum = np.zeros(N + 1)
+    for n in range(3, N + 1):
+        o = orc.row_offset(n, N)
+        rowsum[n] = np.sum(tab[o:o + orc.row_len(n, N)])
+    assert orc.close(rowsum, z[f"d{d}_rowsum"], 1e-12)
+    for n in (N // 3, N):
+        o = orc.row_offset(n, N)
+        assert orc.close(tab[o:o + orc.row_len(n, N)], z[f"d{d}_row{n}"], 1e-13)
+    assert orc.close(S1, z[f"d{d}_S1"], 1e-13)
+    L = orc.oracle()
+    probes = [p for p in load_json(golden_dir, "stable_grid10k_probes.json") if p["d"] == d]
+    assert len(probes) > 40
+    for p in probes:
+        got = L.orc_S_S(orc.dp(tab), orc.dp(S1), N, N, p["n"], p["m"])
+        assert orc.close(got, fh(p["S"]), 1e-13), p
+
+
+def test_grid_aterms_config5(golden_dir):
+    """configs[4]: aterms on the 10^6-pair set at members of the 64-discount grid (every eighth here;
+    the GPU suite checks all 64)."""
+    L = orc.oracle()
+    spec = load_json(golden_dir, "aterms_grid64.json")["big_wide"]
+    assert spec["d"] == list(range(64))
+    g = _groups(spec)
+    N, M = spec["maxn"], spec["maxt"]
+    scratch = np.zeros(synth.cells(N, M) + N)
+    grid = synth.discount_grid(64)
+    for d in range(0, 64, 8):
+        assert fh(spec["x"][d]) == float(grid[d])
+        got = L.orc_aterms(float(grid[d]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
+                           orc.dp(g.bpar), N, M, orc.dp(scratch))
+        assert orc.close(got, fh(spec["aterms"][d]), 1e-13), d
