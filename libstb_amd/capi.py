@@ -19,7 +19,7 @@ from functools import lru_cache
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstb_amd.so")
+LIB_PATH = os.environ.get("STB_LIB_PATH") or os.path.join(_HERE, "lib", "libstb_amd.so")
 
 # flag bits of include/stable.h
 S_STABLE, S_UVTABLE, S_FLOAT, S_VERBOSE, S_QUITONBOUND, S_THREADS, S_ASYMPT = 1, 2, 4, 8, 16, 32, 64

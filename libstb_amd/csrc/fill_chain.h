@@ -26,6 +26,9 @@ struct chain_args {
   const unsigned *ent_cnt;     // DOT = 2: its occurrence count
   unsigned nsg;                // DOT = 2: slices per trip in item_ptr
   double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
+  unsigned long long *dbg;     // diagnostic builds (make stamp): hand-off timeline [block<160][trip<1280][4]
+  int mode;                    // diagnostic builds: 1 consumers only publish and release, 2 no table look-up,
+                               // 3 the producer does not write the ring (results are wrong in all three)
 };
 
 __device__ __forceinline__ int lds_peek(const int *p) {
@@ -40,16 +43,32 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
 }
 
 // the cold part of a bounded wait on an LDS counter, out of line so that the callers' row loops stay
-// straight-line code: returns false when the wait was given up (timeout, or another wave gave up)
+// straight-line code: returns false when the wait was given up (timeout, or another wave gave up).
+// The counter is polled every ~64 * nap cycles; the wall clock (an s_memrealtime round trip through
+// the scalar cache, hundreds of cycles) and the abort flag are looked at once per 64 polls only, so
+// that a waiter reacts within a fraction of a microsecond.
 __device__ __attribute__((noinline)) bool chain_wait_slow(const int *cnt, int need, int *abort_flag, unsigned *hdr,
                                                           unsigned long long timeout, unsigned code, unsigned who, int nap) {
-  const unsigned long long t_begin = wall_clock64();
+  unsigned long long t_begin = 0;
+  bool timing = false;
   for (;;) {
-    // (a spinning wave takes issue slots from the producer it shares a SIMD with)
-    for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(2);
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+    for (int k = 0; k < 64; k++) {
+      // (a spinning wave takes issue slots from the producer it shares a SIMD with)
+#ifdef STB_WAIT_NAP
+      for (int i = 0; i < nap * STB_WAIT_NAP; i++) __builtin_amdgcn_s_sleep(1);
+#else
+      for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
+#endif
+      if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+    }
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
-    if ((unsigned long long)wall_clock64() - t_begin > timeout) {
+    const unsigned long long now = wall_clock64();
+    if (!timing) {
+      timing = true;
+      t_begin = now;
+      if (timeout != 0) continue;
+    }
+    if (now - t_begin >= timeout) {
       if ((threadIdx.x & 63) == 0) {
         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {

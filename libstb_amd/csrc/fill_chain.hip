@@ -1,60 +1,114 @@
-// fill_chain.hip -- the chain forms: ONE launch per fill, column blocks keep their columns for all
-// rows and hand their right edge to the next block through 8-byte granules in HBM.
+// fill_chain.hip -- the chain forms: ONE launch per fill, column strips keep their columns for all
+// rows and hand their right edge to the next strip through 8-byte granules in HBM.
 //
-//   k_fill_chain   S table of S_remake_part (reference lib/stable.c:321-388), also as the DOT kernel
-//                  that sums count * log S for aterms (lib/samplea.c:68-80) without storing a table
+//   k_fill_chain   S table of S_remake_part's double-S branch (reference lib/stable.c:321-388); as a
+//                  DOT kernel it sums count * log S for aterms (lib/samplea.c:68-80) without storing
+//                  a table
 //   k_fillv_chain  V table (lib/stable.c:451-482), bit-identical to the reference
+//
+// k_fill_chain.  A workgroup owns a strip of W = 64*C*P columns for ALL rows of one table:
+//   * P producer waves carry the recurrence S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1} in the linear
+//     domain, C adjacent columns per lane sharing one exponent (block-floating cells, frozen for a
+//     period of rows, renormalised at its end); the left neighbour inside the wave comes through
+//     one DPP wave shift per row, the one across producer waves through the LDS ring, one trip
+//     behind.  Per row: 2 DPP moves, 1 multiply, C fma, C adds and the store of the C raw
+//     significands into an LDS ring of RD trips (a trip = 8 rows).
+//   * NC = MG*C*P consumer waves turn (trip, 64-column slice) items into logs -- exponent field + 7
+//     mantissa bits index a 128-entry table, degree-5 polynomial -- stage-major over the 8 rows, and
+//     store them: 512 contiguous bytes per row and wave.  A consumer hands its ring slot back as soon
+//     as the 8 x 64 significands are in its registers.
+//   * the consumer of the strip's LAST slice also publishes the strip's right edge: the raw double
+//     per row (8-byte granules, -0.0 for an exact zero, so that 0 means "not written yet") and the
+//     lane exponent per trip, write-through stores; a granule is its own flag.
+//   * NF fetcher waves poll the left neighbour strip's granules (128 rows per round trip,
+//     L1-bypassing loads) and deliver complete trips into an LDS ring for the first producer.
+// Waves meet through counters in LDS only (LDS executes a wave's instructions in order); a producer
+// reads everything a trip needs -- counters and its 8 left inputs -- one trip ahead, under the
+// previous trip's arithmetic, and takes one unlikely branch when a counter was short.
+//
+// Strips take (j, d) from an atomic ticket, j-major: a strip waits only for a strip with a smaller
+// ticket, i.e. one that is running or done, so progress does not depend on dispatch order or
+// residency.  Every wait is bounded; on expiry the strip records an error and runs to its end
+// (stb_fill_status, which then repeats the fill with k_fill_pc).
+//
+// DOT = 1 / 2: the logs are not stored but multiplied by the cell's occurrence count among the
+// (n,t) pairs and summed -- aterms' table part (lib/samplea.c:68-80) without a table in memory.
 
 #include <type_traits>
 
 #include "fill_chain.h"
 
-// ---- chain form: ONE launch per fill, column blocks hand their right edge to the next block ------
-//
-// The forms above advance every strip by R rows per launch and recompute an R-column halo so that
-// strips never talk to each other.  Here a column block owns its 64*P columns for ALL rows: what a
-// column needs from its left neighbour (one row up) travels wave to wave, so there is no halo, no
-// launch per row block and no frontier round trip.  Nothing in the steady state is a barrier: the
-// waves of a block run free and meet through counters in LDS.
-//
-//  * P producer waves, 64 columns each (one per lane, DPP shift inside the wave), carry the
-//    recurrence and write raw significands into an LDS ring of CH_RD trips (a trip = CH_U rows).
-//    Producer w reads the last column of producer w-1 from that ring, one trip behind it.
-//  * NC consumer waves take (trip, slice) items round-robin, turn 8 rows x 64 columns into logs
-//    (stage-major, as in k_fill_pc) and store them; they are off the producers' critical path.
-//  * The publisher wave writes the block's last column to global memory as 8-byte granules: the raw
-//    double per row (-0.0 for an exact zero, so that 0 = "not written yet") and the lane exponent
-//    per trip, with write-through stores.  The fetcher wave of the next block reads 128 rows per
-//    round trip with L1-bypassing loads, delivers the leading complete trips into an LDS ring and
-//    re-reads the rest.  A granule is its own flag (one aligned 8-byte store), so the hand-off needs
-//    no fence and no ordering.
-//
-// Block (d, j) starts at the trip in which the diagonal enters its first column and lags its left
-// neighbour by the hand-off latency; a triangular table starts column block j at row 64*P*j anyway.
-// Blocks take their (j, d) from an atomic ticket, j-major, so a block only ever waits for a block
-// with a smaller ticket, i.e. one that is running or done: forward progress does not depend on
-// dispatch order or on how many blocks are resident.  Every wait is bounded by wall-clock time; on
-// expiry the block records an error, stops waiting and runs to its end (stb_fill_status).
-// DOT: the logs are not stored; each is multiplied by the cell's occurrence count and summed (the
-// whole of aterms' table part, lib/samplea.c:68-80, without a table in memory or a second pass).
-//   DOT = 1: dense -- a count slab in the table's layout; every cell's log is computed.
-//   DOT = 2: sparse -- per (trip, 64-column slice) item the list of cells that occur at all
-//            (position in the 8 x 64 tile + count): only their logs are computed, empty items are
-//            skipped without even waiting for the producer.
-template <int P, int NC, int NF, int DOT>
-__global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args A, chain_args X) {
-  constexpr int U = CH_U, RD = CH_RD, RE = CH_RE;
-  constexpr int OW = 64 * P;  // columns of a block
-  static_assert(P >= 1 && P <= NC && NF >= 1 && P + NC + 1 + NF <= 16, "block shape");
+#define ST_U CH_U    // rows per trip
+#define ST_RE CH_RE  // trips in the edge ring
+
+// which wave does what: waves 0 .. P-1 produce; fetchers take the first later waves that share a
+// SIMD with a producer (waves go to SIMDs round-robin, and fetchers mostly sleep); the rest convert
+template <int WT, int P, int NF>
+struct chain_roles {
+  int role[16];  // 0 producer, 1 consumer, 2 fetcher
+  int idx[16];   // ordinal among the waves of the same role
+  constexpr chain_roles() : role{}, idx{} {
+    for (int w = 0; w < 16; w++) {
+      role[w] = 1;
+      idx[w] = 0;
+    }
+    for (int w = 0; w < P; w++) {
+      role[w] = 0;
+      idx[w] = w;
+    }
+    int nf = 0;
+    for (int w = P; w < WT && nf < NF; w++)
+      if ((w & 3) < P) {
+        role[w] = 2;
+        idx[w] = nf++;
+      }
+    for (int w = WT - 1; w >= P && nf < NF; w--)
+      if (role[w] == 1) {
+        role[w] = 2;
+        idx[w] = nf++;
+      }
+    int nc = 0;
+    for (int w = P; w < WT; w++)
+      if (role[w] == 1) idx[w] = nc++;
+  }
+};
+
+// waves per SIMD the register allocation must leave room for: two workgroups per compute unit where
+// two rings fit in LDS and the workgroup is small enough for that to cost no spills (with many
+// tables in flight a second resident strip per compute unit is what removes the tail of strips that
+// would otherwise wait for a free unit)
+constexpr int chain_min_waves(int C, int P, int MG, int NF, int RD) {
+  const int WT = P + MG * C * P + NF;
+  const bool two_fit = RD * ST_U * 64 * C * P * 8 + 8192 <= 80 * 1024;
+#ifdef STB_NO_MINW
+  return 1;
+#endif
+  return (two_fit && WT <= 10) ? (2 * WT + 3) / 4 : 1;
+}
+
+template <int C, int P, int MG, int NF, int DOT, int RD>
+__global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, MG, NF, RD)) void k_fill_chain(fill_args A,
+                                                                                                   chain_args X) {
+  constexpr int U = ST_U, RE = ST_RE;
+  constexpr int S = C * P;      // 64-column slices per strip
+  constexpr int NC = MG * S;    // consumer waves
+  constexpr int WP = 64 * C;    // columns of a producer wave
+  constexpr int W = WP * P;     // columns of a strip
+  constexpr int WT = P + NC + NF;
+  static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
+  static_assert(S <= 4 && WT <= 16 && NF >= 1 && MG >= 1 && (RD & (RD - 1)) == 0 && RD >= 2, "block shape");
   __shared__ double2 lt[128];
-  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][OW];
-  __shared__ int ebuf[4][OW];
-  __shared__ int slot_p[RD][P];
+  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][W];
+  __shared__ int ebuf[8][64 * P];  // lane exponent per period (ring of 8 periods), per producer lane
   __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
   __shared__ int edge_e[RE];
-  __shared__ int prod_done[P], cons_cnt[NC], pub_done, edge_ready, s_abort;
+  __shared__ __attribute__((aligned(16))) unsigned long long cons_cnt64[MG][2];
+  int(*cons_cnt)[4] = reinterpret_cast<int(*)[4]>(cons_cnt64);  // items done, per consumer [group][slice]
+  __shared__ int prod_done[P], edge_ready, s_abort;
+  __shared__ int post_pad[64];  // where lanes 1..63 of a producer's progress post go (see the producers)
   __shared__ unsigned s_ticket;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
   for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
@@ -65,337 +119,420 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
 
   const unsigned N = A.N, M = A.M;
   const int TP = X.TP, G = X.G;
-  const int c0 = 1 + j * OW;  // first column of the block
-  auto first_trip = [&](int w) {  // trip in which the diagonal reaches the first column of slice w
-    const int c = c0 + 64 * w;
+  const int c0 = 1 + j * W;  // first column of the strip
+  auto first_trip = [&](int sl) {  // trip in which the diagonal reaches the first column of slice sl
+    const int c = c0 + 64 * sl;
     return (c <= 3) ? 0 : (c - 3) / U;
   };
   const int g0b = first_trip(0);
   const bool has_left = j > 0, has_right = j < X.B - 1;
   double *table = A.tables + (uint64_t)d * A.tstride;
-  if (tid < P) prod_done[tid] = first_trip(tid);
-  if (tid < NC) cons_cnt[tid] = 0;
+  if (tid < MG * 4) (&cons_cnt[0][0])[tid] = 0;
+  if (tid < P) prod_done[tid] = first_trip(C * tid);
   if (tid == 0) {
-    pub_done = has_right ? first_trip(P - 1) : 0x7fffffff;
     edge_ready = has_left ? g0b : 0x7fffffff;
     s_abort = 0;
   }
   __syncthreads();
 
-  bool aborted = false;
-  // wait until *cnt >= need; bounded: on expiry (or when another wave gave up) stop waiting for good
-  auto wait_ge = [&](const int *cnt, int need, unsigned code) {
-    if (aborted || lds_peek(cnt) >= need) return;
-    const unsigned long long t_begin = wall_clock64();
-    for (;;) {
-      __builtin_amdgcn_s_sleep(1);
-      if (lds_peek(cnt) >= need) {
-        return;
-      }
-      if (lds_peek(&s_abort)) break;
-      if ((unsigned long long)wall_clock64() - t_begin > X.timeout) {
-        if (lane == 0) {
-          __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(X.hdr + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        break;
-      }
+  constexpr chain_roles<WT, P, NF> ROLES{};
+  int role = 1, ridx = 0;
+#pragma unroll
+  for (int w = 0; w < WT; w++)
+    if (wave == w) {
+      role = ROLES.role[w];
+      ridx = ROLES.idx[w];
     }
-    aborted = true;
+  const unsigned who = (unsigned)(j | (d << 16));
+  bool aborted = false;
+  auto wait_ge = [&](const int *cnt, int need, unsigned code, int nap) {
+    if (aborted || lds_peek(cnt) >= need) return;
+    if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, nap)) aborted = true;
   };
+  auto period_of = [&](int t) { return (TP == 1) ? t : (int)__umulhi((unsigned)t, X.tp_magic); };
 
-  if (wave < P) {
+  if (role == 0) {
     // ================= producers =================
+    // A lone wave issues an instruction every ~5 cycles (fp64: ~9) whatever its kind, so this loop is
+    // counted in instructions: what a trip needs from other waves -- three kinds of counters and its
+    // 8 left inputs -- is read while the previous trip is computed, and the rare cases sit behind one
+    // unlikely branch each.
     __builtin_amdgcn_s_setprio(3);
-    const int w = wave;
-    const int g0w = first_trip(w);
-    const int col = 64 * w + lane;  // my column inside the block
-    const int c = c0 + col;
+    const int w = (P == 1) ? 0 : ridx;  // (a compile-time constant for the one-producer shapes)
+    const int g0w = first_trip(C * w);
     const double a = A.a[d];
-    // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
-    double v = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
-    double coef = (double)(2 + g0w * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0w
+    const int colw = WP * w + lane * C;  // first of my C columns inside the strip
+    const int cl = c0 + colw;
+    double v[C], coef[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int c = cl + i;
+      // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
+      v[i] = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+      coef[i] = (double)(2 + g0w * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0w
+    }
     double s = 1.0;
     int ep = 1 + PC_BIAS;
     int p = g0w / TP, tin = g0w - p * TP;
-    // the consumer item that last used the ring slot a trip is about to overwrite
-    int chk_i = (g0w - RD - g0b) * P + w;
-    int chk_c = (chk_i >= 0) ? chk_i % NC : w, chk_k = (chk_i >= 0) ? chk_i / NC : 0;  // (first i >= 0 is w)
-    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w - 1];
-    const int *next_cnt = (w < P - 1) ? &prod_done[w + 1] : &pub_done;
-    // What a trip needs from the other waves -- the left neighbour's progress, the consumers' and
-    // the right neighbour's progress on the ring slot it overwrites -- and its U left inputs are
-    // read one trip AHEAD, under the previous trip's arithmetic, so that no LDS round trip sits on
-    // the row chain.  The inputs are speculative: they are valid if the counter read BEFORE them
-    // (LDS is in order) already covered the trip; otherwise wait and read again.
-    int n_left, n_cons, n_next;
-    double ne[U];
+    // the consumers that last read the ring slot a trip overwrites: trip g - RD, i.e. item kp = g - RD - g0b
+    // of the strip, which group q = kp % MG took as its (kp / MG)-th
+    int kp = g0w - RD - g0b, q = 0, qi = 0;
+    if (kp > 0) {
+      q = kp % MG;
+      qi = kp / MG;
+    }
+    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w > 0 ? w - 1 : 0];
+    const int *next_cnt = &prod_done[(w < P - 1) ? w + 1 : w];
+    int n_left, n_next = 0;
+    int nc[C];
+    // the progress post as ONE store of the whole wave: lane 0 writes the counter, the other lanes a
+    // scratch word each (no exec masking: two scalar instructions and a branch less per trip)
+    int *post_addr = (lane == 0) ? &prod_done[w] : &post_pad[lane];
+    auto peek_counters = [&](int qq) {
+      n_left = lds_peek(left_cnt);
+      if (w < P - 1) n_next = lds_peek(next_cnt);
+      // (the C counters of a group are adjacent: 8-byte LDS reads)
+      if (C >= 2) {
+#pragma unroll
+        for (int i = 0; i < C; i += 2) {
+          const unsigned long long c2 =
+              __hip_atomic_load(&cons_cnt64[qq][(C * w + i) / 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          nc[i] = (int)(unsigned)c2;
+          nc[(i + 1) % C] = (int)(unsigned)(c2 >> 32);
+        }
+      } else {
+        nc[0] = lds_peek(&cons_cnt[qq][w]);
+      }
+      asm volatile("" ::: "memory");
+    };
     auto load_left = [&](double(&x)[U], int g) {
       if (w == 0) {
+        // (separate 8-byte reads: each lands in the register pair the row's DPP shift then overwrites,
+        // which a 16-byte read's register tuple does not allow without two copies per row)
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&edge_in[(g & (RE - 1)) * U]);
 #pragma unroll
-        for (int u = 0; u < U; u++) x[u] = edge_in[(g & (RE - 1)) * U + u];
+        for (int u = 0; u < U; u++)
+          x[u] = __longlong_as_double((long long)__hip_atomic_load(src + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       } else {
-        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][64 * w - 1];
+        // the last column of the producer to my left: row U-1 of trip g-1, rows 0..U-2 of trip g
+        const int ecol = (w > 0) ? WP * w - 1 : 0;
+        const double *b1 = &vbuf[g & (RD - 1)][0][ecol];
+        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][ecol];
 #pragma unroll
-        for (int u = 1; u < U; u++) x[u] = vbuf[g & (RD - 1)][u - 1][64 * w - 1];
+        for (int u = 1; u < U; u++) x[u] = b1[(u - 1) * W];
       }
     };
-    auto look_ahead = [&](int g) {
-      n_left = lds_peek(left_cnt);
-      n_cons = lds_peek(&cons_cnt[chk_c]);
-      n_next = lds_peek(next_cnt);
-      asm volatile("" ::: "memory");
-      load_left(ne, g);
-    };
-    look_ahead(g0w);
-    for (int g = g0w; g < G; g++) {
-      double e[U];
+    auto counters_ok = [&](int g) {
+      bool ok = n_left >= g + 1;
+      if (kp >= 0) {
 #pragma unroll
-      for (int u = 0; u < U; u++) e[u] = ne[u];
-      const bool chk = chk_i >= 0;
-      const int next_need = (w < P - 1) ? g - RD + 2 : g - RD + 1;
-      if (n_left < g + 1 || (chk && (n_cons < chk_k + 1 || n_next < next_need))) {
-        wait_ge(left_cnt, g + 1, 0x100u + (unsigned)g);
-        if (chk) {
-          wait_ge(&cons_cnt[chk_c], chk_k + 1, 0x300u + (unsigned)g);  // slot g % RD converted
-          wait_ge(next_cnt, next_need, 0x400u + (unsigned)g);          // ... read by w+1 / published
-        }
-        asm volatile("" ::: "memory");
+        for (int i = 0; i < C; i++) ok = ok && nc[i] >= qi + 1;
+        // ... and the next producer has read its left inputs from it (rows of trip g - RD feed its
+        // trips g - RD and g - RD + 1)
+        if (w < P - 1) ok = ok && n_next >= g - RD + 2;
+      }
+      return ok;
+    };
+    // one trip: `e` holds its left inputs (read speculatively during the previous trip), `en`
+    // receives the next trip's
+    auto trip = [&](int g, double(&e)[U], double(&en)[U]) {
+      if (__builtin_expect(!counters_ok(g), 0)) {
+        // the counters were read a trip ago: look again (one LDS round trip) before settling down to wait
+        peek_counters(q);
         load_left(e, g);
-      }
-      if (chk) {
-        chk_c += P;
-        if (chk_c >= NC) {
-          chk_c -= NC;
-          chk_k++;
+        if (!counters_ok(g)) {
+          wait_ge(left_cnt, g + 1, 0x100u, 1);
+          if (kp >= 0) {
+#pragma unroll
+            for (int i = 0; i < C; i++) wait_ge(&cons_cnt[q][C * w + i], qi + 1, 0x300u, 1);  // slot g % RD converted
+            if (w < P - 1) wait_ge(next_cnt, g - RD + 2, 0x400u, 1);
+          }
+          asm volatile("" ::: "memory");
+          load_left(e, g);
         }
       }
-      chk_i += P;
-      if (g + 1 < G) look_ahead(g + 1);
-      if (g == g0w || tin == 0) {
+#ifdef STB_STAMPS
+      if (X.dbg && d == 0 && lane == 0 && w == 0 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 3] = wall_clock64();
+#endif
+      // the trip after this one: its slot was last read by item kp + 1
+      kp++;
+      if (kp > 0 && ++q == MG) {
+        q = 0;
+        qi++;
+      }
+      if (g + 1 < G) {
+        peek_counters(q);
+        load_left(en, g + 1);
+      }
+      if (__builtin_expect(g == g0w || tin == 0, 0)) {
         // ---- period set-up ----
-        if (g != g0w && v != 0.0) {  // renormalise: significand back to 2^-PC_BIAS * [0.5,1)
-          const int k = __builtin_amdgcn_frexp_exp(v);
-          v = ldexp(v, -k - PC_BIAS);
-          ep += k + PC_BIAS;
+        if (g != g0w) {  // renormalise: the lane's largest significand back to 2^-PC_BIAS * [0.5,1)
+          int kmax = -4000;
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+          if (kmax > -4000) {
+#pragma unroll
+            for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+            ep += kmax + PC_BIAS;
+          }
         }
         // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
         int el = ep;
         if (w == 0) {
           if (has_left) el = edge_e[g & (RE - 1)];
         } else {
-          el = ebuf[p & 3][64 * w - 1];
+          const int elane = (w > 0) ? 64 * w - 1 : 0;  // lane 63 of the producer to my left
+          el = ebuf[p & 7][elane];
           // the row above the first row of a period was produced under the previous exponent
-          if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 3][64 * w - 1] - el);
+          if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 7][elane] - el);
         }
         int dl = wave_shr1(ep, ep) - ep;
         if (lane == 0) dl = el - ep;
         s = ldexp(1.0, min(max(dl, -1100), 220));
-        ebuf[p & 3][col] = ep;
+        ebuf[p & 7][64 * w + lane] = ep;
       }
-      if (lane == 0) slot_p[g & (RD - 1)][w] = p & 3;
+      double *slot = &vbuf[g & (RD - 1)][0][colw];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const double t0 = wave_shr1(v, e[u]) * s;
-        v = fma(coef, v, t0);
-        coef += 1.0;
-        vbuf[g & (RD - 1)][u][col] = v;
+        const double t0 = wave_shr1(v[C - 1], e[u]) * s;
+#pragma unroll
+        for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+        v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+        for (int i = 0; i < C; i++) coef[i] += 1.0;
+#ifdef STB_STAMPS
+        if (X.mode == 3) continue;
+#endif
+        // (8-byte stores: the compiler pairs them into ds_write2_b64, whose two sources need not be
+        // adjacent registers as a 16-byte store's must)
+#pragma unroll
+        for (int i = 0; i < C; i++) slot[u * W + i] = v[i];
       }
-      lds_post(&prod_done[w], g + 1);
+#ifdef STB_STAMPS
+      if (X.dbg && d == 0 && lane == 0 && w == P - 1 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 0] = wall_clock64();
+#endif
+      asm volatile("" ::: "memory");
+      __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
       if (++tin == TP) {
         tin = 0;
         p++;
       }
+    };
+    double ea[U], eb[U];
+    peek_counters(q);
+    load_left(ea, g0w);
+    int g = g0w;
+    for (; g + 1 < G; g += 2) {
+      trip(g, ea, eb);
+      trip(g + 1, eb, ea);
     }
-  } else if (wave < P + NC) {
+    if (g < G) trip(g, ea, eb);
+  } else if (role == 1) {
     // ================= consumers =================
-    const int ci = wave - P;
-    int w = ci % P, t = g0b + ci / P;
-    int done = 0;
+    const int ci = ridx;
+    const int sl = ci % S, qg = ci / S;
+    const int wv = sl / C;           // the producer wave that owns the slice
+    const int col = 64 * sl + lane;  // my column inside the strip
+    const int cc = c0 + col;
+    const int coff = cc - 2;         // offset in a table row (column 1: the slack before the row)
+    const int ft = first_trip(sl);
+    const bool publisher = (sl == S - 1) && has_right;
+    unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
+    unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
     double acc = 0.0;  // (DOT) this lane's share of the sum
-    if (DOT == 2) {
-      // item (t, w) of block j is slice sg = j P + w of the table: its cells are item_ptr[idx] ..
-      // item_ptr[idx + 1] with idx = t * nsg + sg.  The range of the NEXT item is read while this
-      // one is processed (a wave-uniform load each).
-      auto item_range = [&](int tt, int ww, unsigned &b0, unsigned &b1) {
-        const unsigned idx = (unsigned)tt * X.nsg + (unsigned)(j * P + ww);
-        b0 = X.item_ptr[idx];
-        b1 = X.item_ptr[idx + 1];
-      };
-      unsigned nb = 0, ne = 0;
-      if (t < G) item_range(t, w, nb, ne);
-      for (; t < G;) {
-        const unsigned beg = nb, end = ne;
-        int w2 = w + NC % P, t2 = t + NC / P;
-        if (w2 >= P) {
-          w2 -= P;
-          t2++;
-        }
-        if (t2 < G) item_range(t2, w2, nb, ne);
-        if (beg != end && t >= first_trip(w)) {
-          // the first 64 entries can come in while we wait for the producer
-          unsigned k = beg + lane;
-          unsigned pos = (k < end) ? X.ent_pos[k] : 0u, c = (k < end) ? X.ent_cnt[k] : 0u;
-          wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
-          const int slot = t & (RD - 1);
-          const int pidx = ((TP == 1) ? t : (int)__umulhi((unsigned)t, X.tp_magic)) & 3;  // period of trip t
-          for (;;) {
-            const int col = 64 * w + (int)(pos & 63u);
-            const double val = bfp_log(vbuf[slot][pos >> 6][col], ebuf[pidx][col], lt);
-            acc += (c != 0) ? (double)c * val : 0.0;
-            if (k - lane + 64 >= end) break;  // (wave-uniform)
-            k += 64;
-            pos = (k < end) ? X.ent_pos[k] : 0u;
-            c = (k < end) ? X.ent_cnt[k] : 0u;
-          }
-        }
-        done++;
-        lds_post(&cons_cnt[ci], done);
-        w = w2;
-        t = t2;
+    int k = 0;
+#ifdef STB_STAMPS
+    unsigned long long c_wait = 0, c_items = 0;
+    const unsigned long long c_begin = wall_clock64();
+#endif
+    // (DOT = 2) the cells of item (t, sl) are item_ptr[idx] .. item_ptr[idx + 1], idx = t * nsg + slice of the table
+    unsigned nb = 0, ne = 0;
+    auto item_range = [&](int tt, unsigned &b0, unsigned &b1) {
+      const unsigned idx = (unsigned)tt * X.nsg + (unsigned)(j * S + sl);
+      b0 = X.item_ptr[idx];
+      b1 = X.item_ptr[idx + 1];
+    };
+    if (DOT == 2 && g0b + qg < G) item_range(g0b + qg, nb, ne);
+    for (int t = g0b + qg; t < G; t += MG, k++) {
+      unsigned beg = 0, end = 0;
+      if (DOT == 2) {
+        beg = nb;
+        end = ne;
+        if (t + MG < G) item_range(t + MG, nb, ne);
       }
-    }
-    for (; t < G;) {
-      if (t >= first_trip(w)) {
-        wait_ge(&prod_done[w], t + 1, 0x600u + (unsigned)t);
-        const int ridx = 64 * w + lane;
-        const int cc = c0 + ridx;
-        const int coff = cc - 2;  // offset in a table row (column 1: the slack before the row)
+#ifdef STB_STAMPS
+      const bool live = t >= ft && (DOT != 2 || beg != end) && X.mode != 1;
+#else
+      const bool live = t >= ft && (DOT != 2 || beg != end);
+#endif
+      if (live || (publisher && t >= ft)) {
+        unsigned pos = 0, cnt2 = 0;
+        if (DOT == 2 && live) {  // the first 64 entries can come in while we wait for the producer
+          const unsigned kk = beg + lane;
+          pos = (kk < end) ? X.ent_pos[kk] : 0u;
+          cnt2 = (kk < end) ? X.ent_cnt[kk] : 0u;
+        }
+#ifdef STB_STAMPS
+        const unsigned long long tc0 = wall_clock64();
+#endif
+        wait_ge(&prod_done[wv], t + 1, 0x600u, 1);
+#ifdef STB_STAMPS
+        const unsigned long long tc1 = wall_clock64();
+        c_wait += tc1 - tc0;
+        c_items++;
+#endif
         const int slot = t & (RD - 1);
-        const int myep = ebuf[slot_p[slot][w]][ridx];
-        const int r0 = 3 + t * U;
-        const unsigned pitch = stb_row_pitch((unsigned)r0, M);
-        const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch &&
-                          !(j == 0 && t == 0 && w == 0);
-        const uint64_t rowoff = stb_row_offset((unsigned)r0, M);
-        double *rowbase = table + rowoff;
-        const unsigned *cntbase = X.cnt + rowoff;
-        if (fast) {
-          double x[U], z[U], kf[U], r[U], pl[U];
-          double2 tt[U];
+        const int pidx = period_of(t) & 7;
+        if (publisher) {
+          // the strip's last column, rows of trip t (lanes 0..7), and its lane exponent (lane 8)
+          if (lane <= U) {
+            unsigned long long b;
+            unsigned long long *dst;
+            if (lane < U) {
+              b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][W - 1]);
+              if ((b << 1) == 0) b = CH_NEGZERO;
+              dst = ev_out + 3 + t * U + lane;
+            } else {
+              b = (unsigned long long)((long long)ebuf[pidx][64 * P - 1] + (long long)CH_EOFF);
+              dst = ee_out + t;
+            }
+            __hip_atomic_store(dst, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#ifdef STB_STAMPS
+          if (X.dbg && d == 0 && lane == 0 && j < 160 && t < 1280) X.dbg[((size_t)j * 1280 + t) * 4 + 1] = wall_clock64();
+#endif
+        }
+        if (live && DOT == 2) {
+          unsigned kk = beg + lane;
+          for (;;) {
+            const int cx = 64 * sl + (int)(pos & 63u);
+            const double val = bfp_log(vbuf[slot][pos >> 6][cx], ebuf[pidx][cx / C], lt);
+            acc += (cnt2 != 0) ? (double)cnt2 * val : 0.0;
+            if (kk - lane + 64 >= end) break;  // (wave-uniform)
+            kk += 64;
+            pos = (kk < end) ? X.ent_pos[kk] : 0u;
+            cnt2 = (kk < end) ? X.ent_cnt[kk] : 0u;
+          }
+          lds_post(&cons_cnt[qg][sl], k + 1);
+        } else if (live) {
+          const int myep = ebuf[pidx][col / C];
+          const int r0 = 3 + t * U;
+          const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+          const bool fast = (unsigned)(r0 + U - 1) <= N && stb_row_pitch((unsigned)(r0 + U - 1), M) == pitch &&
+                            !(j == 0 && t == 0 && sl == 0);
+          const uint64_t rowoff = stb_row_offset((unsigned)r0, M);
+          double *rowbase = table + rowoff;
+          const unsigned *cntbase = X.cnt + rowoff;
+          double x[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) x[u] = vbuf[slot][u][col];
           unsigned cn[U];
-          if (DOT == 1) {
+          if (DOT == 1 && fast) {
 #pragma unroll
             for (int u = 0; u < U; u++) cn[u] = cntbase[(size_t)u * pitch + coff];
           }
+          // the significands are in registers: the ring slot may be overwritten
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          lds_post(&cons_cnt[qg][sl], k + 1);
+          if (fast) {
+            double z[U], kf[U], r[U], pl[U];
+            double2 tt[U];
+#ifdef STB_STAMPS
+            if (X.mode == 2) {
 #pragma unroll
-          for (int u = 0; u < U; u++) x[u] = vbuf[slot][u][ridx];
+              for (int u = 0; u < U; u++) tt[u] = make_double2(0.75 + 1e-3 * u, 0.3 + 1e-3 * lane);
+            } else
+#endif
+            {
 #pragma unroll
-          for (int u = 0; u < U; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+              for (int u = 0; u < U; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+            }
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            const int hi = __double2hiint(x[u]);
-            z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
-            kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
-          }
+            for (int u = 0; u < U; u++) {
+              const int hi = __double2hiint(x[u]);
+              z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+              kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+            }
 #pragma unroll
-          for (int u = 0; u < U; u++) r[u] = fma(z[u], tt[u].x, -1.0);
+            for (int u = 0; u < U; u++) r[u] = fma(z[u], tt[u].x, -1.0);
 #pragma unroll
-          for (int u = 0; u < U; u++) pl[u] = fma(r[u], 0.2, -0.25);
+            for (int u = 0; u < U; u++) pl[u] = fma(r[u], 0.2, -0.25);
 #pragma unroll
-          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+            for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
 #pragma unroll
-          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], -0.5);
+            for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], -0.5);
 #pragma unroll
-          for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0);
+            for (int u = 0; u < U; u++) pl[u] = fma(r[u], pl[u], 1.0);
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            const double val = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
-            if (DOT) {
-              // (cells outside the table proper -- the row slack -- have count 0 and may hold anything)
-              acc += (cn[u] != 0) ? (double)cn[u] * val : 0.0;
-            } else {
-              rowbase[(size_t)u * pitch + coff] = val;
+            for (int u = 0; u < U; u++) {
+              const double val = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+              if (DOT) {
+                // (cells outside the table proper -- the row slack -- have count 0 and may hold anything)
+                acc += (cn[u] != 0) ? (double)cn[u] * val : 0.0;
+              } else {
+                rowbase[(size_t)u * pitch + coff] = val;
+              }
+            }
+          } else {
+#pragma unroll 1
+            for (int u = 0; u < U; u++) {
+              const int rr = r0 + u;
+              if ((unsigned)rr <= N && cc >= 2) {
+                const double val = bfp_log(x[u], myep, lt);
+                if (DOT) {
+                  const unsigned c = cntbase[coff];
+                  acc += (c != 0) ? (double)c * val : 0.0;
+                } else {
+                  rowbase[coff] = val;
+                }
+              }
+              const unsigned pt = stb_row_pitch((unsigned)rr, M);
+              rowbase += pt;
+              cntbase += pt;
             }
           }
         } else {
-          for (int u = 0; u < U; u++) {
-            const int rr = r0 + u;
-            if ((unsigned)rr <= N && cc >= 2) {
-              const double val = bfp_log(vbuf[slot][u][ridx], myep, lt);
-              if (DOT) {
-                const unsigned c = cntbase[coff];
-                acc += (c != 0) ? (double)c * val : 0.0;
-              } else {
-                rowbase[coff] = val;
-              }
-            }
-            const unsigned pt = stb_row_pitch((unsigned)rr, M);
-            rowbase += pt;
-            cntbase += pt;
-          }
+          lds_post(&cons_cnt[qg][sl], k + 1);  // (only published)
         }
-      }
-      done++;
-      lds_post(&cons_cnt[ci], done);
-      w += NC % P;
-      t += NC / P;
-      if (w >= P) {
-        w -= P;
-        t++;
+      } else {
+        lds_post(&cons_cnt[qg][sl], k + 1);  // nothing to do for this item
       }
     }
+#ifdef STB_STAMPS
+    if (X.dbg && d == 0 && lane == 0 && j < 160) {  // per consumer wave: items, ticks waited for the producer, ticks in all
+      unsigned long long *o = X.dbg + (size_t)160 * 1280 * 4 + (size_t)160 * 8 * 4 + ((size_t)j * 16 + ci) * 4;
+      o[0] = c_items;
+      o[1] = c_wait;
+      o[2] = wall_clock64() - c_begin;
+      o[3] = 1;
+    }
+#endif
     if (DOT) {
       // fixed-shape tree over the wave: the same bits on every run
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) X.dotp[((uint64_t)d * X.B + j) * NC + ci] = acc;
     }
-  } else if (wave == P + NC) {
-    // ================= publisher =================
-    if (has_right) {
-      __builtin_amdgcn_s_setprio(2);
-      unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
-      unsigned long long *ee_out = X.edge_e + ((uint64_t)d * X.B + j) * X.NP;
-      const int t_first = first_trip(P - 1);
-      int pp = t_first / TP, ptin = t_first - pp * TP;  // period of trip t, tracked without dividing
-      for (int t = t_first; t < G; t++) {
-        // (latency matters here, not issue slots: spin without sleeping)
-        if (!aborted) {
-          const unsigned long long t_begin = wall_clock64();
-          while (lds_peek(&prod_done[P - 1]) < t + 1) {
-            if (lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
-              wait_ge(&prod_done[P - 1], t + 1, 0x700u + (unsigned)t);  // (records the failure)
-              break;
-            }
-          }
-        }
-        const int slot = t & (RD - 1);
-        if (lane < U) {
-          unsigned long long b = (unsigned long long)__double_as_longlong(vbuf[slot][lane][OW - 1]);
-          if ((b << 1) == 0) b = CH_NEGZERO;
-          __hip_atomic_store(ev_out + 3 + t * U + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == U) {
-          const long long ex = (long long)ebuf[pp & 3][OW - 1] + (long long)CH_EOFF;
-          __hip_atomic_store(ee_out + t, (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lds_post(&pub_done, t + 1);
-        if (++ptin == TP) {
-          ptin = 0;
-          pp++;
-        }
-      }
-    }
   } else {
-    // ================= fetchers (waves P+NC+1 ..) =================
+    // ================= fetchers =================
     if (has_left) {
       const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
       const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (j - 1)) * X.NP;
       unsigned long long t_begin = 0;
       bool timing = false;
+      unsigned idle = 0;
       for (int t = g0b; t < G;) {
         // (NF fetcher waves run this same loop out of step: each delivers what its own load found
         // complete beyond what has been delivered already, so the polling period divides by NF)
         t = max(t, lds_peek(&edge_ready));
         if (t >= G) break;
-        // trips t .. t+nt-1 may be written: their ring slots were read by the first producer
-        int lim = lds_peek(&prod_done[0]) + RE;
+        // trips t .. t+nt-1 may be written: their ring slots were read by the producer
+        int lim = lds_peek(&prod_done[0]) + RE - 1;
         if (lim > G) lim = G;
         if (lim <= t) {
-          wait_ge(&prod_done[0], t - RE + 1, 0x800u + (unsigned)t);
+          wait_ge(&prod_done[0], t - RE + 2, 0x800u, 2);
           if (aborted) break;
           continue;
         }
@@ -418,26 +555,32 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
           if ((rows & 0xffull) != 0xffull || ((me >> nr) & 3ull) != 3ull) break;
         }
         if (nr == 0) {
+          // nothing new: poll again shortly; the clock, the error word and the abort flag (a scalar-cache
+          // and a memory round trip) are looked at once per 32 fruitless polls only
+          if ((++idle & 31) != 0 && X.timeout != 0) {
+            __builtin_amdgcn_s_sleep(2);  // (a spinning wave takes issue slots from the producer on its SIMD)
+            continue;
+          }
           if (!timing) {
             timing = true;
             t_begin = wall_clock64();
           }
           const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin > X.timeout) {
+          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
             if (lane == 0) {
               __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               if (err == 0) {
-                __hip_atomic_store(X.hdr + 2, (unsigned)(j | (d << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(X.hdr + 1, 0x900u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
             }
             lds_post(&edge_ready, 0x7fffffff);  // release the producer: it runs on with stale edges
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
           continue;
         }
         timing = false;
+        idle = 0;
         // exponent of each row's trip (lane q of ve holds trip t-1+q) and of the trip before it
         const int ex = (int)(long long)(ve - CH_EOFF);
         const int ka = lane >> 3, kb = 8 + (lane >> 3);
@@ -453,6 +596,9 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
         if (ka < nr && t + ka >= cur) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
         if (kb < nr && t + kb >= cur) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
         if (lane >= 1 && lane <= nr && t - 1 + lane >= cur) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+#ifdef STB_STAMPS
+        if (X.dbg && d == 0 && lane < nr && j < 160 && t + lane < 1280) X.dbg[((size_t)j * 1280 + t + lane) * 4 + 2] = wall_clock64();
+#endif
         t += nr;
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_max(&edge_ready, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -461,6 +607,7 @@ __global__ __launch_bounds__(64 * (P + NC + 1 + NF)) void k_fill_chain(fill_args
     }
   }
 }
+
 
 // ---- chain form of the V-table fill (lib/stable.c:451-482) ------------------------
 //
@@ -669,38 +816,167 @@ __global__ __launch_bounds__(64 * (P + 2)) void k_fillv_chain(fill_args A, chain
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side: geometry, workspace, launches
+// host side
 
-// geometry of k_fill_chain: column blocks per table, trips, edge stream lengths
 struct chain_geom {
-  int P, NC, NF, B, G;
+  int C, P, MG, NF, RD, B, G;
   uint64_t EV, NP;
   size_t bytes;  // header + edge streams for D tables
 };
+
 static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   chain_geom g;
-  // block shape: up to ~5 tables of 10^4 columns narrower blocks on more compute units win (the
-  // fill is a latency chain), with three fetcher waves to shorten the hand-off; for more tables in
-  // flight wider blocks with fewer hand-offs do
-  const bool narrow = (uint64_t)D * M <= 50000;
-  g.P = stb_env_int("STB_CHAIN_P", narrow ? 2 : 4);
-  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = narrow ? 2 : 4;
-  g.NC = stb_env_int("STB_CHAIN_NC", g.P == 4 ? 10 : g.P == 2 ? 6 : 3);
-  if (g.NC < g.P) g.NC = g.P;
-  g.NF = stb_env_int("STB_CHAIN_NF", narrow ? 3 : 1);
+  // strip shape by batch: 128-column strips on many compute units while the fill is a latency chain
+  // (few tables: time = rows x row time of a strip + strips x hand-off, and a producer wave's row time
+  // grows with its columns), 256-column strips -- half the hand-offs, fewer producer instructions per
+  // cell -- beyond.  Measured on MI355X, N = M = 10^4: one table 0.82 ms with 128 columns against 1.0
+  // with 256; eight tables 1.25 ms with 256 against 1.5 with 128.
+  const uint64_t cols = (uint64_t)D * M;
+  const bool few = cols <= (uint64_t)stb_env_int("STB_CHAIN_NARROW_COLS", 50000);
+  g.C = stb_env_int("STB_CHAIN_C", few ? 2 : 4);
+  if (g.C != 1 && g.C != 2 && g.C != 4) g.C = few ? 2 : 4;
+  g.P = stb_env_int("STB_CHAIN_P", 1);
+  if (g.P != 1 && g.P != 2 && g.P != 4) g.P = 1;
+  if (g.C * g.P > 4) g.P = 4 / g.C;
+  g.MG = stb_env_int("STB_CHAIN_MG", 3);
+  if (g.MG < 1) g.MG = 1;
+  if (g.MG > 3) g.MG = 3;
+  if (g.P + g.MG * g.C * g.P + 1 > 16) g.MG = 2;
+  g.NF = stb_env_int("STB_CHAIN_NF", 1);
   if (g.NF < 1) g.NF = 1;
   if (g.NF > 3) g.NF = 3;
-  if (g.NF == 2) g.NF = 3;  // (compiled shapes have one or three fetchers)
-  if (g.P + g.NC + 1 + g.NF > 16) g.NF = 1;
-  if (g.P + g.NC + 1 + g.NF > 16) g.NC = 15 - g.NF - g.P;
-  const unsigned cols = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
-  g.B = (int)((cols + 64 * g.P - 1) / (64 * g.P));
+  g.RD = stb_env_int("STB_CHAIN_RD", g.P > 1 ? 8 : 4);
+  if (g.RD != 2 && g.RD != 4 && g.RD != 8) g.RD = 4;
+  const unsigned c = (M < N - 1) ? M : N - 1;  // columns 1..min(M, N-1) hold stored cells
+  const unsigned W = 64u * g.C * g.P;
+  g.B = (int)((c + W - 1) / W);
   if (g.B < 1) g.B = 1;
-  g.G = (N > 2) ? (int)((N - 2 + CH_U - 1) / CH_U) : 0;
-  g.EV = (uint64_t)3 + (uint64_t)g.G * CH_U + 136;  // the fetcher reads 128 rows at a time
+  g.G = (N > 2) ? (int)((N - 2 + ST_U - 1) / ST_U) : 0;
+  g.EV = (uint64_t)3 + (uint64_t)g.G * ST_U + 136;  // the fetcher reads 128 rows at a time
   g.NP = (uint64_t)g.G + 24;                        // ... and 17 trip exponents
   g.bytes = 256 + (size_t)D * g.B * (g.EV + g.NP) * sizeof(unsigned long long);
   return g;
+}
+
+static size_t chain_s_workspace(unsigned N, unsigned M, int D) {
+  if (N < 3 || M < 2 || D < 1) return 0;
+  // (the strip width is a tunable: size for the narrowest, which has the most strips)
+  chain_geom g = chain_geometry(N, M, D);
+  const unsigned c = (M < N - 1) ? M : N - 1;
+  const size_t Bmax = (c + 63) / 64;
+  return 256 + (size_t)D * Bmax * (g.EV + g.NP) * sizeof(unsigned long long) + 256;
+}
+
+int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out) {
+  const chain_geom g = chain_geometry(N, M, D);
+  if (W_out) *W_out = 64 * g.C * g.P;
+  return 0;
+}
+
+#ifdef STB_STAMPS
+static unsigned long long *g_chain_dbg = nullptr;
+#endif
+
+int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out,
+                     hipStream_t st) {
+  const unsigned N = A.N, M = A.M;
+  const chain_geom sg = chain_geometry(N, M, D);
+  int Pc = stb_period_rows(N);
+  const int Penv = stb_env_int("STB_FILL_P", 0);
+  if (Penv > 0 && Penv < Pc) Pc = Penv;
+  chain_args X;
+  memset(&X, 0, sizeof(X));
+  X.TP = Pc / ST_U;
+  if (X.TP < 1) return stb_fail("stb_fill_S: renormalisation period %d shorter than a trip", Pc);
+  if (sg.RD > 2 * X.TP + 2) return stb_fail("stb_fill_S: ring of %d trips too deep for periods of %d trips", sg.RD, X.TP);
+  X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
+  X.G = sg.G;
+  X.D = D;
+  X.B = sg.B;
+  X.EV = sg.EV;
+  X.NP = sg.NP;
+  if (sg.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the chain form");
+  X.hdr = (unsigned *)ws;
+  X.edge_e = (unsigned long long *)(ws + 256);
+  X.edge_v = X.edge_e + (size_t)D * sg.B * X.NP;
+  X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
+  HIPCHK(hipMemsetAsync(ws, 0, stb_align_up(sg.bytes, 16), st));
+  *hdr_out = X.hdr;
+  stb_launch_s1(A, D, st);
+  X.cnt = dot ? dot->cnt : nullptr;
+  X.item_ptr = dot ? dot->item_ptr : nullptr;
+  X.ent_pos = dot ? dot->ent_pos : nullptr;
+  X.ent_cnt = dot ? dot->ent_cnt : nullptr;
+  X.nsg = dot ? dot->nsg : 0;
+  X.dotp = dot ? dot->dotp : nullptr;
+  if (dot) const_cast<dot_request *>(dot)->parts_per_table = sg.B * sg.MG * sg.C * sg.P;
+  const int dk = !dot ? 0 : (dot->item_ptr ? 2 : 1);
+#ifdef STB_STAMPS
+  X.dbg = nullptr;
+  X.mode = stb_env_int("STB_CHAIN_DEBUG", 0);
+  if (getenv("STB_TIMELINE_FILE")) {
+    if (!g_chain_dbg) HIPCHK(hipMalloc(&g_chain_dbg, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4)));
+    HIPCHK(hipMemsetAsync(g_chain_dbg, 0, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4), st));
+    X.dbg = g_chain_dbg;
+  }
+#endif
+  const dim3 grid((unsigned)sg.B * (unsigned)D);
+#define STRIP1(CC, PP, MM, FF, DD, RR) \
+  STB_LAUNCH((k_fill_chain<CC, PP, MM, FF, DD, RR>), grid, dim3(64 * (PP + MM * CC * PP + FF)), st, A, X)
+#define STRIP(CC, PP, MM, FF, RR)                   \
+  do {                                              \
+    if (dk == 2) STRIP1(CC, PP, MM, FF, 2, RR);     \
+    else if (dk == 1) STRIP1(CC, PP, MM, FF, 1, RR); \
+    else STRIP1(CC, PP, MM, FF, 0, RR);             \
+  } while (0)
+  const int shape = sg.C * 10000 + sg.P * 1000 + sg.MG * 100 + sg.NF * 10 + sg.RD;
+  // (the summing variants are compiled for the two default strip shapes only)
+  if (dk != 0 && shape != 21314 && shape != 41314)
+    return stb_fail("stb_fill_S: the fused evaluation needs a default strip shape (unset STB_CHAIN_C / _P / _MG / _NF / _RD)");
+  switch (shape) {
+    case 21314: STRIP(2, 1, 3, 1, 4); break;  // few tables
+    case 41314: STRIP(4, 1, 3, 1, 4); break;  // several
+    case 21324: STRIP1(2, 1, 3, 2, 0, 4); break;
+    case 21318: STRIP1(2, 1, 3, 1, 0, 8); break;
+    case 41214: STRIP1(4, 1, 2, 1, 0, 4); break;
+    case 41114: STRIP1(4, 1, 1, 1, 0, 4); break;
+    case 11314: STRIP1(1, 1, 3, 1, 0, 4); break;
+    case 12328: STRIP1(1, 2, 3, 2, 0, 8); break;
+    case 14228: STRIP1(1, 4, 2, 2, 0, 8); break;
+    case 22218: STRIP1(2, 2, 2, 1, 0, 8); break;
+    default:
+      return stb_fail("stb_fill_S: no chain kernel for C=%d P=%d MG=%d NF=%d RD=%d", sg.C, sg.P, sg.MG, sg.NF, sg.RD);
+  }
+#undef STRIP
+#undef STRIP1
+  HIPCHK(hipGetLastError());
+#ifdef STB_STAMPS
+  if (X.dbg) {
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t cnt = (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4;
+    unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
+    HIPCHK(hipMemcpy(h, X.dbg, cnt * sizeof(*h), hipMemcpyDeviceToHost));
+    FILE *f = fopen(getenv("STB_TIMELINE_FILE"), "w");
+    for (int jj = 0; jj < 160; jj++)
+      for (int t = 0; t < 1280; t++) {
+        unsigned long long *q = h + ((size_t)jj * 1280 + t) * 4;
+        if (q[0] | q[1] | q[2] | q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, t, q[0], q[1], q[2], q[3]);
+      }
+    for (int jj = 0; jj < 160; jj++)
+      for (int ww = 0; ww < 8; ww++) {  // per producer wave: re-looks, waits, waits on the left input, ticks waited
+        unsigned long long *q = h + (size_t)160 * 1280 * 4 + ((size_t)jj * 8 + ww) * 4;
+        if (q[0] | q[1] | q[2] | q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, 100000 + ww, q[0], q[1], q[2], q[3]);
+      }
+    for (int jj = 0; jj < 160; jj++)
+      for (int ww = 0; ww < 16; ww++) {
+        unsigned long long *q = h + (size_t)160 * 1280 * 4 + (size_t)160 * 8 * 4 + ((size_t)jj * 16 + ww) * 4;
+        if (q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, 200000 + ww, q[0], q[1], q[2], q[3]);
+      }
+    fclose(f);
+    free(h);
+  }
+#endif
+  return 0;
 }
 
 // geometry of k_fillv_chain
@@ -722,92 +998,17 @@ static vchain_geom vchain_geometry(unsigned N, unsigned M, int D) {
   return g;
 }
 
+
 // bytes of workspace the chain forms need for D tables (S or V)
 size_t stb_chain_workspace(unsigned N, unsigned M, int D) {
   if (N < 2 || M < 2 || D < 1) return 0;
-  const size_t s = (N >= 3) ? chain_geometry(N, M, D).bytes : 0;
+  const size_t s = chain_s_workspace(N, M, D);
   const size_t v = vchain_geometry(N, M, D).bytes;
   return (s > v ? s : v) + 256;
 }
 
-int stb_chain_tuning(unsigned N, unsigned M, int D, int *P_out) {
-  const chain_geom g = chain_geometry(N, M, D);
-  if (P_out) *P_out = g.P;
-  return 0;
-}
-
 static unsigned long long chain_timeout_ticks() {
   return (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
-}
-
-// S tables.  ws: 256-byte aligned scratch of at least stb_chain_workspace bytes, zeroed here.
-int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out,
-                     hipStream_t st) {
-  const unsigned N = A.N, M = A.M;
-  const chain_geom cg = chain_geometry(N, M, D);
-  int Pc = stb_period_rows(N);
-  const int Penv = stb_env_int("STB_FILL_P", 0);
-  if (Penv > 0 && Penv < Pc) Pc = Penv;
-  chain_args X;
-  X.TP = Pc / CH_U;
-  if (X.TP < 1) return stb_fail("stb_fill_S: renormalisation period %d shorter than a trip", Pc);
-  X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
-  X.G = cg.G;
-  X.D = D;
-  X.B = cg.B;
-  X.EV = cg.EV;
-  X.NP = cg.NP;
-  if (cg.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the chain form");
-  X.hdr = (unsigned *)ws;
-  X.edge_e = (unsigned long long *)(ws + 256);
-  X.edge_v = X.edge_e + (size_t)D * cg.B * X.NP;
-  X.timeout = chain_timeout_ticks();
-  HIPCHK(hipMemsetAsync(ws, 0, stb_align_up(cg.bytes, 16), st));
-  *hdr_out = X.hdr;
-  stb_launch_s1(A, D, st);
-  const dim3 grid((unsigned)cg.B * (unsigned)D);
-  X.cnt = dot ? dot->cnt : nullptr;
-  X.item_ptr = dot ? dot->item_ptr : nullptr;
-  X.ent_pos = dot ? dot->ent_pos : nullptr;
-  X.ent_cnt = dot ? dot->ent_cnt : nullptr;
-  X.nsg = dot ? dot->nsg : 0;
-  X.dotp = dot ? dot->dotp : nullptr;
-  if (dot) const_cast<dot_request *>(dot)->parts_per_table = cg.B * cg.NC;
-  const int dk = !dot ? 0 : (dot->item_ptr ? 2 : 1);
-#define CHAIN1(PP, NN, FF, DD) STB_LAUNCH((k_fill_chain<PP, NN, FF, DD>), grid, dim3(64 * (PP + NN + 1 + FF)), st, A, X)
-#define CHAIN(PP, NN, FF)                 \
-  do {                                    \
-    if (dk == 2) CHAIN1(PP, NN, FF, 2);   \
-    else if (dk == 1) CHAIN1(PP, NN, FF, 1); \
-    else CHAIN1(PP, NN, FF, 0);           \
-  } while (0)
-  const int shape = cg.P * 1000 + cg.NC * 10 + cg.NF;
-  // (the summing variants are compiled for the two default block shapes only)
-  if (dk != 0 && shape != 2063 && shape != 4101)
-    return stb_fail("stb_fill_S: the fused evaluation needs a default block shape (unset STB_CHAIN_P / _NC / _NF)");
-  switch (shape) {
-    case 2063: CHAIN(2, 6, 3); break;
-    case 4101: CHAIN(4, 10, 1); break;
-    case 1031: CHAIN1(1, 3, 1, 0); break;
-    case 1033: CHAIN1(1, 3, 3, 0); break;
-    case 1061: CHAIN1(1, 6, 1, 0); break;
-    case 1063: CHAIN1(1, 6, 3, 0); break;
-    case 2041: CHAIN1(2, 4, 1, 0); break;
-    case 2043: CHAIN1(2, 4, 3, 0); break;
-    case 2061: CHAIN1(2, 6, 1, 0); break;
-    case 2081: CHAIN1(2, 8, 1, 0); break;
-    case 2083: CHAIN1(2, 8, 3, 0); break;
-    case 4061: CHAIN1(4, 6, 1, 0); break;
-    case 4063: CHAIN1(4, 6, 3, 0); break;
-    case 4081: CHAIN1(4, 8, 1, 0); break;
-    case 4083: CHAIN1(4, 8, 3, 0); break;
-    default:
-      return stb_fail("stb_fill_S: no chain kernel for %d producers / %d consumers / %d fetchers", cg.P, cg.NC, cg.NF);
-  }
-#undef CHAIN
-#undef CHAIN1
-  HIPCHK(hipGetLastError());
-  return 0;
 }
 
 // V tables: P producer waves per block, no consumers (nothing to convert)

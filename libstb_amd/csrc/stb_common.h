@@ -120,7 +120,8 @@ size_t stb_chain_workspace(unsigned N, unsigned M, int D);
 int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out,
                      hipStream_t st);
 int stb_launch_vchain(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
-int stb_chain_tuning(unsigned N, unsigned M, int D, int *P_out);
+int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out);  // columns per strip
+
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
 #define STB_ROWS_LOGDOM 1

@@ -232,17 +232,22 @@ def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     assert orc.max_err(got, tab) <= TOL
 
 
-@pytest.mark.parametrize("P,NC", [(1, 3), (1, 6), (2, 4), (2, 6), (2, 8), (4, 6), (4, 8), (4, 10)])
-def test_chain_geometries_agree(monkeypatch, P, NC):
-    """chain form: every (producer waves, consumer waves) block shape computes the same tables and
-    no block gives up waiting for its neighbour (several column blocks, several tables)"""
-    monkeypatch.setenv("STB_CHAIN_P", str(P))
-    monkeypatch.setenv("STB_CHAIN_NC", str(NC))
+@pytest.mark.parametrize("C,P,MG,NF,RD", [(2, 1, 3, 1, 4), (4, 1, 3, 1, 4), (2, 1, 3, 2, 4), (2, 1, 3, 1, 8), (4, 1, 2, 1, 4),
+                                          (4, 1, 1, 1, 4), (1, 1, 3, 1, 4), (1, 2, 3, 2, 8), (1, 4, 2, 2, 8), (2, 2, 2, 1, 8)])
+def test_chain_geometries_agree(monkeypatch, C, P, MG, NF, RD):
+    """chain form: every strip shape (columns per producer lane, producer waves, consumer groups,
+    fetcher waves, ring depth) computes the same tables and no strip gives up waiting for its
+    neighbour (several strips, several tables)"""
+    for k, v in (("C", C), ("P", P), ("MG", MG), ("NF", NF), ("RD", RD)):
+        monkeypatch.setenv("STB_CHAIN_" + k, str(v))
+    L = capi.lib()
     a = np.array([0.05, 0.5, 0.93])
     T = capi.DeviceTables(900, 700, D=3)
     T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
     T.fill(a, capi.FILL_CHAIN)
     T.status()
+    assert L.stb_fill_fallbacks() == before
     for d in range(3):
         S1, tab = orc.fill_S(a[d], 900, 700)
         got = T.packed_host(d)
