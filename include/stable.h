@@ -5,8 +5,8 @@
  * (wbuntine/libstb lib/stable.h:38-44 flags, :62-113 stable_t, :128-190 functions), so a caller
  * such as samplea.c / demo.c / hca compiles and links against libstb_amd.so unchanged.  What
  * differs is behind the interface: S_make / S_remake / growth fill the table on an MI355X
- * (kernels in libstb_amd/csrc/stb_kernels.hip) and mirror it into host memory, which is what
- * S_S / S_V / S_U / S_UV read.  There is no CPU fill: without a HIP device S_make returns NULL
+ * (kernels in libstb_amd/csrc/fill_*.hip) and S_S / S_V / S_U / S_UV read a host mirror that is
+ * copied from the device on demand, 128 rows at a time.  There is no CPU fill: without a HIP device S_make returns NULL
  * after reporting through yaps_message().
  *
  * Each declaration cites the reference line it replaces.
@@ -105,6 +105,17 @@ void S_report(stable_t *sp, FILE *fp);
 #else
 #define ISFINITE(x) finite(x)
 #endif
+
+/* ---- additions (not in the reference) ----
+ * The host mirror of the tables is filled lazily, block of 128 rows by block, the first time one of
+ * the accessors above touches a row (see libstb_amd/csrc/stable_host.c).  A caller that reads the
+ * row-pointer fields sp->S / sp->V directly (the reference's in-tree callers never do) must ask for
+ * the whole mirror first -- after S_make, after every S_remake and after growth -- or run with
+ * STB_MIRROR=eager in the environment, which makes every build do it.  Returns non-zero on a device
+ * error. */
+int stb_table_sync(stable_t *sp);
+/* how many 128-row blocks of the S and V mirrors have been copied from the device so far */
+void stb_table_mirrored(stable_t *sp, unsigned *s_blocks, unsigned *v_blocks);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
     sig("S_S1", d, [vp, u])
     sig("S_report", None, [vp, vp])
     sig("stb_extend_policy", None, [u, u, u, u, i, i, C.POINTER(u), C.POINTER(u)])
+    sig("stb_table_sync", i, [vp])
+    sig("stb_table_mirrored", None, [vp, C.POINTER(u), C.POINTER(u)])
     # ---- include/yaps.h
     sig("yaps_yapper", None, [vp])
     # ---- include/stb_hip.h
@@ -204,6 +206,15 @@ class Table:
 
     def asympt(self, n, m):
         return self.L.S_asympt(self.sp, n, m)
+
+    def sync(self):
+        check(self.L.stb_table_sync(self.sp))
+
+    def mirrored(self):
+        """(S blocks, V blocks) of 128 rows copied to the host so far"""
+        s, v = C.c_uint(), C.c_uint()
+        self.L.stb_table_mirrored(self.sp, C.byref(s), C.byref(v))
+        return s.value, v.value
 
     def free(self):
         if self.sp:

@@ -73,17 +73,19 @@ struct chain_roles {
   }
 };
 
-// waves per SIMD the register allocation must leave room for: two workgroups per compute unit where
-// two rings fit in LDS and the workgroup is small enough for that to cost no spills (with many
-// tables in flight a second resident strip per compute unit is what removes the tail of strips that
-// would otherwise wait for a free unit)
+// waves per SIMD the register allocation must leave room for: as many workgroups per compute unit
+// (up to four) as fit in LDS while every wave still gets 96 registers.  With many tables in flight
+// the strips that do not fit on the chip at once would otherwise wait for a free unit, and those are
+// the short strips at the right end of the tables, which could only start when the long ones end.
 constexpr int chain_min_waves(int C, int P, int MG, int NF, int RD) {
   const int WT = P + MG * C * P + NF;
-  const bool two_fit = RD * ST_U * 64 * C * P * 8 + 8192 <= 80 * 1024;
+  const int lds = RD * ST_U * 64 * C * P * 8 + 8192;
 #ifdef STB_NO_MINW
   return 1;
 #endif
-  return (two_fit && WT <= 10) ? (2 * WT + 3) / 4 : 1;
+  for (int nb = 4; nb >= 2; nb--)
+    if (nb * lds <= 160 * 1024 && (nb * WT + 3) / 4 <= 5) return (nb * WT + 3) / 4;
+  return 1;
 }
 
 template <int C, int P, int MG, int NF, int DOT, int RD>
@@ -939,6 +941,7 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
     case 21324: STRIP1(2, 1, 3, 2, 0, 4); break;
     case 21318: STRIP1(2, 1, 3, 1, 0, 8); break;
     case 41214: STRIP1(4, 1, 2, 1, 0, 4); break;
+    case 21214: STRIP1(2, 1, 2, 1, 0, 4); break;
     case 41114: STRIP1(4, 1, 1, 1, 0, 4); break;
     case 11314: STRIP1(1, 1, 3, 1, 0, 4); break;
     case 12328: STRIP1(1, 2, 3, 2, 0, 8); break;

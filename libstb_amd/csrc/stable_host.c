@@ -4,9 +4,9 @@
  * Mirrors the reference's lib/stable.c interface (S_make :110, S_remake :549, S_extend :564,
  * S_S1 :822, S_U :875, S_UV :885, S_V :900, S_S :941, S_free :980, S_report :1025,
  * S_asympt :1057) but not its construction: tables are filled on the GPU (stb_fill_S / stb_fill_V
- * in stb_kernels.hip) into one slab per table and copied into a pinned host mirror; the row
- * pointers S[n-3], V[n-2] of the public struct point into that mirror, so the accessors are the
- * same two loads as in the reference.  Growth recomputes the whole table for the new bounds (the
+ * in fill.hip) into one slab per table; a pinned host mirror with the same layout is copied from it
+ * on demand, 128 rows at a time, and the row pointers S[n-3], V[n-2] of the public struct point into
+ * that mirror, so an accessor is a flag test and the reference's two loads.  Growth recomputes the whole table for the new bounds (the
  * result equals the reference's incremental extension) under the reference's integer
  * growth policy.  There is no CPU fill anywhere in this file.
  *
@@ -36,15 +36,38 @@
 #include "../../include/yaps.h"
 #include "stb_layout.h"
 
-/* one generation of host mirror; old generations are parked here when readers may still hold
- * row pointers into them (S_THREADS), mirroring the reference's allocate-copy-swap realloc
- * (lib/stable.c:56-81) */
-typedef struct mirror_gen {
-  void *slab;       /* pinned or malloc'd */
-  void *rows;       /* row-pointer vector */
-  int pinned;
-  struct mirror_gen *next;
-} mirror_gen;
+/*
+ * Host mirror.  The device slab is the table; the host mirror is filled LAZILY, in blocks of
+ * STB_MIRROR_ROWS table rows, the first time an accessor touches a row of the block (one D2H copy
+ * of the block's contiguous slab range).  S_make / S_remake / growth therefore cost the device
+ * fill only -- a caller that reads a few rows of a 10^4 x 10^4 table does not pay for 400 MB over
+ * PCIe -- and the reference's own accessors S_S / S_V / S_U / S_UV see exactly the values a full
+ * copy would give them.  STB_MIRROR=eager (environment) copies everything at build time, which is
+ * what a caller that reads sp->S[n][m] directly (no in-tree caller does) needs; stb_table_sync()
+ * does the same on demand.
+ *
+ * One generation of mirror (slabs, row-pointer vectors, valid flags) is one object, published by a
+ * single pointer store AFTER it is complete and BEFORE the bounds that admit readers to it
+ * (lib/stable.c:539-545 publishes bounds last for the same reason).  Under S_THREADS growth makes a
+ * new generation and parks the old one (a reader may still hold its pointer: lib/stable.c:56-81
+ * allocate-copy-swap); the last two are kept, older ones are freed.
+ */
+#define STB_MIRROR_ROWS 128u
+
+typedef struct mirror {
+  void *slabS, *slabV;               /* pinned (or malloc'd) host slabs, device layout */
+  int pinS, pinV;
+  void **rowsS, **rowsV;             /* row-pointer vectors: what sp->S / sp->V (or Sf / Vf) point to */
+  volatile unsigned char *validS, *validV; /* one flag per block of STB_MIRROR_ROWS rows */
+  unsigned N, M;                     /* bounds this generation describes */
+  uint64_t elemsS, elemsV, bytes;
+  struct mirror *next;               /* retired list */
+} mirror;
+
+typedef struct s1_gen {
+  double *p;
+  struct s1_gen *next;
+} s1_gen;
 
 typedef struct stb_impl {
   /* device */
@@ -54,17 +77,19 @@ typedef struct stb_impl {
   void *d_ws;
   size_t ws_bytes;
   uint64_t d_S_elems, d_V_elems, d_S1_elems, d_Sf_elems, d_Vf_elems;
-  /* host mirrors (current generation); elements are double, or float under S_FLOAT */
-  void *h_S, *h_V;
-  int h_S_pinned, h_V_pinned;
-  uint64_t h_S_elems, h_V_elems;
-  mirror_gen *retired;
+  struct s1_gen *retired_s1; /* S1 vectors replaced by growth while readers may hold them (S_THREADS) */
+  mirror *cur;      /* current generation (readers load it once per access) */
+  mirror *retired;  /* older generations a reader may still hold, newest first */
+  int eager;        /* STB_MIRROR=eager */
   uint64_t bytes_host, bytes_dev;
 } stb_impl;
 
 static void account(stable_t *sp) {
   stb_impl *im = sp->impl;
   uint64_t tot = im->bytes_host + im->bytes_dev;
+  mirror *g;
+  if (im->cur) tot += im->cur->bytes;
+  for (g = im->retired; g; g = g->next) tot += g->bytes;
   sp->memalloced = tot > 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
 }
 
@@ -89,34 +114,169 @@ static void host_slab_free(void *p, int pinned) {
     free(p);
 }
 
-static void retire(stable_t *sp, void *slab, int pinned, void *rows) {
+/* an S1 vector that growth replaced: freed at once, or parked while concurrent readers may hold it */
+static void retire_s1(stable_t *sp, double *old) {
   stb_impl *im = sp->impl;
-  if (!slab && !rows) return;
   if (sp->flags & S_THREADS) {
-    mirror_gen *g = malloc(sizeof(*g));
+    s1_gen *g = malloc(sizeof(*g));
     if (g) {
-      g->slab = slab;
-      g->rows = rows;
-      g->pinned = pinned;
-      g->next = im->retired;
-      im->retired = g;
+      g->p = old;
+      g->next = im->retired_s1;
+      im->retired_s1 = g;
       return;
     }
   }
-  host_slab_free(slab, pinned);
-  free(rows);
+  free(old);
 }
-
-/* host-side storage prepared for new bounds but not yet visible through the public struct */
-typedef struct pending {
-  void *hS, *hV;
-  int hS_pinned, hV_pinned, hS_new, hV_new;
-  uint64_t hS_elems, hV_elems;
-  void **rowsS, **rowsV; /* double** or float** */
-} pending;
 
 /* bytes per stored table value: the reference's S_FLOAT keeps tables as float (lib/stable.h:31-33) */
 static size_t esz(const stable_t *sp) { return (sp->flags & S_FLOAT) ? sizeof(float) : sizeof(double); }
+
+static void mirror_free(mirror *m) {
+  if (!m) return;
+  host_slab_free(m->slabS, m->pinS);
+  host_slab_free(m->slabV, m->pinV);
+  free(m->rowsS);
+  free(m->rowsV);
+  free((void *)m->validS);
+  free((void *)m->validV);
+  free(m);
+}
+
+/* a complete, all-invalid generation for bounds (N,M); NULL when out of memory */
+static mirror *mirror_new(const stable_t *sp, unsigned N, unsigned M) {
+  mirror *m = calloc(1, sizeof(*m));
+  unsigned n;
+  if (!m) return NULL;
+  m->N = N;
+  m->M = M;
+  if (sp->flags & S_STABLE) {
+    uint64_t el = stb_table_elems(N, M);
+    const unsigned nb = (N >= 3 ? N - 3 : 0) / STB_MIRROR_ROWS + 1;
+    if (el < 2) el = 2;
+    m->elemsS = el;
+    m->slabS = host_slab(esz(sp) * el, &m->pinS);
+    m->rowsS = malloc(sizeof(void *) * (N > 3 ? N : 3));
+    m->validS = calloc(nb, 1);
+    if (!m->slabS || !m->rowsS || !m->validS) goto fail;
+    for (n = 3; n <= N; n++) m->rowsS[n - 3] = (char *)m->slabS + esz(sp) * stb_row_offset(n, M);
+    m->bytes += esz(sp) * el + sizeof(void *) * N + nb;
+  }
+  if (sp->flags & S_UVTABLE) {
+    uint64_t el = stb_vtable_elems(N, M);
+    const unsigned nb = (N >= 2 ? N - 2 : 0) / STB_MIRROR_ROWS + 1;
+    if (el < 2) el = 2;
+    m->elemsV = el;
+    m->slabV = host_slab(esz(sp) * el, &m->pinV);
+    m->rowsV = malloc(sizeof(void *) * (N > 2 ? N : 2));
+    m->validV = calloc(nb, 1);
+    if (!m->slabV || !m->rowsV || !m->validV) goto fail;
+    for (n = 2; n <= N; n++) m->rowsV[n - 2] = (char *)m->slabV + esz(sp) * stb_vrow_offset(n, M);
+    m->bytes += esz(sp) * el + sizeof(void *) * N + nb;
+  }
+  return m;
+fail:
+  mirror_free(m);
+  return NULL;
+}
+
+static void mirror_invalidate(const stable_t *sp, mirror *m) {
+  if (m->validS) memset((void *)m->validS, 0, (m->N >= 3 ? m->N - 3 : 0) / STB_MIRROR_ROWS + 1);
+  if (m->validV) memset((void *)m->validV, 0, (m->N >= 2 ? m->N - 2 : 0) / STB_MIRROR_ROWS + 1);
+  (void)sp;
+}
+
+/* copy block b of the S (which = 0) or V (which = 1) table of generation m from the device;
+ * the caller holds the table's lock (when it has one) and has made the table's device current */
+static int mirror_fetch_locked(stable_t *sp, mirror *m, int which, unsigned b) {
+  stb_impl *im = sp->impl;
+  const unsigned first = (which ? 2u : 3u) + b * STB_MIRROR_ROWS;
+  unsigned last = first + STB_MIRROR_ROWS - 1;
+  uint64_t o0, o1;
+  const char *src;
+  char *dst;
+  if (last > m->N) last = m->N;
+  if (which) {
+    o0 = stb_vrow_offset(first, m->M);
+    o1 = stb_vrow_offset(last + 1, m->M);
+    src = (sp->flags & S_FLOAT) ? (const char *)im->d_Vf : (const char *)im->d_V;
+    dst = m->slabV;
+  } else {
+    o0 = stb_row_offset(first, m->M);
+    o1 = stb_row_offset(last + 1, m->M);
+    src = (sp->flags & S_FLOAT) ? (const char *)im->d_Sf : (const char *)im->d_S;
+    dst = m->slabS;
+  }
+  if (stb_memcpy_d2h(dst + esz(sp) * o0, src + esz(sp) * o0, esz(sp) * (o1 - o0), NULL)) return 1;
+  if (stb_stream_sync(NULL)) return 1;
+  __atomic_store_n(which ? &m->validV[b] : &m->validS[b], 1, __ATOMIC_RELEASE);
+  return 0;
+}
+
+/* make sure row n of the S / V table is in the host mirror; returns the generation to read from,
+ * NULL on a device error */
+static mirror *mirror_row(stable_t *sp, int which, unsigned n) {
+  stb_impl *im = sp->impl;
+  mirror *m = __atomic_load_n(&im->cur, __ATOMIC_ACQUIRE);
+  const unsigned b = (n - (which ? 2u : 3u)) / STB_MIRROR_ROWS;
+  volatile unsigned char *valid = which ? m->validV : m->validS;
+  if (__atomic_load_n(&valid[b], __ATOMIC_ACQUIRE)) return m;
+  {
+    int rc = 0, prev_dev;
+    lock(sp);
+    m = im->cur; /* growth may have swapped generations while we waited */
+    valid = which ? m->validV : m->validS;
+    if (!valid[b]) {
+      prev_dev = stb_device_enter(im->dev);
+      rc = mirror_fetch_locked(sp, m, which, b);
+      stb_device_leave(prev_dev);
+    }
+    unlock(sp);
+    if (rc) {
+      yaps_message("libstb_amd: copying table rows from the device failed: %s\n", stb_last_error());
+      return NULL;
+    }
+  }
+  return m;
+}
+
+/* the whole mirror, now (STB_MIRROR=eager, stb_table_sync) */
+static int mirror_all_locked(stable_t *sp, mirror *m) {
+  unsigned b;
+  if (sp->flags & S_STABLE)
+    for (b = 0; b <= (m->N >= 3 ? m->N - 3 : 0) / STB_MIRROR_ROWS; b++)
+      if (!m->validS[b] && 3 + b * STB_MIRROR_ROWS <= m->N && mirror_fetch_locked(sp, m, 0, b)) return 1;
+  if (sp->flags & S_UVTABLE)
+    for (b = 0; b <= (m->N >= 2 ? m->N - 2 : 0) / STB_MIRROR_ROWS; b++)
+      if (!m->validV[b] && 2 + b * STB_MIRROR_ROWS <= m->N && mirror_fetch_locked(sp, m, 1, b)) return 1;
+  return 0;
+}
+
+int stb_table_sync(stable_t *sp) {
+  stb_impl *im;
+  int rc, prev_dev;
+  if (!sp || !sp->impl) return 1;
+  im = sp->impl;
+  lock(sp);
+  prev_dev = stb_device_enter(im->dev);
+  rc = mirror_all_locked(sp, im->cur);
+  stb_device_leave(prev_dev);
+  unlock(sp);
+  return rc;
+}
+
+void stb_table_mirrored(stable_t *sp, unsigned *s_blocks, unsigned *v_blocks) {
+  unsigned b, ns = 0, nv = 0;
+  if (sp && sp->impl) {
+    const mirror *m = ((stb_impl *)sp->impl)->cur;
+    if (m->validS)
+      for (b = 0; b <= (m->N >= 3 ? m->N - 3 : 0) / STB_MIRROR_ROWS; b++) ns += m->validS[b];
+    if (m->validV)
+      for (b = 0; b <= (m->N >= 2 ? m->N - 2 : 0) / STB_MIRROR_ROWS; b++) nv += m->validV[b];
+  }
+  if (s_blocks) *s_blocks = ns;
+  if (v_blocks) *v_blocks = nv;
+}
 
 static int devf_grow(stb_impl *im, float **slot, uint64_t *have, uint64_t want) {
   if (want <= *have) return 0;
@@ -142,23 +302,10 @@ static int dev_grow(stb_impl *im, double **slot, uint64_t *have, uint64_t want) 
   return 0;
 }
 
-static void pending_drop(pending *p) {
-  if (p->hS_new) host_slab_free(p->hS, p->hS_pinned);
-  if (p->hV_new) host_slab_free(p->hV, p->hV_pinned);
-  free(p->rowsS);
-  free(p->rowsV);
-  memset(p, 0, sizeof(*p));
-}
-
-/* size device slabs and scratch for bounds (N,M) and prepare (but do not publish) host mirrors and
- * row-pointer vectors.  A mirror slab is reused when it is already large enough AND nobody can be
- * reading it (first build, or S_remake at unchanged bounds); growth always gets a fresh slab so
- * that concurrent readers keep seeing complete data (lib/stable.c:56-81, :539-545). */
-static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending *p) {
+/* size the device slabs and scratch for bounds (N,M) */
+static int provision(stable_t *sp, unsigned N, unsigned M) {
   stb_impl *im = sp->impl;
   size_t ws = stb_fill_workspace_bytes(N, M, 1);
-  unsigned n;
-  memset(p, 0, sizeof(*p));
   if (ws > im->ws_bytes) {
     stb_device_free(im->d_ws);
     im->bytes_dev -= im->ws_bytes;
@@ -174,19 +321,6 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
     if (el < 2) el = 2;
     if (dev_grow(im, &im->d_S, &im->d_S_elems, el)) return 1;
     if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Sf, &im->d_Sf_elems, el)) return 1;
-    if (growing || el > im->h_S_elems) {
-      p->hS = host_slab(esz(sp) * el, &p->hS_pinned);
-      if (!p->hS) return 1;
-      p->hS_new = 1;
-      p->hS_elems = el;
-    } else {
-      p->hS = im->h_S;
-      p->hS_pinned = im->h_S_pinned;
-      p->hS_elems = im->h_S_elems;
-    }
-    p->rowsS = malloc(sizeof(void *) * (N > 3 ? N : 3));
-    if (!p->rowsS) return 1;
-    for (n = 3; n <= N; n++) p->rowsS[n - 3] = (char *)p->hS + esz(sp) * stb_row_offset(n, M);
   }
   if (sp->flags & S_UVTABLE) {
     uint64_t el = stb_vtable_elems(N, M);
@@ -195,47 +329,26 @@ static int provision(stable_t *sp, unsigned N, unsigned M, int growing, pending 
       return 1; /* scratch for the S1-only fill */
     if (dev_grow(im, &im->d_V, &im->d_V_elems, el)) return 1;
     if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Vf, &im->d_Vf_elems, el)) return 1;
-    if (growing || el > im->h_V_elems) {
-      p->hV = host_slab(esz(sp) * el, &p->hV_pinned);
-      if (!p->hV) return 1;
-      p->hV_new = 1;
-      p->hV_elems = el;
-    } else {
-      p->hV = im->h_V;
-      p->hV_pinned = im->h_V_pinned;
-      p->hV_elems = im->h_V_elems;
-    }
-    p->rowsV = malloc(sizeof(void *) * (N > 2 ? N : 2));
-    if (!p->rowsV) return 1;
-    for (n = 2; n <= N; n++) p->rowsV[n - 2] = (char *)p->hV + esz(sp) * stb_vrow_offset(n, M);
   }
   return 0;
 }
 
-/* device fill for discount a at bounds (N,M), copied into the given mirrors; S1[0..N) refreshed */
-static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void *hV) {
+/* device fill for discount a at bounds (N,M); S1[0..N) refreshed on the host; nothing else is copied */
+static int build(stable_t *sp, double a, unsigned N, unsigned M) {
   stb_impl *im = sp->impl;
   if (sp->flags & S_STABLE) {
     if (stb_fill_S(&a, 1, N, M, im->d_S, im->d_S_elems, im->d_S1, N, im->d_ws, im->ws_bytes,
                    stb_default_variant(), NULL))
       return 1;
-    if (sp->flags & S_FLOAT) {
-      /* all arithmetic was done in double (as lib/stable.c:389-449 does through its frontier
-       * vectors); only the stored values are narrowed, on the device, so the copy is half as big */
-      if (stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
-      if (stb_memcpy_d2h(hS, im->d_Sf, sizeof(float) * stb_table_elems(N, M), NULL)) return 1;
-    } else if (stb_memcpy_d2h(hS, im->d_S, sizeof(double) * stb_table_elems(N, M), NULL))
-      return 1;
+    /* all arithmetic was done in double (as lib/stable.c:389-449 does through its frontier
+     * vectors); only the stored values are narrowed, on the device */
+    if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
-    if (stb_fill_status()) return 1; /* (the copies above waited for the fill) */
+    if (stb_fill_status()) return 1; /* (waits for the fill; repeats it in the other form if it gave up) */
   }
   if (sp->flags & S_UVTABLE) {
     if (stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL)) return 1;
-    if (sp->flags & S_FLOAT) {
-      if (stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
-      if (stb_memcpy_d2h(hV, im->d_Vf, sizeof(float) * stb_vtable_elems(N, M), NULL)) return 1;
-    } else if (stb_memcpy_d2h(hV, im->d_V, sizeof(double) * stb_vtable_elems(N, M), NULL))
-      return 1;
+    if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
     if (stb_fill_status()) return 1; /* before any later fill reuses the workspace and its header */
   }
   if (!(sp->flags & S_STABLE)) {
@@ -251,47 +364,43 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M, void *hS, void 
   return 0;
 }
 
-/* make prepared storage visible: pointers first, bounds last (lib/stable.c:539-545) */
-static void publish(stable_t *sp, pending *p, unsigned N, unsigned M) {
+/* make a complete generation visible: the public row-pointer vectors and the generation pointer
+ * first, bounds last (lib/stable.c:539-545) */
+static void publish(stable_t *sp, mirror *m) {
   stb_impl *im = sp->impl;
-  if (sp->flags & S_STABLE) {
-    void *oldrows;
-    if (sp->flags & S_FLOAT) {
-      oldrows = sp->Sf;
-      sp->Sf = (float **)p->rowsS;
+  mirror *old = im->cur;
+  if (sp->flags & S_FLOAT) {
+    sp->Sf = (float **)m->rowsS;
+    sp->Vf = (float **)m->rowsV;
+  } else {
+    sp->S = (double **)m->rowsS;
+    sp->V = (double **)m->rowsV;
+  }
+  __atomic_store_n(&im->cur, m, __ATOMIC_RELEASE);
+  __atomic_store_n(&sp->usedN, m->N, __ATOMIC_RELEASE);
+  __atomic_store_n(&sp->usedM, m->M, __ATOMIC_RELEASE);
+  if (old) {
+    if (sp->flags & S_THREADS) {
+      /* a reader may still be inside the old generation: park it; keep the last two */
+      mirror *g;
+      int kept = 1;
+      old->next = im->retired;
+      im->retired = old;
+      for (g = old; g->next; g = g->next)
+        if (++kept > 2) {
+          mirror *dead = g->next;
+          g->next = NULL;
+          while (dead) {
+            mirror *nx = dead->next;
+            mirror_free(dead);
+            dead = nx;
+          }
+          break;
+        }
     } else {
-      oldrows = sp->S;
-      sp->S = (double **)p->rowsS;
-    }
-    retire(sp, NULL, 0, oldrows);
-    if (p->hS_new) {
-      retire(sp, im->h_S, im->h_S_pinned, NULL);
-      im->bytes_host += (p->hS_elems - im->h_S_elems) * esz(sp);
-      im->h_S = p->hS;
-      im->h_S_pinned = p->hS_pinned;
-      im->h_S_elems = p->hS_elems;
+      mirror_free(old);
     }
   }
-  if (sp->flags & S_UVTABLE) {
-    void *oldrows;
-    if (sp->flags & S_FLOAT) {
-      oldrows = sp->Vf;
-      sp->Vf = (float **)p->rowsV;
-    } else {
-      oldrows = sp->V;
-      sp->V = (double **)p->rowsV;
-    }
-    retire(sp, NULL, 0, oldrows);
-    if (p->hV_new) {
-      retire(sp, im->h_V, im->h_V_pinned, NULL);
-      im->bytes_host += (p->hV_elems - im->h_V_elems) * esz(sp);
-      im->h_V = p->hV;
-      im->h_V_pinned = p->hV_pinned;
-      im->h_V_elems = p->hV_elems;
-    }
-  }
-  sp->usedN = N;
-  sp->usedM = M;
   account(sp);
 }
 
@@ -349,16 +458,19 @@ stable_t *S_make(unsigned initN, unsigned initM, unsigned maxN, unsigned maxM, d
   sp->a = a;
   sp->lga = lgamma(1.0 - a); /* lib/stable.c:329 */
   {
-    pending p;
+    const char *mm = getenv("STB_MIRROR");
+    mirror *m;
     const int prev_dev = stb_device_enter(im->dev);
-    if (provision(sp, initN, initM, 0, &p) || build(sp, a, initN, initM, p.hS, p.hV)) {
-      yaps_message("S_make: %s\n", stb_last_error());
-      pending_drop(&p);
+    im->eager = mm && strcmp(mm, "eager") == 0;
+    m = mirror_new(sp, initN, initM);
+    if (!m || provision(sp, initN, initM) || build(sp, a, initN, initM) || (im->eager && mirror_all_locked(sp, m))) {
+      yaps_message("S_make: %s\n", m ? stb_last_error() : "out of host memory");
+      mirror_free(m);
       stb_device_leave(prev_dev);
       S_free(sp);
       return NULL;
     }
-    publish(sp, &p, initN, initM);
+    publish(sp, m);
     stb_device_leave(prev_dev);
   }
   if (flags & S_VERBOSE) S_report(sp, stderr);
@@ -376,12 +488,16 @@ int S_remake(stable_t *sp, double a) {
   if (!sp || !sp->impl) return 1;
   if (!(a >= 0.0 && a < 1.0)) return 1;
   {
+    /* same bounds, new discount: the mirror keeps its storage and is refilled on demand (nobody may
+     * be reading during S_remake, as in the reference) */
     stb_impl *im = sp->impl;
     const int prev_dev = stb_device_enter(im->dev);
-    const int rc = build(sp, a, sp->usedN, sp->usedM, im->h_S, im->h_V);
+    int rc;
+    mirror_invalidate(sp, im->cur);
+    rc = build(sp, a, sp->usedN, sp->usedM) || (im->eager && mirror_all_locked(sp, im->cur));
     stb_device_leave(prev_dev);
     if (rc) {
-      /* the table keeps its old discount (the mirrors may be partly overwritten: remake again) */
+      /* the table keeps its old discount; its contents are undefined until a remake succeeds */
       yaps_message("S_remake: %s\n", stb_last_error());
       return 1;
     }
@@ -447,19 +563,19 @@ static int extend(stable_t *sp, int N, int M) {
       }
       memcpy(s1, sp->S1, sizeof(double) * sp->usedN1);
       memset(s1 + sp->usedN1, 0, sizeof(double) * (newN - sp->usedN1));
-      retire(sp, NULL, 0, sp->S1);
+      retire_s1(sp, sp->S1);
       sp->S1 = s1;
       im->bytes_host += sizeof(double) * (newN - sp->usedN1);
       sp->usedN1 = newN;
     }
     {
-      pending p;
+      mirror *m = mirror_new(sp, newN, newM);
       const int prev_dev = stb_device_enter(im->dev);
-      rc = provision(sp, newN, newM, 1, &p) || build(sp, sp->a, newN, newM, p.hS, p.hV);
+      rc = !m || provision(sp, newN, newM) || build(sp, sp->a, newN, newM) || (im->eager && mirror_all_locked(sp, m));
       if (!rc)
-        publish(sp, &p, newN, newM);
+        publish(sp, m);
       else
-        pending_drop(&p);
+        mirror_free(m);
       stb_device_leave(prev_dev);
     }
   }
@@ -493,7 +609,7 @@ double S_S1(stable_t *sp, unsigned n) {
     }
     memcpy(s1, sp->S1, sizeof(double) * sp->usedN1);
     memset(s1 + sp->usedN1, 0, sizeof(double) * (g - sp->usedN1));
-    retire(sp, NULL, 0, sp->S1);
+    retire_s1(sp, sp->S1);
     sp->S1 = s1;
     ((stb_impl *)sp->impl)->bytes_host += sizeof(double) * (g - sp->usedN1);
     sp->usedN1 = g;
@@ -561,8 +677,12 @@ double S_V(stable_t *sp, unsigned n, unsigned m) {
   if (m < 2) return 0;
   if (n < m) return 0;
   if (n > sp->usedN || m > sp->usedM) return 0; /* growth was capped by the max bounds */
-  if (sp->flags & S_FLOAT) return sp->Vf[n - 2][m - 2];
-  return sp->V[n - 2][m - 2];
+  {
+    mirror *mr = mirror_row(sp, 1, n);
+    if (!mr) return 0;
+    if (sp->flags & S_FLOAT) return ((float **)mr->rowsV)[n - 2][m - 2];
+    return ((double **)mr->rowsV)[n - 2][m - 2];
+  }
 }
 
 double S_S(stable_t *sp, unsigned N, unsigned T) {
@@ -592,8 +712,12 @@ double S_S(stable_t *sp, unsigned N, unsigned T) {
       if (T > sp->usedM || N > sp->usedN) return -HUGE_VAL;
     }
   }
-  if (sp->flags & S_FLOAT) return sp->Sf[N - 3][T - 2];
-  return sp->S[N - 3][T - 2];
+  {
+    mirror *mr = mirror_row(sp, 0, N);
+    if (!mr) return -HUGE_VAL;
+    if (sp->flags & S_FLOAT) return ((float **)mr->rowsS)[N - 3][T - 2];
+    return ((double **)mr->rowsS)[N - 3][T - 2];
+  }
 }
 
 void S_free(stable_t *sp) {
@@ -602,22 +726,22 @@ void S_free(stable_t *sp) {
   im = sp->impl;
   free(sp->tag);
   free(sp->S1);
-  free(sp->S);
-  free(sp->V);
-  free(sp->Sf);
-  free(sp->Vf);
   if (im) {
     const int prev_dev = stb_device_enter(im->dev);
-    mirror_gen *g = im->retired;
+    mirror *g = im->retired;
+    s1_gen *s = im->retired_s1;
     while (g) {
-      mirror_gen *nx = g->next;
-      host_slab_free(g->slab, g->pinned);
-      free(g->rows);
-      free(g);
+      mirror *nx = g->next;
+      mirror_free(g);
       g = nx;
     }
-    host_slab_free(im->h_S, im->h_S_pinned);
-    host_slab_free(im->h_V, im->h_V_pinned);
+    while (s) {
+      s1_gen *nx = s->next;
+      free(s->p);
+      free(s);
+      s = nx;
+    }
+    mirror_free(im->cur); /* (owns the row-pointer vectors sp->S / sp->V point to) */
     stb_device_free(im->d_S);
     stb_device_free(im->d_V);
     stb_device_free(im->d_Sf);

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 
 import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from libstb_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +214,121 @@ def test_float_table_grows():
     assert same(d.S(299, 150), tab[orc.row_offset(299, d.usedM) + 148])
     t.free()
     d.free()
+
+
+def test_lazy_mirror_copies_only_touched_blocks(monkeypatch):
+    """the host mirror is filled 128 rows at a time on first touch: S_make / S_remake copy nothing,
+    an accessor copies its block, stb_table_sync (or STB_MIRROR=eager) copies everything; values are
+    the same either way"""
+    N = 3000
+    S1, tab = orc.fill_S(0.45, N, N)
+    t = capi.Table(N, N, N, N, 0.45, capi.S_STABLE | capi.S_UVTABLE)
+    assert t.mirrored() == (0, 0)
+    assert same(t.S(2000, 700), tab[orc.row_offset(2000, N) + 698])
+    assert t.mirrored() == (1, 0)
+    assert same(t.S(2001, 2), tab[orc.row_offset(2001, N)])          # same block
+    assert t.mirrored() == (1, 0)
+    t.V(2999, 5)
+    assert t.mirrored() == (1, 1)
+    assert t.remake(0.2) == 0
+    assert t.mirrored() == (0, 0)                                      # new discount: stale blocks dropped
+    S1b, tabb = orc.fill_S(0.2, N, N)
+    for (n, m) in ((3, 2), (130, 100), (131, 129), (2999, 2998), (3000, 1500)):
+        assert same(t.S(n, m), tabb[orc.row_offset(n, N) + m - 2])
+    t.sync()
+    nb = (N - 3) // 128 + 1
+    assert t.mirrored() == (nb, (N - 2) // 128 + 1)
+    t.free()
+    monkeypatch.setenv("STB_MIRROR", "eager")
+    t = capi.Table(N, N, N, N, 0.45, capi.S_STABLE)
+    assert t.mirrored() == (nb, 0)
+    assert same(t.S(2000, 700), tab[orc.row_offset(2000, N) + 698])
+    t.free()
+
+
+def test_concurrent_readers_while_the_table_grows():
+    """S_THREADS (reference README:66-76): S_S / S_V may be called from several threads; growth is
+    serialised by the table's mutex and publishes complete storage before the bounds that admit
+    readers to it.  Two reader threads hammer cells inside the initial bounds (and whatever has been
+    published since) while the main thread makes the table grow step by step; every value read must
+    equal the oracle's, and the rand() stream of the process must come out untouched by the HIP
+    runtime calls the threads make (the guard is one process-wide lock)."""
+    import ctypes as C
+    import threading
+    import time
+
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    libc.srand(4242)
+    want_rand = [libc.rand() for _ in range(3)]
+    libc.srand(4242)
+
+    a, maxN, maxM = 0.37, 1500, 1200
+    S1, tab = orc.fill_S(a, maxN, maxM)
+    Vt = orc.fill_V(a, maxN, maxM)
+    L = orc.oracle()
+    t = capi.Table(40, 20, maxN, maxM, a, capi.S_STABLE | capi.S_UVTABLE | capi.S_THREADS)
+    stop = threading.Event()
+    errors = []
+
+    def reader(seed):
+        rng = np.random.default_rng(seed)
+        k = 0
+        while not stop.is_set():
+            N, M = t.usedN, t.usedM            # bounds are published last: everything below them is readable
+            n = int(rng.integers(3, N - 1))
+            m = int(rng.integers(2, min(n - 1, M - 2) + 1))
+            got = t.S(n, m)
+            want = L.orc_S_S(orc.dp(tab), orc.dp(S1), maxN, maxM, n, m)
+            if not same(got, want):
+                errors.append(("S", n, m, got, want))
+                return
+            gv = t.V(n, m)
+            wv = L.orc_S_V(orc.dp(Vt), maxN, maxM, n, m)
+            if gv != wv:
+                errors.append(("V", n, m, gv, wv))
+                return
+            k += 1
+            count[seed] = k
+
+    count = {1: 0, 2: 0}
+    th = [threading.Thread(target=reader, args=(s,)) for s in (1, 2)]
+    for x in th:
+        x.start()
+    try:
+        for (n, m) in ((60, 10), (200, 50), (201, 199), (700, 300), (1200, 900), (1499, 1100), (1500, 1199)):
+            got = t.S(n, m)                    # grows the table under the readers
+            assert same(got, L.orc_S_S(orc.dp(tab), orc.dp(S1), maxN, maxM, n, m)), (n, m)
+            floor = min(count.values()) + 40   # let both readers work on every generation
+            t_end = time.time() + 20
+            while min(count.values()) < floor and not errors and time.time() < t_end:
+                time.sleep(0.001)
+    finally:
+        stop.set()
+        for x in th:
+            x.join()
+    assert not errors, errors[:3]
+    assert min(count.values()) >= 7 * 40
+    assert (t.usedN, t.usedM) == (maxN, maxM)
+    t.free()
+    assert [libc.rand() for _ in range(3)] == want_rand
+
+
+def test_quit_on_bound_is_fatal_like_the_reference(tmp_path):
+    """S_QUITONBOUND (lib/stable.c:954-959): overrunning maxN/maxM ends the process through
+    yaps_quit (exit code 1, message on stderr) -- checked in a child process"""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r); "
+        "from libstb_amd import capi; "
+        "t = capi.Table(20, 10, 60, 30, 0.5, capi.S_STABLE | capi.S_QUITONBOUND); "
+        "L = capi.lib(); L.S_tag(t.sp, b'bounded'); "
+        "print('inside', t.S(50, 20) > 0, flush=True); "
+        "t.S(61, 5); print('not reached', flush=True)" % ROOT
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stdout, r.stderr)
+    assert "inside True" in r.stdout and "not reached" not in r.stdout
+    assert "S_S(61,5,0.500000) tagged 'bounded' hit bounds" in r.stderr
