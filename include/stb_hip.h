@@ -144,6 +144,13 @@ stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T, const ui
 void stb_groups_free(stb_groups_t *g);
 /* out_host[D] = aterms(x_d) for every d: table build + sweep + restaurant terms.  D <= Dmax. */
 int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host);
+/* the same values through stored tables and the sorted gather whatever D is (stb_groups_aterms sums
+ * inside the fill when D >= 2, which needs a set-up pass over the pairs on first use) */
+int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host);
+/* new per-restaurant totals T[I] and concentrations bpar[I] for the same pairs */
+int stb_groups_update_restaurants(stb_groups_t *g, const uint32_t *T, const double *bpar);
+/* what the set was created with (any pointer may be NULL) */
+int stb_groups_shape(const stb_groups_t *g, int *I, uint64_t *G, unsigned *N, unsigned *M, int *Dmax);
 /* pieces of the same evaluation, for timing: ms of device time per stage (may be NULL) */
 int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double *out_host,
                             float *ms_fill, float *ms_sweep, float *ms_terms);
@@ -152,6 +159,11 @@ int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double
  * the log-posterior evaluations of the most recent samplea()/sampleb() call on this process:
  * how many, ARMS' return code (ignored by the samplers themselves, as in the reference), and the
  * i-th (abscissa, value) pair */
+/* samplea() keeps the device copy of the (n,t) pairs of its last call (sorted, 6 bytes a pair, plus
+ * the tables' scratch) and reuses it when the next call brings the same pairs -- the reference's
+ * callers resample a many times over unchanged counts; only T and bpar are refreshed.  This drops
+ * the kept set (STB_SAMPLEA_CACHE=0 in the environment never keeps one). */
+void stb_sampler_cache_clear(void);
 int stb_sampler_trace_count(void);
 int stb_sampler_trace_code(void);
 int stb_sampler_trace_get(int i, double *x, double *y);

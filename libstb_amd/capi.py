@@ -114,6 +114,10 @@ def lib() -> C.CDLL:
     sig("stb_groups_create", vp, [i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, u, u, i])
     sig("stb_groups_free", None, [vp])
     sig("stb_groups_aterms", i, [vp, c_double_p, i, c_double_p])
+    sig("stb_groups_aterms_tables", i, [vp, c_double_p, i, c_double_p])
+    sig("stb_groups_update_restaurants", i, [vp, c_u32_p, c_double_p])
+    sig("stb_groups_shape", i, [vp, c_int_p, C.POINTER(u64), C.POINTER(u), C.POINTER(u), c_int_p])
+    sig("stb_sampler_cache_clear", None, [])
     sig("stb_groups_aterms_timed", i, [vp, c_double_p, i, c_double_p, c_float_p, c_float_p, c_float_p])
     # optional entry points (present once the sampler host code is linked in)
     for name, res, args in (

@@ -519,16 +519,14 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
   return 0;
 }
 
-extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D,
-                                       double *out_host, float *ms_fill, float *ms_sweep,
-                                       float *ms_terms) {
-  STB_ENTRY;
+static int groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host, bool allow_fuse, float *ms_fill,
+                         float *ms_sweep, float *ms_terms) {
   if (!g) return stb_fail("stb_groups_aterms: null group set");
   if (D < 1 || D > g->Dmax) return stb_fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
   const int prev_dev = stb_device_enter(g->dev);
   const int v = stb_default_variant();
   // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
-  const bool fuse = g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
+  const bool fuse = allow_fuse && g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
   int rc = 0;
   if (fuse && !g->fused_ready) {
     if (stb_env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) rc = 1;
@@ -541,6 +539,47 @@ extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, in
   return rc;
 }
 
+extern "C" int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double *out_host, float *ms_fill,
+                                       float *ms_sweep, float *ms_terms) {
+  STB_ENTRY;
+  return groups_aterms(g, x_host, D, out_host, true, ms_fill, ms_sweep, ms_terms);
+}
+
 extern "C" int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host) {
-  return stb_groups_aterms_timed(g, x_host, D, out_host, nullptr, nullptr, nullptr);
+  STB_ENTRY;
+  return groups_aterms(g, x_host, D, out_host, true, nullptr, nullptr, nullptr);
+}
+
+// the same values through stored tables and the sorted gather whatever D is: no set-up, which is
+// what a handful of abscissae evaluated once (ARMS' three starting points) want
+extern "C" int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host) {
+  STB_ENTRY;
+  return groups_aterms(g, x_host, D, out_host, false, nullptr, nullptr, nullptr);
+}
+
+// new per-restaurant totals and concentrations for the same (n,t) pairs (they change with every
+// sweep of a Gibbs sampler while the pairs -- sorted once -- may not)
+extern "C" int stb_groups_update_restaurants(stb_groups_t *g, const uint32_t *T, const double *bpar) {
+  STB_ENTRY;
+  if (!g) return stb_fail("stb_groups_update_restaurants: null group set");
+  const int prev_dev = stb_device_enter(g->dev);
+  int rc = 0;
+  if (g->I > 0) {
+    if (hipMemcpyAsync(g->d_T, T, sizeof(uint32_t) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
+        hipMemcpyAsync(g->d_bpar, bpar, sizeof(double) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
+        hipStreamSynchronize(g->st) != hipSuccess)
+      rc = stb_fail("stb_groups_update_restaurants: %s", hipGetErrorString(hipGetLastError()));
+  }
+  stb_device_leave(prev_dev);
+  return rc;
+}
+
+extern "C" int stb_groups_shape(const stb_groups_t *g, int *I, uint64_t *G, unsigned *N, unsigned *M, int *Dmax) {
+  if (!g) return 1;
+  if (I) *I = g->I;
+  if (G) *G = g->G;
+  if (N) *N = g->N;
+  if (M) *M = g->M;
+  if (Dmax) *Dmax = g->Dmax;
+  return 0;
 }

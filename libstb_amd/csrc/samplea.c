@@ -20,26 +20,80 @@
 #include "../../include/stb_hip.h"
 #include "sampler_trace.h"
 
+#define NPRE 3 /* abscissae ARMS is known to ask for first (lib/arms.c:117-119) */
+
 typedef struct {
   stb_groups_t *dev;
   int maxn, maxt;
   int verbose;
+  int keep; /* the device set outlives this call (see `kept`) */
+  /* values evaluated ahead of time, served when ARMS asks for exactly these abscissae */
+  int npre;
+  double xpre[NPRE], ypre[NPRE];
 } a_posterior;
 
 static double aterms(double x, void *vp) {
   a_posterior *ap = vp;
   double val;
+  int i;
   if (x <= 0) {
     fprintf(stderr, "Illegal discount value in aterms()\n"); /* lib/samplea.c:50-53 */
     exit(1);
   }
   if (ap->verbose > 1) fprintf(stderr, "Extending S for M=%d a=%lf\n", ap->maxt, x); /* :54-56 */
+  for (i = 0; i < ap->npre; i++)
+    if (x == ap->xpre[i]) {
+      stb_trace_add(x, ap->ypre[i]);
+      return ap->ypre[i];
+    }
   if (stb_groups_aterms(ap->dev, &x, 1, &val)) {
     fprintf(stderr, "aterms(): device evaluation failed: %s\n", stb_last_error());
     exit(1);
   }
   stb_trace_add(x, val);
   return val;
+}
+
+/* The device copy of the pairs of the last call: a Gibbs sampler resamples a over and over on counts
+ * that change slowly or not at all, and uploading and sorting 10^6 pairs costs as much as four
+ * posterior evaluations.  Kept only while the next call brings exactly the same pairs (64-bit hash
+ * of K, n, t plus the shapes); T and bpar are refreshed on every call. */
+static struct {
+  stb_groups_t *dev;
+  uint64_t hash;
+  int I;
+  size_t G;
+  unsigned N, M;
+} kept;
+
+void stb_sampler_cache_clear(void) {
+  if (kept.dev) stb_groups_free(kept.dev);
+  memset(&kept, 0, sizeof(kept));
+}
+
+static uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  return h ^ (h >> 29);
+}
+static uint64_t hash_bytes(uint64_t h, const void *p, size_t bytes) {
+  const unsigned char *b = p;
+  uint64_t lanes[4] = {h, h ^ 0x6a09e667f3bcc908ull, h ^ 0xbb67ae8584caa73bull, h ^ 0x3c6ef372fe94f82bull};
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    memcpy(w, b + i, 32);
+    lanes[0] = (lanes[0] ^ w[0]) * 0x9fb21c651e98df25ull;
+    lanes[1] = (lanes[1] ^ w[1]) * 0xc2b2ae3d27d4eb4full;
+    lanes[2] = (lanes[2] ^ w[2]) * 0x165667b19e3779f9ull;
+    lanes[3] = (lanes[3] ^ w[3]) * 0x27d4eb2f165667c5ull;
+    lanes[0] ^= lanes[0] >> 31;
+    lanes[1] ^= lanes[1] >> 29;
+    lanes[2] ^= lanes[2] >> 33;
+    lanes[3] ^= lanes[3] >> 30;
+  }
+  for (; i < bytes; i++) lanes[i & 3] = (lanes[i & 3] ^ b[i]) * 0x100000001b3ull;
+  return mix64(mix64(mix64(mix64(h, lanes[0]), lanes[1]), lanes[2]), lanes[3] ^ bytes);
 }
 
 /* environment switch for the sampler family, so both can be exercised from one build:
@@ -100,12 +154,59 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
    * clamps (lib/stable.c:118-129): M = max(maxt,10), N = max(maxn,M) */
   M = ap.maxt < 10 ? 10u : (unsigned)ap.maxt;
   N = (unsigned)ap.maxn < M ? M : (unsigned)ap.maxn;
-  ap.dev = stb_groups_create(I, K, T, nflat, tflat, bpar, N, M, 1);
+  {
+    const char *ce = getenv("STB_SAMPLEA_CACHE");
+    const int keep = !(ce && strcmp(ce, "0") == 0);
+    uint64_t h = 0;
+    if (keep) {
+      h = hash_bytes(0x5eedull, K, sizeof(int) * (size_t)(I > 0 ? I : 0));
+      h = hash_bytes(h, nflat, sizeof(*nflat) * G);
+      h = hash_bytes(h, tflat, sizeof(*tflat) * G);
+    }
+    if (keep && kept.dev && kept.hash == h && kept.I == I && kept.G == G && kept.N == N && kept.M == M) {
+      ap.dev = kept.dev;
+      if (stb_groups_update_restaurants(ap.dev, T, bpar)) {
+        stb_sampler_cache_clear();
+        ap.dev = NULL;
+      }
+    } else {
+      stb_sampler_cache_clear();
+      ap.dev = NULL;
+    }
+    if (!ap.dev) ap.dev = stb_groups_create(I, K, T, nflat, tflat, bpar, N, M, NPRE);
+    if (ap.dev && keep) {
+      kept.dev = ap.dev;
+      kept.hash = h;
+      kept.I = I;
+      kept.G = G;
+      kept.N = N;
+      kept.M = M;
+    }
+    ap.keep = keep;
+  }
   free(nflat);
   free(tflat);
   if (!ap.dev) {
     fprintf(stderr, "Out of memory for S table (%s)\n", stb_last_error()); /* lib/samplea.c:61-64 */
     exit(1);
+  }
+  ap.npre = 0;
+  {
+    if (!use_slice()) {
+      /* ARMS starts from three abscissae it fixes before any evaluation (lib/arms.c:117-119, the
+       * same expression here, so the same bits): evaluate them in ONE batched device call */
+      double x3[NPRE], y3[NPRE];
+      for (i = 0; i < NPRE; i++) x3[i] = inita[0] + (i + 1.0) * (inita[2] - inita[0]) / (NPRE + 1.0);
+      if (stb_groups_aterms_tables(ap.dev, x3, NPRE, y3)) {
+        fprintf(stderr, "aterms(): device evaluation failed: %s\n", stb_last_error());
+        exit(1);
+      }
+      for (i = 0; i < NPRE; i++) {
+        ap.xpre[i] = x3[i];
+        ap.ypre[i] = y3[i];
+      }
+      ap.npre = NPRE;
+    }
   }
 
   stb_trace_reset();
@@ -123,6 +224,6 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
       exit(1);
     }
   }
-  stb_groups_free(ap.dev);
+  if (!ap.keep) stb_groups_free(ap.dev); /* else: kept for the next call */
   return mya;
 }

@@ -76,6 +76,56 @@ def test_samplea_vs_reference(golden_dir, rec_index):
     assert abs(got - fh(rec["a_out"])) <= 1e-6 * abs(fh(rec["a_out"]))
 
 
+def test_samplea_keeps_the_pairs_between_calls(monkeypatch):
+    """samplea keeps the sorted device copy of the (n,t) pairs while the next call brings the same
+    pairs, refreshing T and bpar; a changed pair, shape or STB_SAMPLEA_CACHE=0 builds a new set.  The
+    draw never depends on whether the set was reused."""
+    L = capi.lib()
+    L.stb_sampler_cache_clear()
+    g = synth.groups(100, 100, 1000, "wide")
+    n, t = ragged(g)
+
+    def draw(a_in, bpar, T=None, nn=n, tt=t):
+        orc.seed_libc(777, 12345)
+        return L.samplea(a_in, g.I, orc.i32p(g.K), orc.u32p(g.T if T is None else T), nn, tt, None, orc.dp(bpar), None, 1, 0)
+
+    b10, b3 = g.bpar.copy(), np.full(g.I, 3.0)
+    monkeypatch.setenv("STB_SAMPLEA_CACHE", "0")
+    ref = [draw(0.5, b10), draw(0.5, b3), draw(0.3, b10)]
+    monkeypatch.delenv("STB_SAMPLEA_CACHE")
+    got = [draw(0.5, b10), draw(0.5, b3), draw(0.3, b10)]     # second and third call reuse the set
+    assert got == ref
+    assert ref[0] != ref[1]                                    # (bpar matters: the refresh is what made them agree)
+    # a different pair set must not be served from the kept one
+    g2 = synth.groups(100, 100, 1000, "wide", seed=7)
+    n2, t2 = ragged(g2)
+    orc.seed_libc(777, 12345)
+    a2 = L.samplea(0.5, g2.I, orc.i32p(g2.K), orc.u32p(g2.T), n2, t2, None, orc.dp(g2.bpar), None, 1, 0)
+    monkeypatch.setenv("STB_SAMPLEA_CACHE", "0")
+    orc.seed_libc(777, 12345)
+    assert a2 == L.samplea(0.5, g2.I, orc.i32p(g2.K), orc.u32p(g2.T), n2, t2, None, orc.dp(g2.bpar), None, 1, 0)
+    L.stb_sampler_cache_clear()
+
+
+def test_aterms_tables_equals_fused_and_single(golden_dir):
+    """stb_groups_aterms_tables (stored tables + gather at any D) against the one-at-a-time path"""
+    L = capi.lib()
+    g = synth.groups(100, 100, 1000, "wide")
+    M = max(int(g.t.max()) + 1, 10)
+    N = max(int(g.n.max()) + 1, M)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, 3)
+    assert h, capi.last_error()
+    try:
+        x = np.array([0.3, 0.5, 0.7])
+        three, one = np.zeros(3), np.zeros(1)
+        capi.check(L.stb_groups_aterms_tables(h, capi.dp(x), 3, capi.dp(three)))
+        for d in range(3):
+            capi.check(L.stb_groups_aterms(h, capi.dp(x[d:d + 1].copy()), 1, capi.dp(one)))
+            assert one[0] == three[d]
+    finally:
+        L.stb_groups_free(h)
+
+
 def test_samplea_getval_callback_equals_arrays():
     L = capi.lib()
     g = synth.groups(20, 30, 300, "wide")
