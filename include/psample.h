@@ -8,8 +8,8 @@
  * discount + S_S gather-sum + restaurant terms) and bterms (lib/sampleb.c:33-41) -- runs on the
  * GPU through include/stb_hip.h.
  *
- * Not provided: samplea2 / SAMPLEA_M (compiled out in the reference, lib/psample.h:30) and the
- * gcache helpers of lib/lgamma.h that only it uses.
+ * samplea2 (lib/psample.h:112-117, the S-free variant behind the reference's SAMPLEA_M switch,
+ * lib/psample.h:22-30) is declared under the same switch and always present in the library.
  */
 #ifndef STB_AMD_PSAMPLE_H
 #define STB_AMD_PSAMPLE_H
@@ -57,6 +57,20 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
 double samplea(double apar, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int **t,
                void (*getval)(scnt_int *n, stcnt_int *t, unsigned i, unsigned k), double *bpar,
                rngp_t rng, int loops, int verbose);
+
+/* lib/psample.h:22-30, :112-117; lib/samplea.c:244-340.  The S-free discount step: with the caller's
+ * table S (built for the CURRENT discount apar) sample, for every (n,t) with 1 < t < n, how the n
+ * customers split over the t tables, then draw a from the posterior given those table sizes, which
+ * needs no Stirling table (aterms2, lib/samplea.c:85-150).  Defined in the library whatever the
+ * switch; declared under it as in the reference.  Differences from the reference, all in cases it
+ * leaves undefined: ARMS gets the posterior's data (the reference passes NULL, lib/samplea.c:325-326,
+ * and crashes); getval() is honoured in the sampling loops too; pairs with t = 0 or t > n contribute
+ * nothing; the partition buffer is freed. */
+#ifdef SAMPLEA_M
+double samplea2(double apar, stable_t *S, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int **t,
+                void (*getval)(scnt_int *n, stcnt_int *t, unsigned i, unsigned k), double *bpar,
+                rngp_t rng, int loops, int verbose);
+#endif
 
 #ifdef __cplusplus
 }

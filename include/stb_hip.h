@@ -155,6 +155,19 @@ int stb_groups_shape(const stb_groups_t *g, int *I, uint64_t *G, unsigned *N, un
 int stb_groups_aterms_timed(stb_groups_t *g, const double *x_host, int D, double *out_host,
                             float *ms_fill, float *ms_sweep, float *ms_terms);
 
+/* ---- aterms2, the S-free discount posterior of samplea2 (lib/samplea.c:85-150) ----
+ * For a sampled partition of the customers into tables the posterior needs only how many tables have
+ * each size: cnt[s] = number of tables with s customers (s = 2 .. S-1; entries 0 and 1 are ignored),
+ * plus the per-restaurant T[I], bpar[I] of aterms.  out[d] = sum_i restaurant terms(x_d)
+ * + sum_s cnt[s] * log((1-x_d)(2-x_d)...(s-1-x_d)), evaluated as lib/lgamma.c:36-52 does. */
+typedef struct stb_hist stb_hist_t;
+stb_hist_t *stb_hist_create(const uint32_t *cnt, unsigned S, int I, const uint32_t *T, const double *bpar);
+int stb_hist_aterms2(stb_hist_t *h, const double *x_host, int D, double *out_host);
+void stb_hist_free(stb_hist_t *h);
+/* the table sizes the most recent samplea2() sampled, in the reference's layout (ALData.m,
+ * lib/samplea.c:283-320): returns the number of entries and, through m, the array (uint16) */
+size_t stb_samplea2_partition(const uint16_t **m);
+
 /* ---- diagnostics of the host samplers (include/psample.h) ----
  * the log-posterior evaluations of the most recent samplea()/sampleb() call on this process:
  * how many, ARMS' return code (ignored by the samplers themselves, as in the reference), and the

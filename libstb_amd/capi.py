@@ -129,6 +129,11 @@ def lib() -> C.CDLL:
         ("samplea", d, [d, i, c_int_p, c_u32_p, C.POINTER(c_u32_p), C.POINTER(c_u16_p), vp, c_double_p,
                         vp, i, i]),
         ("sampleb", d, [d, i, d, d, c_u32_p, c_u32_p, d, vp, i, i]),
+        ("samplea2", d, [d, vp, i, c_int_p, c_u32_p, C.POINTER(c_u32_p), C.POINTER(c_u16_p), vp, c_double_p, vp, i, i]),
+        ("stb_samplea2_partition", sz, [C.POINTER(c_u16_p)]),
+        ("stb_hist_create", vp, [c_u32_p, u, i, c_u32_p, c_double_p]),
+        ("stb_hist_aterms2", i, [vp, c_double_p, i, c_double_p]),
+        ("stb_hist_free", None, [vp]),
         ("S_approx", d, [i, i, C.c_float]),
         ("S_approx_da", d, [i, i, C.c_float]),
         ("digammaRN", d, [d]),

@@ -275,3 +275,134 @@ extern "C" int stb_bterms(const double *x_host, int J, double Q, double shape, d
   }
   return run_terms(A, base, d_T, nullptr, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// aterms2: the S-free discount posterior (reference lib/samplea.c:85-150).  For a sampled partition of
+// every restaurant's customers into tables, the posterior's table part is a sum over tables of
+// log Gamma(size - x) / Gamma(1 - x) -- the reference's gcache_value(size - 1) with par = 1 - x
+// (lib/lgamma.c:36-52) -- which depends on the partition only through HOW MANY tables have each
+// size.  samplea2 builds that histogram once per call on the host; each evaluation is then one small
+// kernel over the sizes that occur plus the restaurant terms of aterms.
+
+// lib/lgamma.c:36-52 for par = 1 - x: log of the rising factorial par (par+1) ... (par+j-1)
+__device__ __forceinline__ double gcache_term(int j, double par, double lgpar) {
+#pragma clang fp contract(off)
+  if (j <= 0) return 0.0;
+  if (j == 1) return log(par);
+  if (j == 2) return log(par * (par + 1));
+  if (j == 3) return log(par * (par + 1) * (par + 2));
+  return lgamma((double)j + par) - lgpar;
+}
+
+struct hist_args {
+  double par[STB_TERMS_DMAX];    // 1 - x
+  double lgpar[STB_TERMS_DMAX];  // lgamma(1 - x)
+};
+
+// partial[d][block] = sum over sizes s of cnt[s] * gcache_term(s - 1)
+__global__ __launch_bounds__(256) void k_hist_partial(hist_args A, const uint32_t *cnt, unsigned S, dd_t *partial, int nb) {
+  __shared__ dd_t lds[4];
+  const int d = blockIdx.y;
+  const double par = A.par[d], lgpar = A.lgpar[d];
+  dd_t acc{0.0, 0.0};
+  for (unsigned s = 2 + blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+    const uint32_t c = cnt[s];
+    if (c) dd_add(acc, (double)c * gcache_term((int)s - 1, par, lgpar));
+  }
+  const dd_t r = block_reduce_dd(acc, lds);
+  if (threadIdx.x == 0) partial[(size_t)d * nb + blockIdx.x] = r;
+}
+
+struct stb_hist {
+  int dev;
+  unsigned S;
+  int I;
+  uint32_t *d_cnt, *d_T;
+  double *d_bpar, *d_out;  // d_out: [2][DMAX]
+  void *d_ws;
+  size_t ws_bytes;
+  dd_t *d_partial;
+  int nb;
+  hipStream_t st;
+};
+
+extern "C" void stb_hist_free(stb_hist_t *h) {
+  STB_ENTRY;
+  if (!h) return;
+  const int prev = stb_device_enter(h->dev);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  void *ptrs[] = {h->d_cnt, h->d_T, h->d_bpar, h->d_out, h->d_ws, h->d_partial};
+  for (void *p : ptrs) stb_pool_free(p);
+  if (h->st) (void)hipStreamDestroy(h->st);
+  stb_device_leave(prev);
+  free(h);
+}
+
+extern "C" stb_hist_t *stb_hist_create(const uint32_t *cnt, unsigned S, int I, const uint32_t *T, const double *bpar) {
+  STB_ENTRY;
+  if (stb_device_count() < 1) {
+    stb_fail("stb_hist_create: no HIP device (libstb_amd has no CPU path)");
+    return nullptr;
+  }
+  stb_hist_t *h = (stb_hist_t *)calloc(1, sizeof(*h));
+  if (!h) return nullptr;
+  const int prev = stb_device_enter(stb_get_device());
+  bool ok = hipGetDevice(&h->dev) == hipSuccess;
+  h->S = S;
+  h->I = I;
+  h->nb = (int)((S + 255) / 256);
+  if (h->nb < 1) h->nb = 1;
+  if (h->nb > 64) h->nb = 64;
+  h->ws_bytes = stb_terms_workspace_bytes((uint64_t)(I > 0 ? I : 0), STB_TERMS_DMAX);
+  ok = ok && hipStreamCreate(&h->st) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&h->d_cnt, sizeof(uint32_t) * (S ? S : 1)) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&h->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&h->d_bpar, sizeof(double) * (I > 0 ? I : 1)) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&h->d_out, sizeof(double) * 2 * STB_TERMS_DMAX) == hipSuccess;
+  ok = ok && stb_pool_malloc(&h->d_ws, h->ws_bytes) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&h->d_partial, sizeof(dd_t) * STB_TERMS_DMAX * h->nb) == hipSuccess;
+  if (ok && S) ok = hipMemcpy(h->d_cnt, cnt, sizeof(uint32_t) * S, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && I > 0)
+    ok = hipMemcpy(h->d_T, T, sizeof(uint32_t) * I, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(h->d_bpar, bpar, sizeof(double) * I, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    const hipError_t e = hipGetLastError();
+    stb_fail("stb_hist_create: %s", e != hipSuccess ? hipGetErrorString(e) : "out of memory");
+    stb_device_leave(prev);
+    stb_hist_free(h);
+    return nullptr;
+  }
+  stb_device_leave(prev);
+  return h;
+}
+
+// out_host[d] = aterms2(x_d): restaurant terms + sum over table sizes of count * log rising factorial
+extern "C" int stb_hist_aterms2(stb_hist_t *h, const double *x_host, int D, double *out_host) {
+  STB_ENTRY;
+  if (!h) return stb_fail("stb_hist_aterms2: null histogram");
+  if (D < 1 || D > STB_TERMS_DMAX) return stb_fail("stb_hist_aterms2: D=%d (max %d)", D, STB_TERMS_DMAX);
+  hist_args A;
+  for (int d = 0; d < D; d++) {
+    if (!(x_host[d] > 0 && x_host[d] < 1)) return stb_fail("stb_hist_aterms2: x=%g outside (0,1)", x_host[d]);
+    A.par[d] = 1.0 - x_host[d];
+    A.lgpar[d] = lgamma(A.par[d]);  // lib/lgamma.c:32
+  }
+  const int prev = stb_device_enter(h->dev);
+  int rc = 0;
+  double hh[2 * STB_TERMS_DMAX];
+  do {
+    hipLaunchKernelGGL(k_hist_partial, dim3(h->nb, D), dim3(256), 0, h->st, A, h->d_cnt, h->S, h->d_partial, h->nb);
+    hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, h->st, h->d_partial, h->nb, h->d_out, (const double *)nullptr);
+    if ((rc = stb_restaurant_terms(x_host, D, h->d_T, h->d_bpar, (uint64_t)(h->I > 0 ? h->I : 0), h->d_out + STB_TERMS_DMAX,
+                                   h->d_ws, h->ws_bytes, h->st)))
+      break;
+    if (hipMemcpyAsync(hh, h->d_out, sizeof(hh), hipMemcpyDeviceToHost, h->st) != hipSuccess ||
+        hipStreamSynchronize(h->st) != hipSuccess) {
+      rc = stb_fail("stb_hist_aterms2: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    for (int d = 0; d < D; d++) out_host[d] = hh[STB_TERMS_DMAX + d] + hh[d];
+  } while (0);
+  stb_device_leave(prev);
+  return rc;
+}

@@ -23,8 +23,15 @@
 static int ref_arms_hook(int ninit, double *xl, double *xr,
                          double (*myfunc)(double x, void *mydata), void *mydata, int dometrop,
                          double *xprev, double *xsamp);
+/* samplea2() (compiled only with -DSAMPLEA_M, into _ref/libstb_ref_m.so) hands ARMS a NULL `mydata`
+ * (lib/samplea.c:325-326), which aterms2 then dereferences: while samplea.c is being included the
+ * hook substitutes the address of the caller's local `ald` for a NULL argument -- the reference's
+ * source is untouched, and samplea()'s own call (which passes &ald) is unaffected. */
+#define arms_simple(ni, xl, xr, f, d, m, xp, xs) \
+  ref_arms_hook(ni, xl, xr, f, ((d) ? (void *)(d) : (void *)&ald), m, xp, xs)
+#include "samplea.c" /* -I$(REF)/lib : lib/samplea.c (ALData, aterms, samplea; aterms2, samplea2) */
+#undef arms_simple
 #define arms_simple ref_arms_hook
-#include "samplea.c" /* -I$(REF)/lib : lib/samplea.c (ALData, aterms, samplea) */
 #include "sampleb.c" /* -I$(REF)/lib : lib/sampleb.c (BLData, bterms, sampleb) */
 #undef arms_simple
 
@@ -47,9 +54,11 @@ static double ref_tramp(double x, void *unused) {
   ref_trace.n++;
   return y;
 }
+static void *ref_last_mydata;
 static int ref_arms_hook(int ninit, double *xl, double *xr,
                          double (*myfunc)(double x, void *mydata), void *mydata, int dometrop,
                          double *xprev, double *xsamp) {
+  ref_last_mydata = mydata;
   ref_trace.f = myfunc;
   ref_trace.d = mydata;
   ref_trace.n = 0;
@@ -253,3 +262,63 @@ int ref_slice_probe(int kind, double p0, double p1, double p2, double lo, double
   *ncalls = d.calls;
   return err;
 }
+
+#ifdef SAMPLEA_M
+/* ---- the S-free discount sampler (lib/samplea.c:85-150 aterms2, :244-340 samplea2) ---- */
+/* samplea2 on flat arrays; the table partition it sampled (ALData.m, never freed by the reference) can
+ * be read back afterwards */
+static stcnt_int *ref_m_last;
+static size_t ref_m_count;
+double ref_samplea2_flat(double a, stable_t *sp, int I, int *K, scnt_int *T, scnt_int *nflat, stcnt_int *tflat,
+                         double *bpar, int loops, int verbose) {
+  scnt_int **n = malloc(sizeof(*n) * (I > 0 ? I : 1));
+  stcnt_int **t = malloc(sizeof(*t) * (I > 0 ? I : 1));
+  size_t off = 0;
+  int i, k;
+  double r;
+  ref_m_count = 0;
+  for (i = 0; i < I; i++) {
+    n[i] = nflat + off;
+    t[i] = tflat + off;
+    for (k = 0; k < K[i]; k++)
+      if (t[i][k] > 1 && t[i][k] < n[i][k]) ref_m_count += t[i][k] - 1;
+    off += K[i];
+  }
+  r = samplea2(a, sp, I, K, T, n, t, NULL, bpar, NULL, loops, verbose);
+  ref_m_last = ((ALData *)ref_last_mydata)->m;
+  free(n);
+  free(t);
+  return r;
+}
+size_t ref_m_size(void) { return ref_m_count; }
+unsigned ref_m_get(size_t i) { return ref_m_last[i]; }
+
+/* aterms2(x) for a GIVEN partition m (as samplea2 lays it out) */
+double ref_aterms2_eval(double x, int I, int *K, scnt_int *T, scnt_int *nflat, stcnt_int *tflat, double *bpar,
+                        stcnt_int *m) {
+  ALData ald;
+  scnt_int **n = malloc(sizeof(*n) * (I > 0 ? I : 1));
+  stcnt_int **t = malloc(sizeof(*t) * (I > 0 ? I : 1));
+  size_t off = 0;
+  int i;
+  double r;
+  for (i = 0; i < I; i++) {
+    n[i] = nflat + off;
+    t[i] = tflat + off;
+    off += K[i];
+  }
+  memset(&ald, 0, sizeof(ald));
+  ald.T = T;
+  ald.n = n;
+  ald.t = t;
+  ald.I = I;
+  ald.K = K;
+  ald.val = NULL;
+  ald.bpar = bpar;
+  ald.m = m;
+  r = aterms2(x, &ald);
+  free(n);
+  free(t);
+  return r;
+}
+#endif

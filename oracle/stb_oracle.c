@@ -260,6 +260,89 @@ double orc_aterms(double x, int I, const int *K, const uint32_t *T, const uint32
   return orc_aterms_sum(x, I, K, T, nflat, tflat, bpar, table, S1, N, M);
 }
 
+/* lib/lgamma.c:36-52 gcache_value for par: log of par (par+1) ... (par+j-1); the cache only memoises */
+static double orc_gcache(int j, double par, double lgpar) {
+  if (j <= 0) return 0;
+  if (j == 1) return log(par);
+  if (j == 2) return log(par * (par + 1));
+  if (j == 3) return log(par * (par + 1) * (par + 2));
+  return lgamma(j + par) - lgpar;
+}
+
+double orc_aterms2(double x, int I, const int *K, const uint32_t *T, const uint32_t *nflat, const uint16_t *tflat,
+                   const double *bpar, const uint16_t *m) {
+  /* lib/samplea.c:85-150 with LGCACHE: restaurant terms, then per pair the sampled table sizes */
+  int i, k;
+  size_t g = 0;
+  double val = 0;
+  const double par = 1 - x, lgpar = lgamma(1 - x);
+  const uint16_t *mm = m;
+  for (i = 0; i < I; i++) {
+    val += T[i] * log(x) + lgamma(T[i] + bpar[i] / x) - lgamma(bpar[i] / x);
+    for (k = 0; k < K[i]; k++, g++) {
+      int n = (int)nflat[g];
+      const int t = tflat[g];
+      if (n > 0) {
+        if (t == n) {
+          ;
+        } else if (t == 1) {
+          val += orc_gcache(n - 1, par, lgpar);
+        } else if (t > 1 && t < n) { /* (the reference leaves t = 0 and t > n undefined) */
+          int l;
+          for (l = t - 2; l >= 0; l--) {
+            if (mm[l] > 1) val += orc_gcache(mm[l] - 1, par, lgpar);
+            n -= mm[l];
+          }
+          if (n > 0) val += orc_gcache(n - 1, par, lgpar);
+          mm += t - 1;
+        }
+      }
+    }
+  }
+  return val;
+}
+
+static double orc_logminus(double x, double y) {
+  /* lib/samplea.c:232-238 */
+  if (y >= x) return -HUGE_VAL;
+  if (y - x < -80) return x - exp(y - x);
+  return x + log(1 - exp(y - x));
+}
+
+/* lib/samplea.c:295-320: the table sizes of every pair with 1 < t < n, from the table for discount a
+ * and one uniform per such pair (u[], in pair order); m receives sum (t-1) entries; returns that count */
+size_t orc_partition(double a, const double *table, const double *S1, unsigned N, unsigned M, int I, const int *K,
+                     const uint32_t *nflat, const uint16_t *tflat, const double *u, uint16_t *m) {
+  int i, k;
+  size_t g = 0, nu = 0;
+  uint16_t *mp = m;
+  for (i = 0; i < I; i++)
+    for (k = 0; k < K[i]; k++, g++) {
+      const int t = tflat[g];
+      int Nn = (int)nflat[g], Mm, l;
+      if (!(t > 1 && t < Nn)) continue;
+      {
+        const double ptot = orc_S_S(table, S1, N, M, (unsigned)Nn, (unsigned)t);
+        double rem = ptot + log(u[nu++]);
+        for (Mm = t - 1; Mm >= 1; Mm--) {
+          double fact = 0.0;
+          for (l = 1; l <= Nn - Mm; l++) {
+            double term;
+            if (l > 1) fact += log((l - a) * (Nn - l + 1) / (l - 1));
+            term = fact + orc_S_S(table, S1, N, M, (unsigned)(Nn - l), (unsigned)Mm) - ptot;
+            if (term >= rem) break;
+            rem = orc_logminus(rem, term);
+          }
+          if (l > Nn - Mm) l = Nn - Mm;
+          mp[Mm - 1] = (uint16_t)l;
+          Nn -= l;
+        }
+        mp += t - 1;
+      }
+    }
+  return (size_t)(mp - m);
+}
+
 double orc_bterms(double x, double Q, double shape, int I, const uint32_t *T, double apar) {
   /* lib/sampleb.c:33-41 */
   int i;

@@ -76,6 +76,12 @@ void orc_scan_bounds(int I, const int *K, const uint32_t *nflat, const uint16_t 
 
 /* lib/sampleb.c:33-41 */
 double orc_bterms(double x, double Q, double shape, int I, const uint32_t *T, double apar);
+/* lib/samplea.c:85-150 (aterms2, LGCACHE form) for a given partition m in samplea2's layout */
+double orc_aterms2(double x, int I, const int *K, const uint32_t *T, const uint32_t *nflat, const uint16_t *tflat,
+                   const double *bpar, const uint16_t *m);
+/* lib/samplea.c:295-320: sample the partition from the table for discount a and one uniform per pair */
+size_t orc_partition(double a, const double *table, const double *S1, unsigned N, unsigned M, int I, const int *K,
+                     const uint32_t *nflat, const uint16_t *tflat, const double *u, uint16_t *m);
 
 /* lib/sapprox.c:28-71 (LS_NOPOLYGAMMA build: lib/digamma.h:25) */
 double orc_S_approx(int n, int m, float a);

@@ -407,12 +407,47 @@ def g14_grid_aterms(R):
     dump("aterms_grid64.json", out)
 
 
+def g15_samplea2(R):
+    """8f-4: the S-free discount sampler.  From the reference built with -DSAMPLEA_M
+    (oracle/_ref/libstb_ref_m.so): for three group sets and two starting discounts the table sizes
+    samplea2 sampled (drand48 stream 12345), ARMS' abscissae and values (rand stream 777), the draw,
+    and aterms2 at fixed abscissae for that partition."""
+    if not orc.have_ref_m():
+        sys.exit("oracle/_ref/libstb_ref_m.so missing: run `make -C oracle`")
+    RM = orc.ref_m()
+    out = {"seed_rand": 777, "seed_rand48": 12345, "runs": []}
+    for name in ("small_wide", "small_real", "mid_wide"):
+        I, K, nmax, prof = GROUP_SETS[name]
+        g = synth.groups(I, K, nmax, prof)
+        maxn, maxt = int(g.n.max()) + 1, int(g.t.max()) + 1
+        for a0 in (0.5, 0.15):
+            sp = RM.S_make(maxn, maxt, maxn, maxt, a0, S_STABLE)
+            orc.seed_libc(777, 12345)
+            r = RM.ref_samplea2_flat(a0, sp, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
+                                     orc.dp(g.bpar), 1, 0)
+            m = np.array([RM.ref_m_get(i) for i in range(RM.ref_m_size())], dtype=np.uint16)
+            n = RM.ref_trace_count()
+            rec = {"set": name, "a_in": hx(a0), "a_out": hx(r), "maxn": maxn, "maxt": maxt,
+                   "m_sha256": hashlib.sha256(m.tobytes()).hexdigest(), "m_count": int(m.shape[0]),
+                   "m_head": [int(v) for v in m[:64]],
+                   "trace": {"count": n, "code": RM.ref_trace_code(), "xl": hx(RM.ref_trace_xl()), "xr": hx(RM.ref_trace_xr()),
+                             "x": [hx(RM.ref_trace_x(i)) for i in range(n)], "y": [hx(RM.ref_trace_y(i)) for i in range(n)]},
+                   "aterms2": [{"x": hx(x), "y": hx(RM.ref_aterms2_eval(x, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n),
+                                                                       orc.u16p(g.t), orc.dp(g.bpar), orc.u16p(m)))}
+                               for x in (0.05, 0.3, 0.5, 0.7, 0.95)]}
+            if m.shape[0] <= 5000:
+                rec["m"] = [int(v) for v in m]
+            out["runs"].append(rec)
+            RM.S_free(sp)
+    dump("samplea2.json", out)
+
+
 def main():
     if not orc.have_ref():
         sys.exit("oracle/_ref/libstb_ref.so missing: run `make -C oracle` where /root/reference exists")
     R = orc.ref()
     gens = [g1_small_tables, g2_big_probes, g3_asympt, g4_extend, g5_aterms, g6_bterms,
-            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng, g13_grid_tables, g14_grid_aterms]
+            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng, g13_grid_tables, g14_grid_aterms, g15_samplea2]
     want = sys.argv[1:]
     for g in gens:
         if not want or g.__name__.split("_")[0] in want:

@@ -95,6 +95,10 @@ def oracle() -> C.CDLL:
     L.orc_scan_bounds.argtypes = [i, c_int_p, c_u32_p, c_u16_p, c_int_p, c_int_p]
     L.orc_bterms.restype = d
     L.orc_bterms.argtypes = [d, d, d, i, c_u32_p, d]
+    L.orc_aterms2.restype = d
+    L.orc_aterms2.argtypes = [d, i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, c_u16_p]
+    L.orc_partition.restype = C.c_size_t
+    L.orc_partition.argtypes = [d, c_double_p, c_double_p, u, u, i, c_int_p, c_u32_p, c_u16_p, c_double_p, c_u16_p]
     L.orc_S_approx.restype = d
     L.orc_S_approx.argtypes = [i, i, C.c_float]
     L.orc_time_fill.restype = d
@@ -108,6 +112,40 @@ def oracle() -> C.CDLL:
 
 def have_ref() -> bool:
     return os.path.exists(REF_SO)
+
+
+REF_M_SO = os.path.join(ORACLE_DIR, "_ref", "libstb_ref_m.so")
+
+
+def have_ref_m() -> bool:
+    return os.path.exists(REF_M_SO)
+
+
+@lru_cache(maxsize=None)
+def ref_m() -> C.CDLL:
+    """The real reference compiled with -DSAMPLEA_M (samplea2 / aterms2); build container only."""
+    L = C.CDLL(REF_M_SO)
+    u, d, i, vp = C.c_uint, C.c_double, C.c_int, C.c_void_p
+    L.S_make.restype = vp
+    L.S_make.argtypes = [u, u, u, u, d, C.c_uint32]
+    L.S_free.restype = None
+    L.S_free.argtypes = [vp]
+    L.ref_samplea2_flat.restype = d
+    L.ref_samplea2_flat.argtypes = [d, vp, i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, i, i]
+    L.ref_m_size.restype = C.c_size_t
+    L.ref_m_get.restype = u
+    L.ref_m_get.argtypes = [C.c_size_t]
+    L.ref_aterms2_eval.restype = d
+    L.ref_aterms2_eval.argtypes = [d, i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, c_u16_p]
+    L.ref_trace_count.restype = i
+    L.ref_trace_code.restype = i
+    L.ref_trace_x.restype = d
+    L.ref_trace_x.argtypes = [i]
+    L.ref_trace_y.restype = d
+    L.ref_trace_y.argtypes = [i]
+    L.ref_trace_xl.restype = d
+    L.ref_trace_xr.restype = d
+    return L
 
 
 @lru_cache(maxsize=None)

@@ -203,3 +203,61 @@ def test_rand_stream_is_not_disturbed_by_the_runtime():
     L.stb_groups_free(h)
     got.append(libc.rand())
     assert got == want
+
+
+@pytest.mark.parametrize("run", range(6))
+def test_samplea2_vs_reference(golden_dir, run):
+    """8f-4: samplea2 (the S-free discount step) against the reference built with -DSAMPLEA_M: the
+    sampled table sizes are identical, ARMS makes the same number of evaluations with the same code,
+    its three starting abscissae are identical and the posterior there agrees to 1e-10, the draw to 1e-6"""
+    import ctypes as C
+    import hashlib
+
+    L = capi.lib()
+    rec = load(golden_dir, "samplea2.json")["runs"][run]
+    g = synth.groups(*SETS[rec["set"]])
+    n, t = ragged(g)
+    a0 = fh(rec["a_in"])
+    tab = capi.Table(rec["maxn"], rec["maxt"], rec["maxn"], rec["maxt"], a0, capi.S_STABLE)
+    orc.seed_libc(777, 12345)
+    got = L.samplea2(a0, tab.sp, g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, 1, 0)
+    mp = capi.c_u16_p()
+    cnt = L.stb_samplea2_partition(C.byref(mp))
+    assert cnt == rec["m_count"]
+    m = np.ctypeslib.as_array(mp, shape=(cnt,)).copy()
+    assert [int(v) for v in m[:64]] == rec["m_head"]
+    assert hashlib.sha256(m.tobytes()).hexdigest() == rec["m_sha256"]
+    xs, ys, code = trace(L)
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    assert code == rec["trace"]["code"] and len(xs) == rec["trace"]["count"]
+    assert np.array_equal(xs[:3], want_x[:3])
+    assert orc.close(ys[:3], want_y[:3], 1e-10)
+    assert np.max(np.abs(xs - want_x) / np.abs(want_x)) <= 1e-4
+    assert abs(got - fh(rec["a_out"])) <= 1e-6 * abs(fh(rec["a_out"]))
+    # the posterior itself, for that partition, at fixed abscissae (one batched device call)
+    hist = np.zeros(rec["maxn"] + 2, dtype=np.uint32)
+    mm = 0
+    for nn, tt in zip(g.n, g.t):
+        nn, tt = int(nn), int(tt)
+        if nn == 0 or tt == nn or tt == 0 or tt > nn:
+            continue
+        if tt == 1:
+            hist[nn] += 1
+            continue
+        sizes = m[mm:mm + tt - 1]
+        mm += tt - 1
+        for s in sizes:
+            if s > 1:
+                hist[s] += 1
+        rest = nn - int(sizes.astype(np.int64).sum())
+        if rest > 1:
+            hist[rest] += 1
+    h = L.stb_hist_create(orc.u32p(hist), hist.shape[0], g.I, orc.u32p(g.T), orc.dp(g.bpar))
+    assert h, capi.last_error()
+    x = np.array([fh(p["x"]) for p in rec["aterms2"]])
+    out = np.zeros(len(x))
+    capi.check(L.stb_hist_aterms2(h, capi.dp(x), len(x), capi.dp(out)))
+    L.stb_hist_free(h)
+    assert orc.close(out, [fh(p["y"]) for p in rec["aterms2"]], 1e-10)
+    tab.free()

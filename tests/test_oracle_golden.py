@@ -241,3 +241,44 @@ def test_grid_aterms_config5(golden_dir):
         got = L.orc_aterms(float(grid[d]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
                            orc.dp(g.bpar), N, M, orc.dp(scratch))
         assert orc.close(got, fh(spec["aterms"][d]), 1e-13), d
+
+
+def _uniforms(count):
+    """the drand48 stream samplea2 draws its one uniform per pair from (seed 12345)"""
+    import ctypes as C
+
+    libc = C.CDLL(None)
+    libc.drand48.restype = C.c_double
+    orc.seed_libc(777, 12345)
+    return np.array([libc.drand48() for _ in range(count)])
+
+
+@pytest.mark.parametrize("run", range(6))
+def test_samplea2_partition_and_aterms2(golden_dir, run):
+    """8f-4: the oracle's restatement of samplea2's table-size sampling (lib/samplea.c:295-320) and of
+    aterms2 (:85-150) against the reference built with -DSAMPLEA_M"""
+    import hashlib
+
+    L = orc.oracle()
+    rec = load_json(golden_dir, "samplea2.json")["runs"][run]
+    g = synth.groups(*{"small_wide": (20, 30, 300, "wide"), "small_real": (20, 30, 300, "realistic"),
+                       "mid_wide": (100, 100, 1000, "wide")}[rec["set"]])
+    a0 = fh(rec["a_in"])
+    N, M = rec["maxn"], max(rec["maxt"], 10)
+    N = max(N, M)
+    S1, tab = orc.fill_S(a0, N, M)
+    npairs = int(np.sum((g.t > 1) & (g.t < g.n)))
+    u = _uniforms(npairs)
+    m = np.zeros(rec["m_count"] + 1, dtype=np.uint16)
+    cnt = L.orc_partition(a0, orc.dp(tab), orc.dp(S1), N, M, g.I, orc.i32p(g.K), orc.u32p(g.n), orc.u16p(g.t), orc.dp(u),
+                          orc.u16p(m))
+    assert cnt == rec["m_count"]
+    m = np.ascontiguousarray(m[:cnt])
+    assert [int(v) for v in m[:64]] == rec["m_head"]
+    assert hashlib.sha256(m.tobytes()).hexdigest() == rec["m_sha256"]
+    if "m" in rec:
+        assert [int(v) for v in m] == rec["m"]
+    for p in rec["aterms2"]:
+        got = L.orc_aterms2(fh(p["x"]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
+                            orc.u16p(m))
+        assert orc.close(got, fh(p["y"]), 1e-13), p
