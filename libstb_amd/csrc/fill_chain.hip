@@ -826,7 +826,7 @@ struct chain_geom {
   size_t bytes;  // header + edge streams for D tables
 };
 
-static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
+static chain_geom chain_geometry(unsigned N, unsigned M, int D, bool summing = false) {
   chain_geom g;
   // strip shape by batch: 128-column strips on many compute units while the fill is a latency chain
   // (few tables: time = rows x row time of a strip + strips x hand-off, and a producer wave's row time
@@ -834,7 +834,10 @@ static chain_geom chain_geometry(unsigned N, unsigned M, int D) {
   // cell -- beyond.  Measured on MI355X, N = M = 10^4: one table 0.82 ms with 128 columns against 1.0
   // with 256; eight tables 1.25 ms with 256 against 1.5 with 128.
   const uint64_t cols = (uint64_t)D * M;
-  const bool few = cols <= (uint64_t)stb_env_int("STB_CHAIN_NARROW_COLS", 50000);
+  // (the summing kernels have little consumer work per strip: they are bound by the producers, and
+  // narrow strips put more producer waves on a compute unit -- 64 discounts x 10^6 pairs at N = 10^4:
+  // 2.5 ms with 128-column strips against 4.4 with 256)
+  const bool few = summing || cols <= (uint64_t)stb_env_int("STB_CHAIN_NARROW_COLS", 50000);
   g.C = stb_env_int("STB_CHAIN_C", few ? 2 : 4);
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = few ? 2 : 4;
   g.P = stb_env_int("STB_CHAIN_P", 1);
@@ -882,7 +885,7 @@ static unsigned long long *g_chain_dbg = nullptr;
 int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out,
                      hipStream_t st) {
   const unsigned N = A.N, M = A.M;
-  const chain_geom sg = chain_geometry(N, M, D);
+  const chain_geom sg = chain_geometry(N, M, D, dot != nullptr);
   int Pc = stb_period_rows(N);
   const int Penv = stb_env_int("STB_FILL_P", 0);
   if (Penv > 0 && Penv < Pc) Pc = Penv;
@@ -933,16 +936,16 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   } while (0)
   const int shape = sg.C * 10000 + sg.P * 1000 + sg.MG * 100 + sg.NF * 10 + sg.RD;
   // (the summing variants are compiled for the two default strip shapes only)
-  if (dk != 0 && shape != 21314 && shape != 41314)
+  if (dk != 0 && shape != 21314 && shape != 41314 && shape != 41214 && shape != 41114)
     return stb_fail("stb_fill_S: the fused evaluation needs a default strip shape (unset STB_CHAIN_C / _P / _MG / _NF / _RD)");
   switch (shape) {
     case 21314: STRIP(2, 1, 3, 1, 4); break;  // few tables
     case 41314: STRIP(4, 1, 3, 1, 4); break;  // several
+    case 41214: STRIP(4, 1, 2, 1, 4); break;
+    case 41114: STRIP(4, 1, 1, 1, 4); break;
     case 21324: STRIP1(2, 1, 3, 2, 0, 4); break;
     case 21318: STRIP1(2, 1, 3, 1, 0, 8); break;
-    case 41214: STRIP1(4, 1, 2, 1, 0, 4); break;
     case 21214: STRIP1(2, 1, 2, 1, 0, 4); break;
-    case 41114: STRIP1(4, 1, 1, 1, 0, 4); break;
     case 11314: STRIP1(1, 1, 3, 1, 0, 4); break;
     case 12328: STRIP1(1, 2, 3, 2, 0, 8); break;
     case 14228: STRIP1(1, 4, 2, 2, 0, 8); break;

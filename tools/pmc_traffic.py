@@ -4,16 +4,16 @@ WRITE_SIZE and FETCH_SIZE are collected in SEPARATE passes (TCC slots), both are
 gfx950 FETCH_SIZE counts wide coalesced reads at half their size -> doubled here.
 
 usage: pmc_traffic.py <label> <write_pass_dir> <fetch_pass_dir> <fills_in_run> [out.json]
-Appends/updates profiles/r01_hbm_traffic.json: per kernel, bytes per launch and per fill.
+Appends/updates profiles/r02_hbm_traffic.json: per kernel, bytes per launch and per fill.
 """
 import collections, csv, glob, json, os, sys
 
 label, wdir, fdir, fills = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic.json")
+out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_hbm_traffic.json")
 
 
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[-1]
     agg, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:

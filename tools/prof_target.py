@@ -1,0 +1,80 @@
+"""One small workload per kernel, for rocprofv3 (kernel-trace statistics and PMC passes).
+
+    rocprofv3 --kernel-trace --stats -d OUT -o NAME -- python3 tools/prof_target.py WHAT [reps]
+    rocprofv3 --pmc WRITE_SIZE -d OUT -o NAME -- python3 tools/prof_target.py WHAT [reps]
+
+The interpreter itself follows `--` (no env / shell hop: the profiler's library has initialised the
+GPU by then).  WHAT:
+    fill1 fill8 fill64   stb_fill_S of 1 / 8 / 64 tables, N = M = 10000 (k_fill_chain / k_fill_pc)
+    vfill                stb_fill_V, N = M = 10000                      (k_fillv_chain)
+    grid64               the fused 64-discount aterms over 10^6 pairs, n < 10000 (k_fill_chain DOT)
+    sweep64              the same grid through stored tables             (k_fill_pc, k_sweep_partial)
+    eval1                one-discount aterms, 10^6 pairs, n < 4000       (k_fill_chain, k_sweep_partial, k_terms_partial)
+    bterms               stb_bterms, 10^6 restaurants x 20 abscissae     (k_terms_partial)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from libstb_amd import capi, synth
+
+what = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+L = capi.lib()
+N = 10000
+
+
+def groups_handle(g, Dmax):
+    M = max(int(g.t.max()) + 1, 10)
+    Ng = max(int(g.n.max()) + 1, M)
+    h = L.stb_groups_create(g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p),
+                            g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p), capi.dp(g.bpar), Ng, M, Dmax)
+    assert h, capi.last_error()
+    return h
+
+
+if what in ("fill1", "fill8", "fill64"):
+    D = int(what[4:])
+    a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
+    T = capi.DeviceTables(N, N, D=D)
+    for _ in range(reps):
+        T.fill(a)
+    torch.cuda.synchronize()
+    T.status()
+elif what == "vfill":
+    T = capi.DeviceVTables(N, N, D=1)
+    for _ in range(reps):
+        T.fill(np.array([0.5]))
+    torch.cuda.synchronize()
+elif what in ("grid64", "sweep64"):
+    if what == "sweep64":
+        os.environ["STB_ATERMS_FUSED"] = "0"
+    g = synth.groups(1000, 1000, N, "wide")
+    h = groups_handle(g, 64)
+    x = np.ascontiguousarray(synth.discount_grid(64))
+    out = np.zeros(64)
+    for _ in range(reps):
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 64, capi.dp(out)))
+    L.stb_groups_free(h)
+elif what == "eval1":
+    g = synth.groups(1000, 1000, 4000, "wide")
+    h = groups_handle(g, 1)
+    x, out = np.array([0.45]), np.zeros(1)
+    for _ in range(reps):
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 1, capi.dp(out)))
+    L.stb_groups_free(h)
+elif what == "bterms":
+    g = synth.groups(1000000, 1, 4000, "realistic")
+    dg = capi.DeviceGroups(g)
+    x = np.linspace(1.0, 100.0, 20)
+    for _ in range(reps):
+        capi.bterms(x, 0.05, g.shape, 0.5, dg)
+    torch.cuda.synchronize()
+else:
+    raise SystemExit("unknown workload " + what)
+print("done", what, reps)
