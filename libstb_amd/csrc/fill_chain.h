@@ -26,6 +26,7 @@ struct chain_args {
   const unsigned *ent_cnt;     // DOT = 2: its occurrence count
   unsigned nsg;                // DOT = 2: slices per trip in item_ptr
   double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
+  int poll_nap;                // s_sleep argument (64 cycles each) between two polls of a fetcher
   unsigned long long *dbg;     // diagnostic builds (make stamp): hand-off timeline [block<160][trip<1280][4]
   int mode;                    // diagnostic builds: 1 consumers only publish and release, 2 no table look-up,
                                // 3 the producer does not write the ring (results are wrong in all three)
@@ -40,6 +41,17 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
   asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
+}
+
+// the 32-bit LDS address of a __shared__ object, and a store of two doubles to `addr` + 8*OFF and
+// `addr` + 8*(OFF+1) whose sources may be any two register pairs
+typedef __attribute__((address_space(3))) double stb_lds_double;
+__device__ __forceinline__ unsigned lds_addr_of(double *p) { return (unsigned)(uintptr_t)(stb_lds_double *)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_store2(unsigned addr, double x, double y) {
+  static_assert(OFF >= 0 && OFF + 1 <= 255, "ds_write2_b64 offsets are 8 bits");
+  asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(OFF), "n"(OFF + 1)
+               : "memory");
 }
 
 // the cold part of a bounded wait on an LDS counter, out of line so that the callers' row loops stay

@@ -40,6 +40,9 @@
 
 #define ST_U CH_U    // rows per trip
 #define ST_RE CH_RE  // trips in the edge ring
+#ifndef ST_FK
+#define ST_FK 2      // polls a fetcher keeps in flight
+#endif
 
 // which wave does what: waves 0 .. P-1 produce; fetchers take the first later waves that share a
 // SIMD with a producer (waves go to SIMDs round-robin, and fetchers mostly sleep); the rest convert
@@ -262,10 +265,10 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
         q = 0;
         qi++;
       }
-      if (g + 1 < G) {
-        peek_counters(q);
-        load_left(en, g + 1);
-      }
+      // (unconditionally: past the last trip this reads ring slots that exist and uses nothing, and a
+      // load under a condition costs two register copies per row in the trip that consumes it)
+      peek_counters(q);
+      load_left(en, g + 1);
       if (__builtin_expect(g == g0w || tin == 0, 0)) {
         // ---- period set-up ----
         if (g != g0w) {  // renormalise: the lane's largest significand back to 2^-PC_BIAS * [0.5,1)
@@ -295,8 +298,20 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
         ebuf[p & 7][64 * w + lane] = ep;
       }
       double *slot = &vbuf[g & (RD - 1)][0][colw];
+      // The row stores are written out as ds_write2_b64: left to itself the compiler joins a lane's
+      // columns into ds_write_b128, whose source must be four adjacent registers, and pays for that
+      // with two to four register copies a row -- in a loop that is counted in instructions.  The
+      // two 8-bit offsets of ds_write2 (units of 8 bytes) reach two rows when the strip is 128
+      // columns wide, one row otherwise: one address register per `RB` rows.
+      constexpr int RB = (W + C - 1 <= 255) ? 2 : 1;
+      unsigned sbase[U / RB];
+      if (C >= 2) {
+        const unsigned sb = lds_addr_of(slot);
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+        for (int k = 0; k < U / RB; k++) sbase[k] = sb + (unsigned)(k * RB * W * 8);
+      }
+      auto row = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
         const double t0 = wave_shr1(v[C - 1], e[u]) * s;
 #pragma unroll
         for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
@@ -304,13 +319,25 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
 #pragma unroll
         for (int i = 0; i < C; i++) coef[i] += 1.0;
 #ifdef STB_STAMPS
-        if (X.mode == 3) continue;
+        if (X.mode == 3) return;
 #endif
-        // (8-byte stores: the compiler pairs them into ds_write2_b64, whose two sources need not be
-        // adjacent registers as a 16-byte store's must)
-#pragma unroll
-        for (int i = 0; i < C; i++) slot[u * W + i] = v[i];
-      }
+        if constexpr (C >= 2) {
+          constexpr int off = (u % RB) * W;
+          lds_store2<off>(sbase[u / RB], v[0], v[1]);
+          if constexpr (C == 4) lds_store2<off + 2>(sbase[u / RB], v[2], v[3]);
+        } else {
+          slot[u * W] = v[0];
+        }
+      };
+      static_assert(U == 8, "rows of a trip");
+      row(std::integral_constant<int, 0>{});
+      row(std::integral_constant<int, 1>{});
+      row(std::integral_constant<int, 2>{});
+      row(std::integral_constant<int, 3>{});
+      row(std::integral_constant<int, 4>{});
+      row(std::integral_constant<int, 5>{});
+      row(std::integral_constant<int, 6>{});
+      row(std::integral_constant<int, 7>{});
 #ifdef STB_STAMPS
       if (X.dbg && d == 0 && lane == 0 && w == P - 1 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 0] = wall_clock64();
 #endif
@@ -522,89 +549,106 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
     if (has_left) {
       const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
       const unsigned long long *ee_in = X.edge_e + ((uint64_t)d * X.B + (j - 1)) * X.NP;
-      unsigned long long t_begin = 0;
-      bool timing = false;
-      unsigned idle = 0;
-      for (int t = g0b; t < G;) {
-        // (NF fetcher waves run this same loop out of step: each delivers what its own load found
-        // complete beyond what has been delivered already, so the polling period divides by NF)
-        t = max(t, lds_peek(&edge_ready));
-        if (t >= G) break;
-        // trips t .. t+nt-1 may be written: their ring slots were read by the producer
-        int lim = lds_peek(&prod_done[0]) + RE - 1;
+      // A poll reads a window of 8 trips from the left strip's edge -- per lane one row's value (the
+      // row above the one it feeds), its trip's exponent and that of the trip before -- and delivers
+      // the leading trips it finds complete.  Store to visible load takes 0.4-0.5 us, the length of a
+      // producer's trip: FK polls are issued a fraction of that apart and then settled in order, so a
+      // poll may start below what an earlier one -- or another fetcher wave -- has delivered since; it
+      // delivers what lies beyond.  Everything a round needs from LDS is asked for a nap ahead, and
+      // nothing is exchanged between lanes: the wave shares its SIMD with the producer.
+      struct edge_poll {
+        unsigned long long va, e1, e0;
+        int tb, nt;
+      };
+      const int ka = lane >> 3;
+      int t = g0b;  // trips below it are delivered
+      int pd = lds_peek(&prod_done[0]);
+      auto issue = [&](edge_poll &p) {
+        // trips tb .. tb+nt-1 may be written: their ring slots were read by the producer
+        int lim = pd + RE - 1;
         if (lim > G) lim = G;
-        if (lim <= t) {
-          wait_ge(&prod_done[0], t - RE + 2, 0x800u, 2);
-          if (aborted) break;
-          continue;
-        }
-        const int nt = min(16, lim - t);
-        // 128 rows (the values one row above the rows they feed) and 17 trip exponents, one round trip
-        const int row0 = 2 + t * U;
-        const int ra = row0 + lane, rb = row0 + 64 + lane;
-        const bool need_a = lane < 8 * nt, need_b = 64 + lane < 8 * nt;
-        const bool need_e = lane <= nt;
-        unsigned long long va = 0, vb = 0, ve = 0;
-        if (need_a) va = __hip_atomic_load(ev_in + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (need_b) vb = __hip_atomic_load(ev_in + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (need_e) ve = __hip_atomic_load(ee_in + t - 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long ma = __ballot(!need_a || va != 0);
-        const unsigned long long mb = __ballot(!need_b || vb != 0);
-        const unsigned long long me = __ballot(!need_e || ve != 0);
-        int nr = 0;  // leading trips with all 8 rows, their exponent and the one before it present
-        for (; nr < nt; nr++) {
-          const unsigned long long rows = (nr < 8) ? (ma >> (8 * nr)) : (mb >> (8 * (nr - 8)));
-          if ((rows & 0xffull) != 0xffull || ((me >> nr) & 3ull) != 3ull) break;
-        }
-        if (nr == 0) {
-          // nothing new: poll again shortly; the clock, the error word and the abort flag (a scalar-cache
-          // and a memory round trip) are looked at once per 32 fruitless polls only
-          if ((++idle & 31) != 0 && X.timeout != 0) {
-            __builtin_amdgcn_s_sleep(2);  // (a spinning wave takes issue slots from the producer on its SIMD)
-            continue;
+        p.tb = t;
+        p.nt = max(0, min(8, lim - t));
+        // (every lane loads, t < G, and the arrays have room for the window past the last trip: a load
+        // under a condition would turn the wait for THIS poll's data into a wait for all loads in flight)
+        p.va = __hip_atomic_load(ev_in + 2 + t * U + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.e1 = __hip_atomic_load(ee_in + t + ka, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.e0 = __hip_atomic_load(ee_in + t + ka - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto settle = [&](const edge_poll &p) {
+        // leading trips with all 8 rows, their exponent and the one before it present
+        const unsigned long long miss = ~__ballot(p.va != 0 && p.e1 != 0 && p.e0 != 0);
+        const int nr = min(p.nt, miss ? (int)(__builtin_ctzll(miss) >> 3) : 8);
+        int cur = t;
+        if (NF > 1) cur = max(cur, lds_peek(&edge_ready));
+        t = cur;
+        if (p.tb + nr <= cur) return false;
+        const int ex = (int)(long long)(p.e1 - CH_EOFF);
+        double xa = __longlong_as_double((long long)p.va);
+        if (ka < nr && p.tb + ka >= cur) {
+          if ((lane & 7) == 0) {
+            // the first row of a trip comes from the trip before: bring it to this trip's exponent
+            xa = ldexp(xa, (int)(long long)(p.e0 - CH_EOFF) - ex);
+            edge_e[(p.tb + ka) & (RE - 1)] = ex;
           }
-          if (!timing) {
-            timing = true;
-            t_begin = wall_clock64();
-          }
-          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
-            if (lane == 0) {
-              __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (err == 0) {
-                __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            lds_post(&edge_ready, 0x7fffffff);  // release the producer: it runs on with stale edges
-            break;
-          }
-          continue;
-        }
-        timing = false;
-        idle = 0;
-        // exponent of each row's trip (lane q of ve holds trip t-1+q) and of the trip before it
-        const int ex = (int)(long long)(ve - CH_EOFF);
-        const int ka = lane >> 3, kb = 8 + (lane >> 3);
-        const int ea = __shfl(ex, ka + 1), ea1 = __shfl(ex, ka);
-        const int eb = __shfl(ex, kb + 1), eb1 = __shfl(ex, kb);
-        double xa = __longlong_as_double((long long)va), xb = __longlong_as_double((long long)vb);
-        // the first row of a trip comes from the trip before: bring it to this trip's exponent
-        if ((lane & 7) == 0) {
-          xa = ldexp(xa, ea1 - ea);
-          xb = ldexp(xb, eb1 - eb);
-        }
-        const int cur = lds_peek(&edge_ready);  // trips below it were delivered by another fetcher
-        if (ka < nr && t + ka >= cur) edge_in[((t + ka) & (RE - 1)) * U + (lane & 7)] = xa;
-        if (kb < nr && t + kb >= cur) edge_in[((t + kb) & (RE - 1)) * U + (lane & 7)] = xb;
-        if (lane >= 1 && lane <= nr && t - 1 + lane >= cur) edge_e[(t - 1 + lane) & (RE - 1)] = ex;
+          edge_in[((p.tb + ka) & (RE - 1)) * U + (lane & 7)] = xa;
 #ifdef STB_STAMPS
-        if (X.dbg && d == 0 && lane < nr && j < 160 && t + lane < 1280) X.dbg[((size_t)j * 1280 + t + lane) * 4 + 2] = wall_clock64();
+          if (X.dbg && d == 0 && (lane & 7) == 0 && j < 160 && p.tb + ka < 1280)
+            X.dbg[((size_t)j * 1280 + p.tb + ka) * 4 + 2] = wall_clock64();
 #endif
-        t += nr;
+        }
+        t = p.tb + nr;
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_max(&edge_ready, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
+        return true;
+      };
+      auto pause = [&]() {
+        // (a spinning wave takes issue slots from the producer on its SIMD)
+        if (X.poll_nap >= 4) __builtin_amdgcn_s_sleep(4);
+        else if (X.poll_nap == 3) __builtin_amdgcn_s_sleep(3);
+        else if (X.poll_nap == 2) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(1);
+      };
+      constexpr int FK = ST_FK;
+      edge_poll q[FK];
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      unsigned idle = 0;
+      while (t < G) {
+#pragma unroll
+        for (int i = 0; i < FK; i++) {
+          issue(q[i]);
+          if (i == FK - 1) pd = lds_peek(&prod_done[0]);  // (for the next round)
+          pause();
+        }
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < FK; i++) any = settle(q[i]) || any;
+        if (any) {
+          timing = false;
+          idle = 0;
+          continue;
+        }
+        // nothing new: the clock, the error word and the abort flag (a scalar-cache and a memory round
+        // trip) are looked at once per 32 fruitless rounds only
+        if ((++idle & 31) != 0 && X.timeout != 0) continue;
+        if (!timing) {
+          timing = true;
+          t_begin = wall_clock64();
+        }
+        const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+          if (lane == 0) {
+            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (err == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          lds_post(&edge_ready, 0x7fffffff);  // release the producer: it runs on with stale edges
+          break;
+        }
       }
     }
   }
@@ -905,6 +949,7 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   X.edge_e = (unsigned long long *)(ws + 256);
   X.edge_v = X.edge_e + (size_t)D * sg.B * X.NP;
   X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
+  X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
   HIPCHK(hipMemsetAsync(ws, 0, stb_align_up(sg.bytes, 16), st));
   *hdr_out = X.hdr;
   stb_launch_s1(A, D, st);

@@ -7,7 +7,7 @@ usage: python tools/timeline_chain.py [N] [out-file]        (run from the repo r
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libstb_amd import capi
-capi.LIB_PATH = capi.LIB_PATH.replace("libstb_amd.so", "libstb_amd_stamp.so")
+capi.LIB_PATH = os.environ.get("STB_LIB_PATH") or capi.LIB_PATH.replace("libstb_amd.so", "libstb_amd_stamp.so")
 import numpy as np, torch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/timeline_chain.txt"
@@ -61,6 +61,10 @@ for j in blocks[:-1]:
           f"  delivered->used {np.median(use):6.2f}  produced->used median {np.median(tot):6.2f} (p10 {np.percentile(tot,10):.2f} p90 {np.percentile(tot,90):.2f})")
     hist, edges = np.histogram(tot, bins=[0, 1, 1.5, 2, 2.5, 3, 3.5, 4, 5, 6, 8, 12, 1e9])
     print("   histogram of produced->used (us):", " ".join(f"<{e:g}:{h}" for h, e in zip(hist, edges[1:])))
+    # how the lag develops along the strip: the first trips, then every eighth of the way
+    idx = sorted(set(list(range(min(6, len(rows)))) + [len(rows) * q // 8 for q in range(1, 8)] + [len(rows) - 1]))
+    print("   trip: published->delivered, delivered->used, produced->used, own trip time:",
+          " ".join(f"{int(rows[i, 0])}:{dlv[i]:.2f},{use[i]:.2f},{tot[i]:.2f},{(rows[i, 4] - rows[i - 1, 4]) / 100.0 if i else 0:.2f}" for i in idx))
     k = len(rows) // 2
     print("   sample trips:", [(int(x[0]), round(us(x[1]), 1), round(us(x[2]), 1), round(us(x[3]), 1), round(us(x[4]), 1)) for x in rows[k:k + 4]])
 last = blocks[-1]
