@@ -40,6 +40,9 @@
 
 #define ST_U CH_U    // rows per trip
 #define ST_RE CH_RE  // trips in the edge ring
+#ifndef ST_LOOK
+#define ST_LOOK -1   // the row of a trip after which the next trip's counters and left inputs are read (-1: before row 0)
+#endif
 #ifndef ST_FK
 #define ST_FK 2      // polls a fetcher keeps in flight
 #endif
@@ -77,9 +80,12 @@ struct chain_roles {
 };
 
 // waves per SIMD the register allocation must leave room for: as many workgroups per compute unit
-// (up to four) as fit in LDS while every wave still gets 96 registers.  With many tables in flight
-// the strips that do not fit on the chip at once would otherwise wait for a free unit, and those are
-// the short strips at the right end of the tables, which could only start when the long ones end.
+// (up to four) as fit in LDS while a wave keeps at least 80 registers.  A workgroup's waves go to the
+// four SIMDs round-robin, ceil(WT/4) on the fullest, and the dispatcher only places a workgroup
+// whose waves all fit (placement census, tools/census_chain.py: with 96 registers a second
+// 10-wave workgroup was never co-resident; the strips that do not fit on the chip at once wait for a
+// free unit, and those are the short strips at the right end of the tables, which then start when the
+// long ones end).
 constexpr int chain_min_waves(int C, int P, int MG, int NF, int RD) {
   const int WT = P + MG * C * P + NF;
   const int lds = RD * ST_U * 64 * C * P * 8 + 8192;
@@ -87,13 +93,12 @@ constexpr int chain_min_waves(int C, int P, int MG, int NF, int RD) {
   return 1;
 #endif
   for (int nb = 4; nb >= 2; nb--)
-    if (nb * lds <= 160 * 1024 && (nb * WT + 3) / 4 <= 5) return (nb * WT + 3) / 4;
+    if (nb * lds <= 160 * 1024 && nb * ((WT + 3) / 4) <= 6) return nb * ((WT + 3) / 4);
   return 1;
 }
 
 template <int C, int P, int MG, int NF, int DOT, int RD>
-__global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, MG, NF, RD)) void k_fill_chain(fill_args A,
-                                                                                                   chain_args X) {
+__device__ __forceinline__ void chain_body(const fill_args &A, const chain_args &X) {
   constexpr int U = ST_U, RE = ST_RE;
   constexpr int S = C * P;      // 64-column slices per strip
   constexpr int NC = MG * S;    // consumer waves
@@ -103,13 +108,17 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
   static_assert(S <= 4 && WT <= 16 && NF >= 1 && MG >= 1 && (RD & (RD - 1)) == 0 && RD >= 2, "block shape");
   __shared__ double2 lt[128];
-  __shared__ __attribute__((aligned(16))) double vbuf[RD][U][W];
+  // (the ring is dynamic LDS -- RD*U*W*8 bytes at launch -- so that the compiler does not count it: it
+  // would relax `waves per SIMD` to the occupancy LDS allows with a workgroup's waves spread evenly over
+  // the SIMDs, 5 for two 10-wave workgroups, one short of what the fullest SIMD must hold)
+  extern __shared__ __attribute__((aligned(16))) double chain_ring[];
+  double(*vbuf)[U][W] = reinterpret_cast<double(*)[U][W]>(chain_ring);
   __shared__ int ebuf[8][64 * P];  // lane exponent per period (ring of 8 periods), per producer lane
   __shared__ __attribute__((aligned(16))) double edge_in[RE * U];
   __shared__ int edge_e[RE];
   __shared__ __attribute__((aligned(16))) unsigned long long cons_cnt64[MG][2];
   int(*cons_cnt)[4] = reinterpret_cast<int(*)[4]>(cons_cnt64);  // items done, per consumer [group][slice]
-  __shared__ int prod_done[P], edge_ready, s_abort;
+  __shared__ int prod_done[P], edge_ready, s_abort, s_awake;
   __shared__ int post_pad[64];  // where lanes 1..63 of a producer's progress post go (see the producers)
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
   if (tid == 0) {
     edge_ready = has_left ? g0b : 0x7fffffff;
     s_abort = 0;
+    s_awake = has_left ? 0 : 1;
   }
   __syncthreads();
 
@@ -155,6 +165,13 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
     if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, nap)) aborted = true;
   };
   auto period_of = [&](int t) { return (TP == 1) ? t : (int)__umulhi((unsigned)t, X.tp_magic); };
+  // A strip has nothing to do until the diagonal reaches it, and a workgroup that spins meanwhile slows
+  // the one it shares a compute unit with (8 tables: 1.55 ms against 1.35 with the last strips not even
+  // resident).  So everybody dozes -- one LDS look per ~1000 cycles -- until the fetcher has seen the
+  // left strip publish a trip shortly before the first one needed here.
+  auto doze = [&]() {
+    while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(16);
+  };
 
   if (role == 0) {
     // ================= producers =================
@@ -162,204 +179,263 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
     // counted in instructions: what a trip needs from other waves -- three kinds of counters and its
     // 8 left inputs -- is read while the previous trip is computed, and the rare cases sit behind one
     // unlikely branch each.
+    doze();
     __builtin_amdgcn_s_setprio(3);
-    const int w = (P == 1) ? 0 : ridx;  // (a compile-time constant for the one-producer shapes)
-    const int g0w = first_trip(C * w);
-    const double a = A.a[d];
-    const int colw = WP * w + lane * C;  // first of my C columns inside the strip
-    const int cl = c0 + colw;
-    double v[C], coef[C];
-#pragma unroll
-    for (int i = 0; i < C; i++) {
-      const int c = cl + i;
-      // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
-      v[i] = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
-      coef[i] = (double)(2 + g0w * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0w
-    }
-    double s = 1.0;
-    int ep = 1 + PC_BIAS;
-    int p = g0w / TP, tin = g0w - p * TP;
-    // the consumers that last read the ring slot a trip overwrites: trip g - RD, i.e. item kp = g - RD - g0b
-    // of the strip, which group q = kp % MG took as its (kp / MG)-th
-    int kp = g0w - RD - g0b, q = 0, qi = 0;
-    if (kp > 0) {
-      q = kp % MG;
-      qi = kp / MG;
-    }
-    const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w > 0 ? w - 1 : 0];
-    const int *next_cnt = &prod_done[(w < P - 1) ? w + 1 : w];
-    int n_left, n_next = 0;
-    int nc[C];
-    // the progress post as ONE store of the whole wave: lane 0 writes the counter, the other lanes a
-    // scratch word each (no exec masking: two scalar instructions and a branch less per trip)
-    int *post_addr = (lane == 0) ? &prod_done[w] : &post_pad[lane];
-    auto peek_counters = [&](int qq) {
-      n_left = lds_peek(left_cnt);
-      if (w < P - 1) n_next = lds_peek(next_cnt);
-      // (the C counters of a group are adjacent: 8-byte LDS reads)
-      if (C >= 2) {
-#pragma unroll
-        for (int i = 0; i < C; i += 2) {
-          const unsigned long long c2 =
-              __hip_atomic_load(&cons_cnt64[qq][(C * w + i) / 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          nc[i] = (int)(unsigned)c2;
-          nc[(i + 1) % C] = (int)(unsigned)(c2 >> 32);
-        }
-      } else {
-        nc[0] = lds_peek(&cons_cnt[qq][w]);
-      }
-      asm volatile("" ::: "memory");
-    };
-    auto load_left = [&](double(&x)[U], int g) {
-      if (w == 0) {
-        // (separate 8-byte reads: each lands in the register pair the row's DPP shift then overwrites,
-        // which a 16-byte read's register tuple does not allow without two copies per row)
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&edge_in[(g & (RE - 1)) * U]);
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          x[u] = __longlong_as_double((long long)__hip_atomic_load(src + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      } else {
-        // the last column of the producer to my left: row U-1 of trip g-1, rows 0..U-2 of trip g
-        const int ecol = (w > 0) ? WP * w - 1 : 0;
-        const double *b1 = &vbuf[g & (RD - 1)][0][ecol];
-        x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][ecol];
-#pragma unroll
-        for (int u = 1; u < U; u++) x[u] = b1[(u - 1) * W];
-      }
-    };
-    auto counters_ok = [&](int g) {
-      bool ok = n_left >= g + 1;
-      if (kp >= 0) {
-#pragma unroll
-        for (int i = 0; i < C; i++) ok = ok && nc[i] >= qi + 1;
-        // ... and the next producer has read its left inputs from it (rows of trip g - RD feed its
-        // trips g - RD and g - RD + 1)
-        if (w < P - 1) ok = ok && n_next >= g - RD + 2;
-      }
-      return ok;
-    };
-    // one trip: `e` holds its left inputs (read speculatively during the previous trip), `en`
-    // receives the next trip's
-    auto trip = [&](int g, double(&e)[U], double(&en)[U]) {
-      if (__builtin_expect(!counters_ok(g), 0)) {
-        // the counters were read a trip ago: look again (one LDS round trip) before settling down to wait
-        peek_counters(q);
-        load_left(e, g);
-        if (!counters_ok(g)) {
-          wait_ge(left_cnt, g + 1, 0x100u, 1);
-          if (kp >= 0) {
-#pragma unroll
-            for (int i = 0; i < C; i++) wait_ge(&cons_cnt[q][C * w + i], qi + 1, 0x300u, 1);  // slot g % RD converted
-            if (w < P - 1) wait_ge(next_cnt, g - RD + 2, 0x400u, 1);
-          }
-          asm volatile("" ::: "memory");
-          load_left(e, g);
-        }
-      }
+    // (one copy of the loop per producer wave of the block, each with its own index w folded in)
+    auto produce = [&](auto wc) {
+      constexpr int w = decltype(wc)::value;
 #ifdef STB_STAMPS
-      if (X.dbg && d == 0 && lane == 0 && w == 0 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 3] = wall_clock64();
-#endif
-      // the trip after this one: its slot was last read by item kp + 1
-      kp++;
-      if (kp > 0 && ++q == MG) {
-        q = 0;
-        qi++;
-      }
-      // (unconditionally: past the last trip this reads ring slots that exist and uses nothing, and a
-      // load under a condition costs two register copies per row in the trip that consumes it)
-      peek_counters(q);
-      load_left(en, g + 1);
-      if (__builtin_expect(g == g0w || tin == 0, 0)) {
-        // ---- period set-up ----
-        if (g != g0w) {  // renormalise: the lane's largest significand back to 2^-PC_BIAS * [0.5,1)
-          int kmax = -4000;
-#pragma unroll
-          for (int i = 0; i < C; i++)
-            if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
-          if (kmax > -4000) {
-#pragma unroll
-            for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
-            ep += kmax + PC_BIAS;
-          }
+      // placement census: where the producer of every strip ran (compute unit, SIMD, XCD) and when
+      unsigned long long *census = nullptr;
+      if (X.dbg && w == 0 && s_ticket < 1024u) {
+        census = X.dbg + (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + (size_t)s_ticket * 4;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) {
+          census[0] = (unsigned long long)j | ((unsigned long long)d << 16) | (1ull << 40);
+          census[1] = (unsigned long long)hw | ((unsigned long long)(xcc & 15u) << 32);
+          census[2] = wall_clock64();
         }
-        // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
-        int el = ep;
+      }
+#endif
+      const int g0w = first_trip(C * w);
+      const double a = A.a[d];
+      const int colw = WP * w + lane * C;  // first of my C columns inside the strip
+      const int cl = c0 + colw;
+      double v[C], coef[C];
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int c = cl + i;
+        // row 2 of the table: S^2_1 = 1 - a, S^2_2 = 1; everything else starts above the diagonal
+        v[i] = (c == 1) ? ldexp(1.0 - a, -1 - PC_BIAS) : (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+        coef[i] = (double)(2 + g0w * U) - (double)c * a;  // n - 1 - c a for the first row of trip g0w
+      }
+      double s = 1.0;
+      int ep = 1 + PC_BIAS;
+      int p = g0w / TP, tin = g0w - p * TP;
+      // the consumers that last read the ring slot a trip overwrites: trip g - RD, i.e. item kp = g - RD - g0b
+      // of the strip, which group q = kp % MG took as its (kp / MG)-th
+      int kp = g0w - RD - g0b, q = 0, qi = 0;
+      if (kp > 0) {
+        q = kp % MG;
+        qi = kp / MG;
+      }
+      const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w > 0 ? w - 1 : 0];
+      const int *next_cnt = &prod_done[(w < P - 1) ? w + 1 : w];
+      int n_left, n_next = 0;
+      int nc[C];
+#ifdef STB_STAMPS
+      unsigned long long st_relook = 0, st_wait = 0, st_left = 0, st_ticks = 0;
+#endif
+      // the progress post as ONE store of the whole wave: lane 0 writes the counter, the other lanes a
+      // scratch word each (no exec masking: two scalar instructions and a branch less per trip)
+      int *post_addr = (lane == 0) ? &prod_done[w] : &post_pad[lane];
+      auto peek_counters = [&](int qq) {
+        n_left = lds_peek(left_cnt);
+        if (w < P - 1) n_next = lds_peek(next_cnt);
+        // (the C counters of a group are adjacent: 8-byte LDS reads)
+        if (C >= 2) {
+#pragma unroll
+          for (int i = 0; i < C; i += 2) {
+            const unsigned long long c2 =
+                __hip_atomic_load(&cons_cnt64[qq][(C * w + i) / 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nc[i] = (int)(unsigned)c2;
+            nc[(i + 1) % C] = (int)(unsigned)(c2 >> 32);
+          }
+        } else {
+          nc[0] = lds_peek(&cons_cnt[qq][w]);
+        }
+        asm volatile("" ::: "memory");
+      };
+      auto load_left = [&](double(&x)[U], int g) {
         if (w == 0) {
-          if (has_left) el = edge_e[g & (RE - 1)];
+          // (separate 8-byte reads: each lands in the register pair the row's DPP shift then overwrites,
+          // which a 16-byte read's register tuple does not allow without two copies per row)
+          const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&edge_in[(g & (RE - 1)) * U]);
+#pragma unroll
+          for (int u = 0; u < U; u++)
+            x[u] = __longlong_as_double((long long)__hip_atomic_load(src + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         } else {
-          const int elane = (w > 0) ? 64 * w - 1 : 0;  // lane 63 of the producer to my left
-          el = ebuf[p & 7][elane];
-          // the row above the first row of a period was produced under the previous exponent
-          if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 7][elane] - el);
-        }
-        int dl = wave_shr1(ep, ep) - ep;
-        if (lane == 0) dl = el - ep;
-        s = ldexp(1.0, min(max(dl, -1100), 220));
-        ebuf[p & 7][64 * w + lane] = ep;
-      }
-      double *slot = &vbuf[g & (RD - 1)][0][colw];
-      // The row stores are written out as ds_write2_b64: left to itself the compiler joins a lane's
-      // columns into ds_write_b128, whose source must be four adjacent registers, and pays for that
-      // with two to four register copies a row -- in a loop that is counted in instructions.  The
-      // two 8-bit offsets of ds_write2 (units of 8 bytes) reach two rows when the strip is 128
-      // columns wide, one row otherwise: one address register per `RB` rows.
-      constexpr int RB = (W + C - 1 <= 255) ? 2 : 1;
-      unsigned sbase[U / RB];
-      if (C >= 2) {
-        const unsigned sb = lds_addr_of(slot);
+          // the last column of the producer to my left: row U-1 of trip g-1, rows 0..U-2 of trip g
+          const int ecol = (w > 0) ? WP * w - 1 : 0;
+          const double *b1 = &vbuf[g & (RD - 1)][0][ecol];
+          x[0] = vbuf[(g - 1) & (RD - 1)][U - 1][ecol];
 #pragma unroll
-        for (int k = 0; k < U / RB; k++) sbase[k] = sb + (unsigned)(k * RB * W * 8);
-      }
-      auto row = [&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        const double t0 = wave_shr1(v[C - 1], e[u]) * s;
-#pragma unroll
-        for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
-        v[0] = fma(coef[0], v[0], t0);
-#pragma unroll
-        for (int i = 0; i < C; i++) coef[i] += 1.0;
-#ifdef STB_STAMPS
-        if (X.mode == 3) return;
-#endif
-        if constexpr (C >= 2) {
-          constexpr int off = (u % RB) * W;
-          lds_store2<off>(sbase[u / RB], v[0], v[1]);
-          if constexpr (C == 4) lds_store2<off + 2>(sbase[u / RB], v[2], v[3]);
-        } else {
-          slot[u * W] = v[0];
+          for (int u = 1; u < U; u++) x[u] = b1[(u - 1) * W];
         }
       };
-      static_assert(U == 8, "rows of a trip");
-      row(std::integral_constant<int, 0>{});
-      row(std::integral_constant<int, 1>{});
-      row(std::integral_constant<int, 2>{});
-      row(std::integral_constant<int, 3>{});
-      row(std::integral_constant<int, 4>{});
-      row(std::integral_constant<int, 5>{});
-      row(std::integral_constant<int, 6>{});
-      row(std::integral_constant<int, 7>{});
+      auto counters_ok = [&](int g) {
+        bool ok = n_left >= g + 1;
+        if (kp >= 0) {
+#pragma unroll
+          for (int i = 0; i < C; i++) ok = ok && nc[i] >= qi + 1;
+          // ... and the next producer has read its left inputs from it (rows of trip g - RD feed its
+          // trips g - RD and g - RD + 1)
+          if (w < P - 1) ok = ok && n_next >= g - RD + 2;
+        }
+        return ok;
+      };
+      // one trip: `e` holds its left inputs (read speculatively during the previous trip), `en`
+      // receives the next trip's
+      auto trip = [&](int g, double(&e)[U], double(&en)[U]) {
+        if (__builtin_expect(!counters_ok(g), 0)) {
+          // the counters were read a trip ago: look again (one LDS round trip) before settling down to wait
 #ifdef STB_STAMPS
-      if (X.dbg && d == 0 && lane == 0 && w == P - 1 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 0] = wall_clock64();
+          const unsigned long long tw0 = wall_clock64();
+          st_relook++;
 #endif
-      asm volatile("" ::: "memory");
-      __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      asm volatile("" ::: "memory");
-      if (++tin == TP) {
-        tin = 0;
-        p++;
+          peek_counters(q);
+          load_left(e, g);
+          if (!counters_ok(g)) {
+#ifdef STB_STAMPS
+            st_wait++;
+            if (n_left < g + 1) st_left++;
+#endif
+            wait_ge(left_cnt, g + 1, 0x100u, 1);
+            if (kp >= 0) {
+#pragma unroll
+              for (int i = 0; i < C; i++) wait_ge(&cons_cnt[q][C * w + i], qi + 1, 0x300u, 1);  // slot g % RD converted
+              if (w < P - 1) wait_ge(next_cnt, g - RD + 2, 0x400u, 1);
+            }
+            asm volatile("" ::: "memory");
+            load_left(e, g);
+          }
+#ifdef STB_STAMPS
+          st_ticks += wall_clock64() - tw0;
+#endif
+        }
+#ifdef STB_STAMPS
+        if (X.dbg && d == 0 && lane == 0 && w == 0 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 3] = wall_clock64();
+#endif
+        // the trip after this one: its slot was last read by item kp + 1
+        kp++;
+        if (kp > 0 && ++q == MG) {
+          q = 0;
+          qi++;
+        }
+        // (unconditionally: past the last trip this reads ring slots that exist and uses nothing, and a
+        // load under a condition costs two register copies per row in the trip that consumes it)
+        auto look_ahead = [&]() {
+          peek_counters(q);
+          load_left(en, g + 1);
+        };
+        if (ST_LOOK < 0) look_ahead();
+        if (__builtin_expect(g == g0w || tin == 0, 0)) {
+          // ---- period set-up ----
+          if (g != g0w) {  // renormalise: the lane's largest significand back to 2^-PC_BIAS * [0.5,1)
+            int kmax = -4000;
+#pragma unroll
+            for (int i = 0; i < C; i++)
+              if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+            if (kmax > -4000) {
+#pragma unroll
+              for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+              ep += kmax + PC_BIAS;
+            }
+          }
+          // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
+          int el = ep;
+          if (w == 0) {
+            if (has_left) el = edge_e[g & (RE - 1)];
+          } else {
+            const int elane = (w > 0) ? 64 * w - 1 : 0;  // lane 63 of the producer to my left
+            el = ebuf[p & 7][elane];
+            // the row above the first row of a period was produced under the previous exponent
+            if (tin == 0 && p >= 1 && lane == 0) e[0] = ldexp(e[0], ebuf[(p - 1) & 7][elane] - el);
+          }
+          int dl = wave_shr1(ep, ep) - ep;
+          if (lane == 0) dl = el - ep;
+          s = ldexp(1.0, min(max(dl, -1100), 220));
+          ebuf[p & 7][64 * w + lane] = ep;
+        }
+        double *slot = &vbuf[g & (RD - 1)][0][colw];
+        // The row stores are written out as ds_write2_b64: left to itself the compiler joins a lane's
+        // columns into ds_write_b128, whose source must be four adjacent registers, and pays for that
+        // with two to four register copies a row -- in a loop that is counted in instructions.  The
+        // two 8-bit offsets of ds_write2 (units of 8 bytes) reach two rows when the strip is 128
+        // columns wide, one row otherwise: one address register per `RB` rows.
+        constexpr int RB = (W + C - 1 <= 255) ? 2 : 1;
+        unsigned sbase[U / RB];
+        if (C >= 2) {
+          const unsigned sb = lds_addr_of(slot);
+#pragma unroll
+          for (int k = 0; k < U / RB; k++) sbase[k] = sb + (unsigned)(k * RB * W * 8);
+        }
+        auto row = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          const double t0 = wave_shr1(v[C - 1], e[u]) * s;
+#pragma unroll
+          for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+          v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+          for (int i = 0; i < C; i++) coef[i] += 1.0;
+#ifdef STB_STAMPS
+          if (X.mode == 3) return;
+#endif
+          if constexpr (C >= 2) {
+            constexpr int off = (u % RB) * W;
+            lds_store2<off>(sbase[u / RB], v[0], v[1]);
+            if constexpr (C == 4) lds_store2<off + 2>(sbase[u / RB], v[2], v[3]);
+          } else {
+            slot[u * W] = v[0];
+          }
+        };
+        static_assert(U == 8, "rows of a trip");
+        row(std::integral_constant<int, 0>{});
+        if (ST_LOOK == 0) look_ahead();
+        row(std::integral_constant<int, 1>{});
+        if (ST_LOOK == 1) look_ahead();
+        row(std::integral_constant<int, 2>{});
+        if (ST_LOOK == 2) look_ahead();
+        row(std::integral_constant<int, 3>{});
+        if (ST_LOOK == 3) look_ahead();
+        row(std::integral_constant<int, 4>{});
+        if (ST_LOOK == 4) look_ahead();
+        row(std::integral_constant<int, 5>{});
+        if (ST_LOOK == 5) look_ahead();
+        row(std::integral_constant<int, 6>{});
+        if (ST_LOOK == 6) look_ahead();
+        row(std::integral_constant<int, 7>{});
+        if (ST_LOOK == 7) look_ahead();
+#ifdef STB_STAMPS
+        if (X.dbg && d == 0 && lane == 0 && w == P - 1 && j < 160 && g < 1280) X.dbg[((size_t)j * 1280 + g) * 4 + 0] = wall_clock64();
+#endif
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (++tin == TP) {
+          tin = 0;
+          p++;
+        }
+      };
+      double ea[U], eb[U];
+      peek_counters(q);
+      load_left(ea, g0w);
+      int g = g0w;
+      for (; g + 1 < G; g += 2) {
+        trip(g, ea, eb);
+        trip(g + 1, eb, ea);
       }
+      if (g < G) trip(g, ea, eb);
+#ifdef STB_STAMPS
+      if (census && lane == 0) census[3] = wall_clock64();
+      if (X.dbg && d == 0 && lane == 0 && j < 160 && w < 8) {  // looked again, waited, waited for the left input, ticks
+        unsigned long long *o = X.dbg + (size_t)160 * 1280 * 4 + ((size_t)j * 8 + w) * 4;
+        o[0] = st_relook;
+        o[1] = st_wait;
+        o[2] = st_left;
+        o[3] = st_ticks;
+      }
+#endif
     };
-    double ea[U], eb[U];
-    peek_counters(q);
-    load_left(ea, g0w);
-    int g = g0w;
-    for (; g + 1 < G; g += 2) {
-      trip(g, ea, eb);
-      trip(g + 1, eb, ea);
-    }
-    if (g < G) trip(g, ea, eb);
+    if (P == 1 || ridx == 0) produce(std::integral_constant<int, 0>{});
+    else if (ridx == 1) produce(std::integral_constant<int, (P >= 2) ? 1 : 0>{});
+    else if (ridx == 2) produce(std::integral_constant<int, (P >= 4) ? 2 : 0>{});
+    else produce(std::integral_constant<int, (P >= 4) ? 3 : 0>{});
   } else if (role == 1) {
     // ================= consumers =================
+    doze();
     const int ci = ridx;
     const int sl = ci % S, qg = ci / S;
     const int wv = sl / C;           // the producer wave that owns the slice
@@ -544,7 +620,7 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
       for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) X.dotp[((uint64_t)d * X.B + j) * NC + ci] = acc;
     }
-  } else {
+  } else if (role == 2) {
     // ================= fetchers =================
     if (has_left) {
       const unsigned long long *ev_in = X.edge_v + ((uint64_t)d * X.B + (j - 1)) * X.EV;
@@ -562,6 +638,22 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
       };
       const int ka = lane >> 3;
       int t = g0b;  // trips below it are delivered
+      {
+        // the left strip publishes from its trip g0b - 8 on (the first trip of its last 64 columns): wait,
+        // dozing, for the exponent granule of trip g0b - 6, then wake the workgroup
+        const unsigned long long *probe = ee_in + max(g0b - 6, 0);
+        unsigned long long t_begin = 0;
+        unsigned spins = 0;
+        while (__hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(16);
+          if ((++spins & 255u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || lds_peek(&s_abort) ||
+              (unsigned long long)wall_clock64() - t_begin >= X.timeout)
+            break;  // (the main loop below gives up properly)
+        }
+        lds_post(&s_awake, 1);
+      }
       int pd = lds_peek(&prod_done[0]);
       auto issue = [&](edge_poll &p) {
         // trips tb .. tb+nt-1 may be written: their ring slots were read by the producer
@@ -652,6 +744,13 @@ __global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, M
       }
     }
   }
+}
+
+
+template <int C, int P, int MG, int NF, int DOT, int RD>
+__global__ __launch_bounds__(64 * (P + MG * C * P + NF), chain_min_waves(C, P, MG, NF, RD)) void k_fill_chain(fill_args A,
+                                                                                                   chain_args X) {
+  chain_body<C, P, MG, NF, DOT, RD>(A, X);
 }
 
 
@@ -965,14 +1064,15 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   X.dbg = nullptr;
   X.mode = stb_env_int("STB_CHAIN_DEBUG", 0);
   if (getenv("STB_TIMELINE_FILE")) {
-    if (!g_chain_dbg) HIPCHK(hipMalloc(&g_chain_dbg, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4)));
-    HIPCHK(hipMemsetAsync(g_chain_dbg, 0, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4), st));
+    if (!g_chain_dbg) HIPCHK(hipMalloc(&g_chain_dbg, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + 1024 * 4)));
+    HIPCHK(hipMemsetAsync(g_chain_dbg, 0, sizeof(unsigned long long) * (160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + 1024 * 4), st));
     X.dbg = g_chain_dbg;
   }
 #endif
   const dim3 grid((unsigned)sg.B * (unsigned)D);
 #define STRIP1(CC, PP, MM, FF, DD, RR) \
-  STB_LAUNCH((k_fill_chain<CC, PP, MM, FF, DD, RR>), grid, dim3(64 * (PP + MM * CC * PP + FF)), st, A, X)
+  STB_LAUNCH_SHM((k_fill_chain<CC, PP, MM, FF, DD, RR>), grid, dim3(64 * (PP + MM * CC * PP + FF)), \
+                 (size_t)RR * ST_U * 64 * CC * PP * sizeof(double), st, A, X)
 #define STRIP(CC, PP, MM, FF, RR)                   \
   do {                                              \
     if (dk == 2) STRIP1(CC, PP, MM, FF, 2, RR);     \
@@ -993,6 +1093,8 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
     case 21214: STRIP1(2, 1, 2, 1, 0, 4); break;
     case 11314: STRIP1(1, 1, 3, 1, 0, 4); break;
     case 12328: STRIP1(1, 2, 3, 2, 0, 8); break;
+    case 12318: STRIP1(1, 2, 3, 1, 0, 8); break;
+    case 12314: STRIP1(1, 2, 3, 1, 0, 4); break;
     case 14228: STRIP1(1, 4, 2, 2, 0, 8); break;
     case 22218: STRIP1(2, 2, 2, 1, 0, 8); break;
     default:
@@ -1004,7 +1106,7 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
 #ifdef STB_STAMPS
   if (X.dbg) {
     HIPCHK(hipStreamSynchronize(st));
-    const size_t cnt = (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4;
+    const size_t cnt = (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + 1024 * 4;
     unsigned long long *h = (unsigned long long *)malloc(cnt * sizeof(*h));
     HIPCHK(hipMemcpy(h, X.dbg, cnt * sizeof(*h), hipMemcpyDeviceToHost));
     FILE *f = fopen(getenv("STB_TIMELINE_FILE"), "w");
@@ -1024,6 +1126,16 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
         if (q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, 200000 + ww, q[0], q[1], q[2], q[3]);
       }
     fclose(f);
+    if (getenv("STB_CENSUS_FILE")) {  // ticket, strip, table, HW_ID, XCC_ID, first and last clock of the producer
+      f = fopen(getenv("STB_CENSUS_FILE"), "w");
+      for (int k = 0; k < 1024; k++) {
+        unsigned long long *q = h + (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + (size_t)k * 4;
+        if (q[0])
+          fprintf(f, "%d %llu %llu %llu %llu %llu %llu\n", k, q[0] & 0xffffull, (q[0] >> 16) & 0xffffull, q[1] & 0xffffffffull,
+                  q[1] >> 32, q[2], q[3]);
+      }
+      fclose(f);
+    }
     free(h);
   }
 #endif

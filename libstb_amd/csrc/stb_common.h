@@ -92,15 +92,16 @@ struct fill_args {
 
 // per-launch timing (fill.hip): when armed, a launch gets a begin/end event pair
 void stb_prof_events(hipEvent_t *e0, hipEvent_t *e1);
-#define STB_LAUNCH(KERN, GRID, BLOCK, ST, ...)                                          \
+#define STB_LAUNCH_SHM(KERN, GRID, BLOCK, SHM, ST, ...)                                 \
   do {                                                                                  \
     hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                          \
     stb_prof_events(&pe0_, &pe1_);                                                      \
     if (pe0_)                                                                           \
-      hipExtLaunchKernelGGL(KERN, GRID, BLOCK, 0, ST, pe0_, pe1_, 0, __VA_ARGS__);      \
+      hipExtLaunchKernelGGL(KERN, GRID, BLOCK, SHM, ST, pe0_, pe1_, 0, __VA_ARGS__);    \
     else                                                                                \
-      hipLaunchKernelGGL(KERN, GRID, BLOCK, 0, ST, __VA_ARGS__);                        \
+      hipLaunchKernelGGL(KERN, GRID, BLOCK, SHM, ST, __VA_ARGS__);                      \
   } while (0)
+#define STB_LAUNCH(KERN, GRID, BLOCK, ST, ...) STB_LAUNCH_SHM(KERN, GRID, BLOCK, 0, ST, __VA_ARGS__)
 
 // rows per renormalisation period of the block-floating forms that start a period at 2^-700
 int stb_period_rows(unsigned N);
