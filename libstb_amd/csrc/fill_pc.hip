@@ -18,9 +18,15 @@
 // the PC_U logs a consumer lane owns per trip are evaluated stage-major for ILP.
 // log S^n_1 (the S1 vector) is not produced here: k_s1 evaluates lgamma(n-a) - lgamma(1-a).
 #define PC_U 8
+#ifndef PC_ST
+#define PC_ST 4   // rows a consumer lane converts at once
+#endif
+#ifndef PC_MINW
+#define PC_MINW 6  // waves per SIMD the register allocation leaves room for
+#endif
 
 template <int NCW>
-__global__ __launch_bounds__(64 * (1 + NCW)) void k_fill_pc(fill_args A, int k, int P) {
+__global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A, int k, int P) {
   constexpr int C = 4;
   constexpr int OW = 64 * NCW;      // owned (stored) columns per block
   constexpr int H = 256 - OW;       // halo columns recomputed per block
@@ -141,40 +147,45 @@ __global__ __launch_bounds__(64 * (1 + NCW)) void k_fill_pc(fill_args A, int k, 
           const int r0 = ns + (q - 1) * PC_U;
           const int cnt = min(PC_U, ne - r0 + 1);
           if (cnt == PC_U) {
-            // U rows of my column, stage-major
-            double x[PC_U], z[PC_U], kf[PC_U], r[PC_U], pl[PC_U];
-            double2 t[PC_U];
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) x[u] = vbuf[(q - 1) & 1][u][ridx];
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) {
-              const int hi = __double2hiint(x[u]);
-              z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
-              kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
-            }
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) r[u] = fma(z[u], t[u].x, -1.0);
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], 0.2, -0.25);
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], -0.5);
-#pragma unroll
-            for (int u = 0; u < PC_U; u++) pl[u] = fma(r[u], pl[u], 1.0);
+            // U rows of my column, stage-major PC_ST rows at a time (8 at once need 116 registers: 4
+            // waves per SIMD; 4 at once fit 80: 6 waves, i.e. 8 workgroups per compute unit)
             const unsigned pitch = stb_row_pitch((unsigned)r0, M);
-            if (stb_row_pitch((unsigned)(r0 + PC_U - 1), M) == pitch) {
+            const bool same_pitch = stb_row_pitch((unsigned)(r0 + PC_U - 1), M) == pitch;
 #pragma unroll
-              for (int u = 0; u < PC_U; u++)
-                rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
-              rowbase += (size_t)PC_U * pitch;
-            } else {
+            for (int h = 0; h < PC_U; h += PC_ST) {
+              double x[PC_ST], z[PC_ST], kf[PC_ST], r[PC_ST], pl[PC_ST];
+              double2 t[PC_ST];
 #pragma unroll
-              for (int u = 0; u < PC_U; u++) {
-                rowbase[coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
-                rowbase += stb_row_pitch((unsigned)(r0 + u), M);
+              for (int u = 0; u < PC_ST; u++) x[u] = vbuf[(q - 1) & 1][h + u][ridx];
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) t[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) {
+                const int hi = __double2hiint(x[u]);
+                z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+                kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+              }
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) r[u] = fma(z[u], t[u].x, -1.0);
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+              for (int u = 0; u < PC_ST; u++) pl[u] = fma(r[u], pl[u], 1.0);
+              if (same_pitch) {
+#pragma unroll
+                for (int u = 0; u < PC_ST; u++)
+                  rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                rowbase += (size_t)PC_ST * pitch;
+              } else {
+#pragma unroll
+                for (int u = 0; u < PC_ST; u++) {
+                  rowbase[coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                  rowbase += stb_row_pitch((unsigned)(r0 + h + u), M);
+                }
               }
             }
           } else {
