@@ -103,6 +103,9 @@ void stb_pool_trim(void);
  * synchronised before _end): sum of the per-launch device durations in ms and their count */
 void stb_fill_profile_begin(void);
 int stb_fill_profile_end(double *kernel_ms_total, int *launches);
+/* device time in ms from the first of those launches' start to the last one's end (large batches of
+ * the producer/consumer form run two sub-batches side by side, so the sum counts that time twice) */
+double stb_fill_profile_span(void);
 /* V tables (next row 8f-1): V^n_m for 2<=n<=N, 2<=m<=min(n,M); lib/stable.c:451-482 */
 int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
                uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);

@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
     sig("stb_has_ablation", i, [])
     sig("stb_fill_profile_begin", None, [])
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
+    sig("stb_fill_profile_span", C.c_double, [])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
     sig("stb_table_to_float", i, [vp, vp, u64, vp])
     sig("stb_lookup_S", i, [vp, vp, u, u, vp, vp, u64, vp, vp])

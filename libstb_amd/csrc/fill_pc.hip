@@ -244,6 +244,29 @@ int stb_launch_s1(const fill_args &A, int D, hipStream_t st) {
 }
 
 // rows 2..N in launches of A.R rows; A.H = 256 - 64 * consumers; A.R <= A.H
+//
+// Every launch ends with compute units running dry while its last workgroups finish (a workgroup
+// takes ~20 us, a launch of 64 tables 30-100 us), and the next launch cannot start before: the kernel
+// boundary is what publishes the frontier.  Tables do not depend on each other, so a large batch is
+// cut into STB_PC_STREAMS (default 2 from 24 tables on) sub-batches whose launches go to streams of
+// their own, forked from and joined to the caller's stream by events: one sub-batch's tail is filled
+// by the other's workgroups.
+struct pc_side_streams {
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+};
+static thread_local pc_side_streams g_side[16];
+
+static fill_args pc_slice(const fill_args &A, int d0) {
+  fill_args B = A;
+  B.a = A.a + d0;
+  B.tables = A.tables + (uint64_t)d0 * A.tstride;
+  B.S1 = A.S1 + (uint64_t)d0 * A.s1stride;
+  B.fm = A.fm + (uint64_t)d0 * 2 * A.W;
+  B.fe = A.fe + (uint64_t)d0 * 2 * A.W;
+  return B;
+}
+
 int stb_launch_pc(fill_args &A, int D, hipStream_t st) {
   const int N = (int)A.N, M = (int)A.M, R = A.R;
   const int ncw = (256 - A.H) / 64;
@@ -256,19 +279,52 @@ int stb_launch_pc(fill_args &A, int D, hipStream_t st) {
     const int per = (R + p - 1) / p;
     return (R + per - 1) / per;
   }();
-  stb_launch_s1(A, D, st);
+  int ns = stb_env_int("STB_PC_STREAMS", D >= 24 ? 2 : 1);
+  if (ns < 1) ns = 1;
+  if (ns > 4) ns = 4;
+  if (ns > D) ns = D;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  pc_side_streams &S = g_side[dev & 15];
+  hipStream_t str[4] = {st, nullptr, nullptr, nullptr};
+  if (ns > 1) {
+    if (!S.fork) HIPCHK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(S.fork, st));
+    for (int i = 1; i < ns; i++) {
+      if (!S.s[i - 1]) {
+        HIPCHK(hipStreamCreateWithFlags(&S.s[i - 1], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&S.join[i - 1], hipEventDisableTiming));
+      }
+      str[i] = S.s[i - 1];
+      HIPCHK(hipStreamWaitEvent(str[i], S.fork, 0));
+    }
+  }
+  fill_args sub[4];
+  int dn[4];
+  for (int i = 0; i < ns; i++) {
+    const int d0 = (int)((int64_t)D * i / ns), d1 = (int)((int64_t)D * (i + 1) / ns);
+    sub[i] = pc_slice(A, d0);
+    dn[i] = d1 - d0;
+    stb_launch_s1(sub[i], dn[i], str[i]);
+  }
   const int nlaunch = (N - 1 + R - 1) / R;
   for (int k = 0; k < nlaunch; k++) {
     int n1 = 2 + (k + 1) * R - 1;
     if (n1 > N) n1 = N;
     int ncols = (n1 < M ? n1 : M) - 1;
     if (ncols < 1) ncols = 1;
-    const dim3 grid((ncols + OW - 1) / OW, D);
-    if (ncw == 3)
-      STB_LAUNCH((k_fill_pc<3>), grid, dim3(256), st, A, k, P);
-    else
-      STB_LAUNCH((k_fill_pc<2>), grid, dim3(192), st, A, k, P);
+    for (int i = 0; i < ns; i++) {
+      const dim3 grid((ncols + OW - 1) / OW, dn[i]);
+      if (ncw == 3)
+        STB_LAUNCH((k_fill_pc<3>), grid, dim3(256), str[i], sub[i], k, P);
+      else
+        STB_LAUNCH((k_fill_pc<2>), grid, dim3(192), str[i], sub[i], k, P);
+    }
   }
   HIPCHK(hipGetLastError());
+  for (int i = 1; i < ns; i++) {
+    HIPCHK(hipEventRecord(S.join[i - 1], str[i]));
+    HIPCHK(hipStreamWaitEvent(st, S.join[i - 1], 0));
+  }
   return 0;
 }
