@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 stats() {  # name, then the python3 command line
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 "$@" > $OUT/$name.stdout 2> $OUT/$name.stderr
-  local f=$(ls $OUT/$name/*/*kernel_stats.csv 2>/dev/null | tail -1)
+  local f=$(find $OUT/$name -name "*kernel_stats.csv" 2>/dev/null | tail -1)
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
   echo "stats $name: $(head -3 $OUT/${name}_kernel_stats.csv 2>/dev/null | tail -2 | cut -c1-150)"
 }
