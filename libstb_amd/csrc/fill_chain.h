@@ -26,7 +26,6 @@ struct chain_args {
   const unsigned *ent_cnt;     // DOT = 2: its occurrence count
   unsigned nsg;                // DOT = 2: slices per trip in item_ptr
   double *dotp;                // DOT kernels: [D][B][NC] partial sums of count * log S
-  int pace;                    // (experiment) idle time per trip of the first strip, in units of 16 cycles
   int poll_nap;                // s_sleep argument (64 cycles each) between two polls of a fetcher
   unsigned long long *dbg;     // diagnostic builds (make stamp): hand-off timeline [block<160][trip<1280][4]
   int mode;                    // diagnostic builds: 1 consumers only publish and release, 2 no table look-up,

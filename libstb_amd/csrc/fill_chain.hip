@@ -404,9 +404,6 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
         asm volatile("" ::: "memory");
         __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        // (experiment: the first strip sets the pace of all; X.pace x 16 idle cycles a trip there)
-        if (j == 0 && X.pace > 0)
-          for (int i = 0; i < X.pace; i++) asm volatile("s_nop 15");
         if (++tin == TP) {
           tin = 0;
           p++;
@@ -1052,7 +1049,6 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   X.edge_v = X.edge_e + (size_t)D * sg.B * X.NP;
   X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
   X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
-  X.pace = stb_env_int("STB_CHAIN_PACE", 0);
   HIPCHK(hipMemsetAsync(ws, 0, stb_align_up(sg.bytes, 16), st));
   *hdr_out = X.hdr;
   stb_launch_s1(A, D, st);

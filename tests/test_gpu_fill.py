@@ -1,10 +1,12 @@
 """GPU parity: the HIP table fill (K1/K2) through the C ABI against the CPU oracle and the golden
 fixtures dumped from the reference.  Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import ctypes as C
 import json
 import os
 
 import numpy as np
 import pytest
+import torch
 
 import orc
 from libstb_amd import capi, synth
@@ -362,3 +364,50 @@ def test_set_device_is_recorded_by_tables():
     prev = L.stb_device_enter(0)
     L.stb_device_leave(prev)
     t.free()
+
+
+def test_pc_sub_batches_on_forked_streams(monkeypatch):
+    """from 24 tables on k_fill_pc runs two halves of the batch on two internal streams forked from
+    and joined to the caller's: same tables as one stream gives, for a batch that does not split
+    evenly, and work queued behind the fill on the caller's stream sees the finished tables"""
+    N, M, D = 700, 500, 27
+    a = synth.discount_grid(64)[:D]
+    monkeypatch.setenv("STB_PC_STREAMS", "1")
+    T1 = capi.DeviceTables(N, M, D=D)
+    T1.fill(a, capi.FILL_PC)
+    T1.status()
+    for ns in ("2", "3"):
+        monkeypatch.setenv("STB_PC_STREAMS", ns)
+        T2 = capi.DeviceTables(N, M, D=D)
+        T2.tables.fill_(float("nan"))
+        T2.fill(a, capi.FILL_PC)
+        after = T2.tables.clone()        # queued on the same stream behind the fill, nothing synchronised in between
+        T2.status()
+        for d in (0, D // 2 - 1, D // 2, D - 1):
+            for n in (3, 129, N):
+                o = T2.rowoff(n)
+                ln = T2.row(d, n).numel()
+                assert torch.equal(T2.row(d, n), T1.row(d, n)), (ns, d, n)
+                assert torch.equal(after[d, o:o + ln], T1.row(d, n)), (ns, d, n)
+    monkeypatch.delenv("STB_PC_STREAMS")
+    tab = orc.fill_S(float(a[D - 1]), N, M)[1]
+    assert orc.max_err(T1.packed_host(D - 1), tab) <= TOL
+
+
+def test_profile_span_of_overlapping_launches():
+    """stb_fill_profile_end sums the launches' device times, stb_fill_profile_span is first start to
+    last end: equal-ish for one stream, the span clearly shorter when two sub-batches overlap"""
+    L = capi.lib()
+    T = capi.DeviceTables(4000, 4000, D=32)
+    a = synth.discount_grid(64)[:32]
+    T.fill(a, capi.FILL_PC)
+    torch.cuda.synchronize()
+    L.stb_fill_profile_begin()
+    T.fill(a, capi.FILL_PC)
+    torch.cuda.synchronize()
+    ms, n = C.c_double(0.0), C.c_int(0)
+    capi.check(L.stb_fill_profile_end(C.byref(ms), C.byref(n)))
+    span = L.stb_fill_profile_span()
+    T.status()
+    assert n.value > 2 and 0.0 < span <= ms.value * 1.001
+    assert span < 0.8 * ms.value        # two streams ran side by side
