@@ -187,6 +187,7 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
 #ifdef STB_STAMPS
       // placement census: where the producer of every strip ran (compute unit, SIMD, XCD) and when
       unsigned long long *census = nullptr;
+      unsigned long long census_c0 = 0;
       if (X.dbg && w == 0 && s_ticket < 1024u) {
         census = X.dbg + (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + (size_t)s_ticket * 4;
         unsigned hw, xcc;
@@ -196,6 +197,7 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
           census[0] = (unsigned long long)j | ((unsigned long long)d << 16) | (1ull << 40);
           census[1] = (unsigned long long)hw | ((unsigned long long)(xcc & 15u) << 32);
           census[2] = wall_clock64();
+          census_c0 = clock64();
         }
       }
 #endif
@@ -419,7 +421,10 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
       }
       if (g < G) trip(g, ea, eb);
 #ifdef STB_STAMPS
-      if (census && lane == 0) census[3] = wall_clock64();
+      if (census && lane == 0) {
+        census[3] = wall_clock64();
+        census[1] |= ((unsigned long long)(clock64() - census_c0) >> 10) << 36;  // shader cycles / 1024 of the producer's life
+      }
       if (X.dbg && d == 0 && lane == 0 && j < 160 && w < 8) {  // looked again, waited, waited for the left input, ticks
         unsigned long long *o = X.dbg + (size_t)160 * 1280 * 4 + ((size_t)j * 8 + w) * 4;
         o[0] = st_relook;
@@ -1126,13 +1131,13 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
         if (q[3]) fprintf(f, "%d %d %llu %llu %llu %llu\n", jj, 200000 + ww, q[0], q[1], q[2], q[3]);
       }
     fclose(f);
-    if (getenv("STB_CENSUS_FILE")) {  // ticket, strip, table, HW_ID, XCC_ID, first and last clock of the producer
+    if (getenv("STB_CENSUS_FILE")) {  // ticket, strip, table, HW_ID, XCC_ID, first and last wall clock of the producer, its shader cycles
       f = fopen(getenv("STB_CENSUS_FILE"), "w");
       for (int k = 0; k < 1024; k++) {
         unsigned long long *q = h + (size_t)160 * 1280 * 4 + 160 * 8 * 4 + 160 * 16 * 4 + (size_t)k * 4;
         if (q[0])
-          fprintf(f, "%d %llu %llu %llu %llu %llu %llu\n", k, q[0] & 0xffffull, (q[0] >> 16) & 0xffffull, q[1] & 0xffffffffull,
-                  q[1] >> 32, q[2], q[3]);
+          fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", k, q[0] & 0xffffull, (q[0] >> 16) & 0xffffull, q[1] & 0xffffffffull,
+                  (q[1] >> 32) & 15ull, q[2], q[3], (q[1] >> 36) << 10);
       }
       fclose(f);
     }

@@ -17,7 +17,7 @@ os.environ["STB_CENSUS_FILE"] = "gpurun_out/census_chain.txt"
 T.fill(a, capi.FILL_CHAIN); torch.cuda.synchronize()
 T.status()
 r = np.loadtxt("gpurun_out/census_chain.txt", dtype=np.int64, ndmin=2)
-tick, strip, table, hw, xcc, t0, t1 = r.T
+tick, strip, table, hw, xcc, t0, t1, cyc = r.T
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 unit = xcc * 1000 + se * 100 + sh * 16 + cu          # one compute unit
 print(f"{len(r)} producers recorded (tickets < 1024); {len(set(unit))} compute units used; XCDs {sorted(set(xcc))}")
@@ -47,4 +47,7 @@ for tb in sorted(set(table.tolist()))[:2]:
     m = table == tb
     o = np.argsort(strip[m])
     print(f"table {tb}: strip: start us / producer time us:", " ".join(f"{int(s_)}:{a_:.0f}/{b_:.0f}" for s_, a_, b_ in list(zip(strip[m][o], start[m][o], dur[m][o]))[::max(1, m.sum() // 10)]))
+long_ = (t1 - t0) > 0.5 * (t1 - t0).max()
+mhz = cyc[long_] / ((t1 - t0)[long_] / 100.0)
+print(f"shader clock seen by the long-lived producers (s_memtime cycles per wall-clock us): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
 print(f"first producer start -> last producer end: {(t1.max() - t0.min()) / 100.0:.1f} us")
