@@ -121,9 +121,10 @@ extern "C" int stb_has_ablation(void) { return stb_ablation_fill != nullptr; }
 
 // STB_FILL_SCALED picks the form by how many table columns are in flight: the chain form (one
 // launch, no halo) up to STB_CHAIN_MAX_COLS columns over all tables, the producer/consumer form
-// beyond.
+// beyond.  (MI355X, tools/ab_chain.py: 16 tables of 10^4 columns 2.01 ms pc against 2.11 chain, 12
+// tables 1.78 against 1.68; 32 tables of 4000 columns 0.78 against 0.70.)
 static bool chain_wins(unsigned N, unsigned M, int D) {
-  const uint64_t cap = (uint64_t)stb_env_int("STB_CHAIN_MAX_COLS", 200000);
+  const uint64_t cap = (uint64_t)stb_env_int("STB_CHAIN_MAX_COLS", 150000);
   return (uint64_t)D * M <= cap && N >= 3 && N < (1u << 27);
 }
 

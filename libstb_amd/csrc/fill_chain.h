@@ -43,17 +43,6 @@ __device__ __forceinline__ void lds_post(int *p, int v) {
   asm volatile("" ::: "memory");
 }
 
-// the 32-bit LDS address of a __shared__ object, and a store of two doubles to `addr` + 8*OFF and
-// `addr` + 8*(OFF+1) whose sources may be any two register pairs
-typedef __attribute__((address_space(3))) double stb_lds_double;
-__device__ __forceinline__ unsigned lds_addr_of(double *p) { return (unsigned)(uintptr_t)(stb_lds_double *)p; }
-template <int OFF>
-__device__ __forceinline__ void lds_store2(unsigned addr, double x, double y) {
-  static_assert(OFF >= 0 && OFF + 1 <= 255, "ds_write2_b64 offsets are 8 bits");
-  asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(OFF), "n"(OFF + 1)
-               : "memory");
-}
-
 // the cold part of a bounded wait on an LDS counter, out of line so that the callers' row loops stay
 // straight-line code: returns false when the wait was given up (timeout, or another wave gave up).
 // The counter is polled every ~64 * nap cycles; the wall clock (an s_memrealtime round trip through

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
   __shared__ double2 lt[128];
   __shared__ __attribute__((aligned(32))) double vbuf[2][PC_U][OW];
   __shared__ int ebuf[2][OW];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the role branches are scalar branches)
   if (tid < 128) lt[tid] = A.lt[tid];
 
   const int j = blockIdx.x;
@@ -121,6 +122,9 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
       // pitch, plus a per-lane constant column offset
       double *rowbase = table + stb_row_offset((unsigned)ns, M);
       const int coff = cc - 2;
+      const unsigned coff8 = (unsigned)coff * 8u;  // (cc >= 2)
+      int one_hi = 0x3ff00000;
+      asm volatile("" : "+v"(one_hi));  // (keep the pattern in a vector register)
       const int trips = (ne - ns + 1 + PC_U - 1) / PC_U;
       // trip q: the producer computes rows ns+U*q.., the consumers emit the rows of trip q-1
       for (int q = 0; q <= trips; q++) {
@@ -128,6 +132,27 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
           if (q < trips) {
             const int r0 = ns + q * PC_U;
             const int cnt = min(PC_U, ne - r0 + 1);
+            if (cnt == PC_U) {
+              // a full trip, unrolled; ds_write2_b64 takes any two register pairs where a 16-byte store
+              // wants four adjacent registers, i.e. eight register copies a row
+              unsigned dst = lds_addr_of(&vbuf[q & 1][0][owned ? lane * C - H : 0]);
+              const unsigned step = (unsigned)(OW * sizeof(double));
+#pragma unroll
+              for (int u = 0; u < PC_U; u++) {
+                const double t0 = wave_shr1_zero(v[3]) * s;
+                v[3] = fma(coef[3], v[3], v[2]);
+                v[2] = fma(coef[2], v[2], v[1]);
+                v[1] = fma(coef[1], v[1], v[0]);
+                v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+                for (int i = 0; i < C; i++) coef[i] += 1.0;
+                if (owned) {
+                  lds_store2<0>(dst, v[0], v[1]);
+                  lds_store2<2>(dst, v[2], v[3]);
+                }
+                dst += step;
+              }
+            } else
             for (int u = 0; u < cnt; u++) {
               const double t0 = wave_shr1_zero(v[3]) * s;
               v[3] = fma(coef[3], v[3], v[2]);
@@ -137,9 +162,11 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
 #pragma unroll
               for (int i = 0; i < C; i++) coef[i] += 1.0;
               if (owned) {
-                double2 *dst = reinterpret_cast<double2 *>(&vbuf[q & 1][u][lane * C - H]);
-                dst[0] = make_double2(v[0], v[1]);
-                dst[1] = make_double2(v[2], v[3]);
+                // (ds_write2_b64 takes any two register pairs; a 16-byte store wants four adjacent
+                // registers and the compiler pays for them with eight register copies a row)
+                const unsigned dst = lds_addr_of(&vbuf[q & 1][u][lane * C - H]);
+                lds_store2<0>(dst, v[0], v[1]);
+                lds_store2<2>(dst, v[2], v[3]);
               }
             }
           }
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
 #pragma unroll
               for (int u = 0; u < PC_ST; u++) {
                 const int hi = __double2hiint(x[u]);
-                z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+                z[u] = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x[u]));
                 kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
               }
 #pragma unroll
@@ -178,12 +205,12 @@ __global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A
               if (same_pitch) {
 #pragma unroll
                 for (int u = 0; u < PC_ST; u++)
-                  rowbase[(size_t)u * pitch + coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                  store_sbase(rowbase + (size_t)u * pitch, coff8, fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y)));
                 rowbase += (size_t)PC_ST * pitch;
               } else {
 #pragma unroll
                 for (int u = 0; u < PC_ST; u++) {
-                  rowbase[coff] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y));
+                  store_sbase(rowbase, coff8, fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], t[u].y)));
                   rowbase += stb_row_pitch((unsigned)(r0 + h + u), M);
                 }
               }

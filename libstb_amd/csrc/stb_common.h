@@ -155,6 +155,31 @@ __device__ __forceinline__ double wave_shr1(double v, double fill) {
   return __hiloint2double(hi, lo);
 }
 
+// the 32-bit LDS address of a __shared__ object, and a store of two doubles to `addr` + 8*OFF and
+// `addr` + 8*(OFF+1) whose sources may be any two register pairs
+typedef __attribute__((address_space(3))) double stb_lds_double;
+__device__ __forceinline__ unsigned lds_addr_of(double *p) { return (unsigned)(uintptr_t)(stb_lds_double *)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_store2(unsigned addr, double x, double y) {
+  static_assert(OFF >= 0 && OFF + 1 <= 255, "ds_write2_b64 offsets are 8 bits");
+  asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(x), "v"(y), "n"(OFF), "n"(OFF + 1)
+               : "memory");
+}
+
+// A store of one double per lane at (wave-uniform base) + (per-lane unsigned byte offset): the base
+// goes to scalar registers and the address costs no vector instruction (the compiler's own choice for
+// base[lane_index] is one or two 64-bit vector adds per store).
+__device__ __forceinline__ void store_sbase(const void *sbase, unsigned byte_off, double val) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(byte_off), "v"(val), "s"(sbase) : "memory");
+}
+// high word of the double with the mantissa of `hi` and the exponent of 1.0: (hi & 0xfffff) | 0x3ff00000
+// in one instruction (v_bfi_b32 takes one scalar operand: the 1.0 pattern comes in a vector register)
+__device__ __forceinline__ int mantissa_of_one(int hi, int one_hi_vgpr) {
+  int r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x000fffff), "v"(hi), "v"(one_hi_vgpr));
+  return r;
+}
+
 // log(v 2^ep) from the bits of v: exponent field + 7 leading mantissa bits index a 128-entry table
 // {1/c, -log(1/c)} (held in LDS by the callers), then a degree-5 polynomial in r = z/c - 1,
 // |r| < 2^-8 (the construction used by table-driven libm logs).  Absolute error a few 1e-16.
