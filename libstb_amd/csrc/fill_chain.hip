@@ -447,6 +447,9 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
     const int col = 64 * sl + lane;  // my column inside the strip
     const int cc = c0 + col;
     const int coff = cc - 2;         // offset in a table row (column 1: the slack before the row)
+    const unsigned coff8 = (unsigned)(coff + 1) * 8u;
+    int one_hi = 0x3ff00000;
+    asm volatile("" : "+v"(one_hi));  // (the bit pattern of 1.0's high word, kept in a vector register for v_bfi_b32)
     const int ft = first_trip(sl);
     const bool publisher = (sl == S - 1) && has_right;
     unsigned long long *ev_out = X.edge_v + ((uint64_t)d * X.B + j) * X.EV;
@@ -562,7 +565,7 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
 #pragma unroll
             for (int u = 0; u < U; u++) {
               const int hi = __double2hiint(x[u]);
-              z[u] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x[u]));
+              z[u] = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x[u]));
               kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
             }
 #pragma unroll
@@ -582,7 +585,11 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
                 // (cells outside the table proper -- the row slack -- have count 0 and may hold anything)
                 acc += (cn[u] != 0) ? (double)cn[u] * val : 0.0;
               } else {
-                rowbase[(size_t)u * pitch + coff] = val;
+                // (row address from scalar registers, my column as a byte offset: no vector address
+                // arithmetic; coff >= -1, hence the base one element down.  With several producer
+                // waves the compiler does not see that the row address is the same in every lane.)
+                if constexpr (P == 1) store_sbase(rowbase - 1 + (size_t)u * pitch, coff8, val);
+                else rowbase[(size_t)u * pitch + coff] = val;
               }
             }
           } else {

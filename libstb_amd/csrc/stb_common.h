@@ -168,9 +168,16 @@ __device__ __forceinline__ void lds_store2(unsigned addr, double x, double y) {
 
 // A store of one double per lane at (wave-uniform base) + (per-lane unsigned byte offset): the base
 // goes to scalar registers and the address costs no vector instruction (the compiler's own choice for
-// base[lane_index] is one or two 64-bit vector adds per store).
+// base[lane_index] is one or two 64-bit vector adds per store).  The base passes through an s_mov
+// inside the statement: a vector-memory instruction that reads a scalar register within five cycles of
+// a VECTOR instruction writing it (v_readfirstlane) gets the old value, the compiler does not look
+// into an asm statement for that hazard, and a scalar instruction in between is interlocked.
 __device__ __forceinline__ void store_sbase(const void *sbase, unsigned byte_off, double val) {
-  asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(byte_off), "v"(val), "s"(sbase) : "memory");
+  unsigned long long base_copy;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0"
+               : "=&s"(base_copy)
+               : "v"(byte_off), "v"(val), "s"(sbase)
+               : "memory");
 }
 // high word of the double with the mantissa of `hi` and the exponent of 1.0: (hi & 0xfffff) | 0x3ff00000
 // in one instruction (v_bfi_b32 takes one scalar operand: the 1.0 pattern comes in a vector register)
