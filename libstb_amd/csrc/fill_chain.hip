@@ -92,7 +92,14 @@ constexpr int chain_min_waves(int C, int P, int MG, int NF, int RD) {
 #ifdef STB_NO_MINW
   return 1;
 #endif
-  for (int nb = 4; nb >= 2; nb--)
+#ifdef STB_STAMPS
+  // (the diagnostic build carries clocks and counters in registers: with the production budget it
+  // spills and its timeline shows consumers twice as slow as they are; it runs few tables anyway)
+  const int nb_max = 2;
+#else
+  const int nb_max = 4;
+#endif
+  for (int nb = nb_max; nb >= 2; nb--)
     if (nb * lds <= 160 * 1024 && nb * ((WT + 3) / 4) <= 6) return nb * ((WT + 3) / 4);
   return 1;
 }
