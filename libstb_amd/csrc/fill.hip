@@ -89,6 +89,8 @@ static size_t ws_head(unsigned M, int D) {  // discounts + frontier
 
 static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
   size_t form = stb_chain_workspace(N, M, D);
+  const size_t ck = stb_ck_workspace(N, M, D);
+  if (ck > form) form = ck;
   if (stb_ablation_workspace) {
     const size_t ab = stb_ablation_workspace(N, M, D);
     if (ab > form) form = ab;
@@ -112,7 +114,7 @@ extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
 extern "C" int stb_default_variant(void) {
   const int v = stb_env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
   return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
-          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX)
+          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX || v == STB_FILL_CK)
              ? v
              : STB_FILL_SCALED;
 }
@@ -128,13 +130,14 @@ static bool chain_wins(unsigned N, unsigned M, int D) {
   return (uint64_t)D * M <= cap && N >= 3 && N < (1u << 27);
 }
 
-enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION };
+enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK };
 
 static int pick_form(int variant, unsigned N, unsigned M, int D) {
   switch (variant) {
     case STB_FILL_LOGDOMAIN: return FORM_ROWS_LOG;
     case STB_FILL_PC: return (N < (1u << 27)) ? FORM_PC : FORM_ROWS_LOG;
     case STB_FILL_CHAIN: return (N >= 3 && N < (1u << 27)) ? FORM_CHAIN : (N < 3 ? FORM_PC : FORM_ROWS_LOG);
+    case STB_FILL_CK: return stb_ck_eligible(N, M, D) ? FORM_CK : pick_form(STB_FILL_CHAIN, N, M, D);
     case STB_FILL_CHAINX:  // (its converter blocks need a compute unit per 64-column chunk)
       if (D > 2) return pick_form(STB_FILL_CHAIN, N, M, D);
       return (N >= 3 && N < (1u << 27)) ? FORM_ABLATION : pick_form(STB_FILL_CHAIN, N, M, D);
@@ -284,6 +287,17 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       g_last.st = st;
       g_last.s_table = true;
       g_last.can_fall_back = (g_dot_req == nullptr);
+      return 0;
+    }
+    case FORM_CK: {
+      unsigned *hdr = nullptr;
+      if (stb_launch_ck(A, D, ws, ws_left, &hdr, st)) return 1;
+      g_last.hdr = hdr;
+      g_last.A = A;
+      g_last.D = D;
+      g_last.st = st;
+      g_last.s_table = true;
+      g_last.can_fall_back = true;
       return 0;
     }
     case FORM_PC:

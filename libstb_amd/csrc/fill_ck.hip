@@ -1,0 +1,1031 @@
+// fill_ck.hip -- the checkpointed form of the S-table fill: ONE launch, a latency chain that only
+// carries the recurrence, and tile workers that do everything else.
+//
+// Replaces the table part of S_remake_part's double-S branch (reference lib/stable.c:321-388):
+//   S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1},   stored as log S^n_m for 2 <= m <= min(n-1, M).
+//
+// Why another form.  Rows are strictly sequential, so some wave has to walk all N rows of the first
+// columns, one dependent step per row: that chain (N x row time + strips x hand-off) is the floor of
+// a fill.  In k_fill_chain the wave that walks it also feeds, through an LDS ring, the waves that turn
+// its cells into logs and store them, and those waves live in the same workgroup: the strip at
+// column 1 converts 1.6 x the average strip's cells on one compute unit, and its producer runs at
+// the pace its consumers leave it.  Here the two jobs are separated:
+//
+//   spine    P waves of a workgroup walk 64*C-column wave strips of one table for all rows, C adjacent
+//            columns per lane in block-floating form (see k_fill_chain), and do NOTHING but the
+//            recurrence: per row 2 DPP moves, 1 multiply, C fma, C adds and one 8-byte LDS post of
+//            the strip's last column.  What they hand on: (i) that last column per row, to the next
+//            spine wave through LDS and -- by the workgroup's publisher wave -- to HBM as 8-byte
+//            granules (the edge stream of the strip); (ii) every RB trips (a block, ~96 rows) the
+//            whole row of significands and lane exponents (a checkpoint), straight to HBM.
+//   workers  every other wave of the grid.  A worker takes a tile (table d, wave strip jw, block b)
+//            from a ticket, waits until the spine has passed it, loads the tile's checkpoint and the
+//            left strip's edge stream for its rows, and recomputes the tile's ~96 rows x 64*C columns
+//            in registers -- the same fma sequence -- converting every row to logs and storing it as it
+//            goes.  No LDS ring, no waits inside a tile, no neighbours: tiles are independent, so the
+//            log work and the table's HBM traffic are spread evenly over the chip whatever the
+//            shape of the table (a triangle) or the number of tables.
+//
+// Column 1 (S^n_1 = Gamma(n-a)/Gamma(1-a), the S1 vector) is not a table column.  Wave strips start
+// at column 2 -- element 0 of a row -- so a lane's C cells are one aligned 8*C-byte store and a
+// wave's row segment is whole 128-byte lines.  The left input of column 2 comes from k_col1, a
+// prefix product over n written in the edge-stream format of a virtual strip "-1" before the fill
+// starts: every strip, the first included, has a left neighbour and is treated alike.
+//
+// Everything handed from one workgroup to another is self-flagging 8-byte (or 4-byte) granules
+// written with write-through stores and read with L1-bypassing loads: 0 means "not written yet"
+// (an exact zero travels as -0.0; exponents carry an offset).  The counters that order the tiles
+// (progress per strip) are hints for scheduling only.  Every wait is bounded; on expiry the waiter
+// records an error in the header and everybody runs to the end (stb_fill_status repeats the fill
+// with k_fill_pc).
+
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "fill_chain.h"
+
+#define CK_U CH_U      // rows per trip
+#define CK_RE 32       // trips in the rings between spine waves and from the fetcher (power of two)
+#define CK_NW 8        // waves per workgroup
+#define CK_EOFF32 (1u << 30)
+#define CK_MAXRB 16    // trips per block at most (worker edge buffer: 128 rows)
+
+struct ck_args {
+  unsigned *hdr;               // [0] role ticket, [1] error code, [2] error detail, [3] tile ticket; zeroed per fill
+  unsigned long long *edge_v;  // [D][JW+1][EV]  last column of a wave strip, indexed by row (strip 0: column 1)
+  unsigned long long *edge_e;  // [D][JW+1][NP]  its lane exponent + CH_EOFF, indexed by trip + 1
+  unsigned long long *ck_v;    // [D][JW][NBK][64*C]  checkpoint: significands at the start of a block
+  unsigned *ck_e;              // [D][JW][NBK][64]    ... and lane exponents + CK_EOFF32
+  unsigned *progress;          // [D][JW]  blocks a spine wave has finished (scheduling hint)
+  const unsigned *order;       // [n_tiles] jw | b << 16, in the order the tiles become ready
+  uint64_t EV, NP;
+  int D, B, JW, NBK;           // tables, spine workgroups per table, wave strips per table, blocks
+  int TP, RB, G;               // trips per period, trips per block, trips in all (rows 3 .. 2 + 8 G)
+  unsigned n_tiles;            // per table
+  unsigned n_spine;            // spine workgroups in all (B * D)
+  unsigned long long timeout;  // wall_clock64 ticks a wait may last
+  int poll_nap;
+  int spare_work;              // 1: the spare waves of a spine workgroup work as tile workers meanwhile
+  unsigned long long *dbg;     // STB_CK_TIMELINE: wall-clock stamps, table 0: [JW][NBK + 2] spine (start, block ends, end),
+                               // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
+};
+
+__device__ __forceinline__ int ck_first_trip(int c) { return (c <= 3) ? 0 : (c - 3) / CK_U; }
+
+typedef double ck_double2 __attribute__((ext_vector_type(2)));
+
+// aligned 16-byte store at (wave-uniform base) + (per-lane byte offset); see store_sbase
+__device__ __forceinline__ void store_sbase16(const void *sbase, unsigned byte_off, double x, double y) {
+  unsigned long long base_copy;
+  ck_double2 v2 = {x, y};
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0\n\ts_nop 1"
+               : "=&s"(base_copy)
+               : "v"(byte_off), "v"(v2), "s"(sbase)
+               : "memory");
+}
+
+// 8-byte LDS store at `addr` + OFF bytes (a statement the compiler neither splits nor predicates)
+template <int OFF>
+__device__ __forceinline__ void lds_store1(unsigned addr, double x) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(x), "n"(OFF) : "memory");
+}
+
+// ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
+template <int NCELL>
+__device__ __forceinline__ void ck_logs(const double (&x)[NCELL], int myep, const double2 *lt, int one_hi,
+                                        double (&val)[NCELL]) {
+  double z[NCELL], kf[NCELL], r[NCELL], pl[NCELL];
+  double2 tt[NCELL];
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) {
+    const int hi = __double2hiint(x[u]);
+    z[u] = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x[u]));
+    kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+  }
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) r[u] = fma(z[u], tt[u].x, -1.0);
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) pl[u] = fma(r[u], pl[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < NCELL; u++) val[u] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+}
+
+// renormalise a lane: the largest of its C significands back to 2^-PC_BIAS * [0.5,1)
+template <int C>
+__device__ __forceinline__ void ck_renorm(double (&v)[C], int &ep) {
+  int kmax = -4000;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+  if (kmax > -4000) {
+#pragma unroll
+    for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+    ep += kmax + PC_BIAS;
+  }
+}
+
+template <int C, int P>
+__global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_args A, ck_args X) {
+  constexpr int U = CK_U, RE = CK_RE;
+  constexpr int WS = 64 * C;  // columns of a wave strip
+  static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
+  static_assert(P >= 1 && P <= 4, "spine waves per workgroup");
+  __shared__ double2 lt[128];
+  // spine workgroups
+  __shared__ __attribute__((aligned(16))) double xedge[4][RE * U];  // last column of spine wave w, ring indexed by row
+  __shared__ int xexp[4][RE];                                       // its lane exponent per trip
+  __shared__ __attribute__((aligned(16))) double edge_in[RE * U];   // what the fetcher delivers to spine wave 0
+  __shared__ int edge_e[RE];
+  __shared__ __attribute__((aligned(16))) double pad8[64 + RE * U + 8];  // where lanes 0..62 of a masked post go
+  __shared__ int pad4[64 + RE + 8];
+  __shared__ int prod_done[4], pub_done[4], edge_ready, s_abort, s_awake;
+  __shared__ int post_pad[4][64];
+  __shared__ unsigned s_ticket;
+  // workers: the left inputs of a tile, per wave
+  __shared__ __attribute__((aligned(16))) double w_le[CK_NW][CK_MAXRB * U];
+  __shared__ int w_lee[CK_NW][CK_MAXRB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
+  if (tid < 128) lt[tid] = A.lt[tid];
+  for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
+  __syncthreads();
+  const unsigned ticket = s_ticket;
+  const unsigned N = A.N, M = A.M;
+  const int TP = X.TP, RB = X.RB, G = X.G;
+  bool worker = true;
+
+  if (ticket < X.n_spine) {
+    // =========================================================================================
+    // spine workgroup: wave strips j*P .. j*P + P - 1 of table d
+    const int j = (int)(ticket / (unsigned)X.D);
+    const int d = (int)(ticket % (unsigned)X.D);
+    const int jw0 = j * P;
+    const int g0b = ck_first_trip(2 + jw0 * WS);
+    if (tid < 4) {
+      const int jw = jw0 + tid;
+      const int g0 = (jw < X.JW) ? ck_first_trip(2 + jw * WS) : G;
+      prod_done[tid] = g0;
+      pub_done[tid] = g0;
+    }
+    if (tid == 0) {
+      edge_ready = g0b;
+      s_abort = 0;
+      s_awake = (j == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    const unsigned who = (unsigned)(j | (d << 16));
+    bool aborted = false;
+    auto wait_ge = [&](const int *cnt, int need, unsigned code, int nap) {
+      if (aborted || lds_peek(cnt) >= need) return;
+      if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, nap)) aborted = true;
+    };
+    auto doze = [&]() {
+      while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(16);
+    };
+    const size_t strip0 = (size_t)d * (X.JW + 1);  // index of the virtual strip (column 1) of table d
+
+    if (wave < P) {
+      // ================= spine waves =================
+      worker = false;
+      doze();
+      __builtin_amdgcn_s_setprio(3);
+      auto spine = [&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        const int jw = jw0 + w;
+        if (jw >= X.JW) return;
+        const int c0w = 2 + jw * WS;
+        const int g0w = ck_first_trip(c0w);
+        const double a = A.a[d];
+        const int cl = c0w + lane * C;
+        double v[C], coef[C];
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          const int c = cl + i;
+          v[i] = (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;  // row 2: S^2_2 = 1, nothing to its right
+          coef[i] = (double)(2 + g0w * U) - (double)c * a;   // n - 1 - c a for the first row of trip g0w
+        }
+        double s = 1.0;
+        int ep = 1 + PC_BIAS;
+        int p = g0w / TP, tin = g0w - p * TP;
+        int bnext = g0w / RB + 1;  // the next block boundary is trip bnext * RB
+        unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (X.NBK + 2) : nullptr;
+        if (dbg) dbg[0] = wall_clock64();
+        const bool has_next = (w < P - 1) && (jw + 1 < X.JW);
+        const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w > 0 ? w - 1 : 0];
+        const int *next_cnt = &prod_done[(w < P - 1) ? w + 1 : w];
+        int n_left, n_next = 0x7fffffff, n_pub;
+        // masked posts: lane 63 writes the ring, lane 0 the counter, the other lanes scratch
+        const unsigned edge_base = (lane == 63) ? lds_addr_of(&xedge[w][0]) : lds_addr_of(&pad8[lane]);
+        int *exp_base = (lane == 63) ? &xexp[w][0] : &pad4[lane];
+        int *post_addr = (lane == 0) ? &prod_done[w] : &post_pad[w][lane];
+        unsigned long long *ckv = X.ck_v + (((size_t)d * X.JW + jw) * X.NBK) * (64 * C) + lane * C;
+        unsigned *cke = X.ck_e + (((size_t)d * X.JW + jw) * X.NBK) * 64 + lane;
+        unsigned *prog = X.progress + (size_t)d * X.JW + jw;
+        auto peek_counters = [&]() {
+          n_left = lds_peek(left_cnt);
+          if (has_next) n_next = lds_peek(next_cnt);
+          n_pub = lds_peek(&pub_done[w]);
+          asm volatile("" ::: "memory");
+        };
+        auto load_left = [&](double(&x)[U], int g) {
+          // the input of row u of trip g is the left column one row up: ring entry 8 g + u - 1
+          const double *src = (w == 0) ? edge_in : &xedge[w > 0 ? w - 1 : 0][0];
+          if (w == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = src[(g & (RE - 1)) * U + u];  // (the fetcher stores it shifted)
+          } else {
+            x[0] = src[((g - 1) & (RE - 1)) * U + U - 1];
+#pragma unroll
+            for (int u = 1; u < U; u++) x[u] = src[(g & (RE - 1)) * U + u - 1];
+          }
+        };
+        auto counters_ok = [&](int g) {
+          return n_left >= g + 1 && n_next >= g - RE + 2 && n_pub >= g - RE + 1;
+        };
+        auto trip = [&](int g, double(&e)[U], double(&en)[U]) {
+          if (__builtin_expect(!counters_ok(g), 0)) {
+            peek_counters();
+            load_left(e, g);
+            if (!counters_ok(g)) {
+              wait_ge(left_cnt, g + 1, 0x100u, 1);
+              if (has_next) wait_ge(next_cnt, g - RE + 2, 0x400u, 1);
+              wait_ge(&pub_done[w], g - RE + 1, 0x500u, 1);
+              asm volatile("" ::: "memory");
+              load_left(e, g);
+            }
+          }
+          // what the next trip needs from the other waves is read now, under this trip's arithmetic
+          peek_counters();
+          load_left(en, g + 1);
+          if (__builtin_expect(g == g0w || tin == 0, 0)) {
+            if (g != g0w) {
+              if (g == bnext * RB) {
+                // ---- checkpoint: the row as it stands before trip g, for the worker of block bnext ----
+                unsigned long long *dst = ckv + (size_t)bnext * (64 * C);
+#pragma unroll
+                for (int i = 0; i < C; i++) {
+                  unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+                  if ((b << 1) == 0) b = CH_NEGZERO;
+                  __hip_atomic_store(dst + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(cke + (size_t)bnext * 64, (unsigned)ep + CK_EOFF32, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(prog, (unsigned)bnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dbg) dbg[bnext] = wall_clock64();
+                bnext++;
+              }
+              ck_renorm<C>(v, ep);
+            }
+            // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
+            int el;
+            if (w == 0) {
+              el = edge_e[g & (RE - 1)];
+            } else {
+              el = xexp[w > 0 ? w - 1 : 0][g & (RE - 1)];
+              // the row above the first row of a trip was produced under the previous trip's exponent
+              e[0] = ldexp(e[0], xexp[w > 0 ? w - 1 : 0][(g - 1) & (RE - 1)] - el);
+            }
+            int dl = wave_shr1(ep, ep) - ep;
+            if (lane == 0) dl = el - ep;
+            s = ldexp(1.0, min(max(dl, -1100), 220));
+          }
+          exp_base[g & (RE - 1)] = ep;
+          const unsigned ebase = edge_base + (unsigned)((g & (RE - 1)) * U * 8);
+          auto row = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const double t0 = wave_shr1(v[C - 1], e[u]) * s;
+#pragma unroll
+            for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+            v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+            for (int i = 0; i < C; i++) coef[i] += 1.0;
+            lds_store1<u * 8>(ebase, v[C - 1]);
+          };
+          static_assert(U == 8, "rows of a trip");
+          row(std::integral_constant<int, 0>{});
+          row(std::integral_constant<int, 1>{});
+          row(std::integral_constant<int, 2>{});
+          row(std::integral_constant<int, 3>{});
+          row(std::integral_constant<int, 4>{});
+          row(std::integral_constant<int, 5>{});
+          row(std::integral_constant<int, 6>{});
+          row(std::integral_constant<int, 7>{});
+          asm volatile("" ::: "memory");
+          __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          if (++tin == TP) {
+            tin = 0;
+            p++;
+          }
+        };
+        double ea[U], eb[U];
+        peek_counters();
+        load_left(ea, g0w);
+        int g = g0w;
+        for (; g + 1 < G; g += 2) {
+          trip(g, ea, eb);
+          trip(g + 1, eb, ea);
+        }
+        if (g < G) trip(g, ea, eb);
+        if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dbg) dbg[X.NBK + 1] = wall_clock64();
+      };
+      if (P == 1 || wave == 0) spine(std::integral_constant<int, 0>{});
+      else if (wave == 1) spine(std::integral_constant<int, (P >= 2) ? 1 : 0>{});
+      else if (wave == 2) spine(std::integral_constant<int, (P >= 3) ? 2 : 0>{});
+      else spine(std::integral_constant<int, (P >= 4) ? 3 : 0>{});
+      __builtin_amdgcn_s_setprio(0);
+    } else if (wave == P) {
+      // ================= fetcher: the left strip's edge stream -> LDS, for spine wave 0 =================
+      worker = false;
+      const unsigned long long *ev_in = X.edge_v + (strip0 + jw0) * X.EV;      // strip jw0 - 1 (virtual for j = 0)
+      const unsigned long long *ee_in = X.edge_e + (strip0 + jw0) * X.NP + 1;  // [t] for trip t >= -1
+      struct edge_poll {
+        unsigned long long va, e1, e0;
+        int tb, nt;
+      };
+      const int ka = lane >> 3;
+      int t = g0b;  // trips below it are delivered
+      if (j > 0) {
+        // the left strip publishes from its own first trip on: wait, dozing, for the exponent granule of
+        // a trip shortly before the first one needed here, then wake the workgroup
+        const unsigned long long *probe = ee_in + max(g0b - 6, 0);
+        unsigned long long t_begin = 0;
+        unsigned spins = 0;
+        while (__hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(16);
+          if ((++spins & 255u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || lds_peek(&s_abort) ||
+              (unsigned long long)wall_clock64() - t_begin >= X.timeout)
+            break;  // (the main loop below gives up properly)
+        }
+        lds_post(&s_awake, 1);
+      }
+      int pd = lds_peek(&prod_done[0]);
+      auto issue = [&](edge_poll &q) {
+        int lim = pd + RE - 1;  // trips below it may be written: their ring slots were read by the spine
+        if (lim > G) lim = G;
+        q.tb = t;
+        q.nt = max(0, min(8, lim - t));
+        q.va = __hip_atomic_load(ev_in + 2 + t * U + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q.e1 = __hip_atomic_load(ee_in + t + ka, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q.e0 = __hip_atomic_load(ee_in + t + ka - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto settle = [&](const edge_poll &q) {
+        const unsigned long long miss = ~__ballot(q.va != 0 && q.e1 != 0 && q.e0 != 0);
+        const int nr = min(q.nt, miss ? (int)(__builtin_ctzll(miss) >> 3) : 8);
+        const int cur = t;
+        if (q.tb + nr <= cur) return false;
+        const int ex = (int)(long long)(q.e1 - CH_EOFF);
+        double xa = __longlong_as_double((long long)q.va);
+        if (ka < nr && q.tb + ka >= cur) {
+          if ((lane & 7) == 0) {
+            xa = ldexp(xa, (int)(long long)(q.e0 - CH_EOFF) - ex);
+            edge_e[(q.tb + ka) & (RE - 1)] = ex;
+          }
+          edge_in[((q.tb + ka) & (RE - 1)) * U + (lane & 7)] = xa;
+        }
+        t = q.tb + nr;
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&edge_ready, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        return true;
+      };
+      auto pause = [&]() {
+        if (X.poll_nap >= 4) __builtin_amdgcn_s_sleep(4);
+        else if (X.poll_nap == 3) __builtin_amdgcn_s_sleep(3);
+        else if (X.poll_nap == 2) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(1);
+      };
+      constexpr int FK = 2;
+      edge_poll q[FK];
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      unsigned idle = 0;
+      while (t < G) {
+#pragma unroll
+        for (int i = 0; i < FK; i++) {
+          issue(q[i]);
+          if (i == FK - 1) pd = lds_peek(&prod_done[0]);
+          pause();
+        }
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < FK; i++) any = settle(q[i]) || any;
+        if (any) {
+          timing = false;
+          idle = 0;
+          continue;
+        }
+        if ((++idle & 31) != 0 && X.timeout != 0) continue;
+        if (!timing) {
+          timing = true;
+          t_begin = wall_clock64();
+        }
+        const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+          if (lane == 0) {
+            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (err == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          lds_post(&edge_ready, 0x7fffffff);  // release the spine: it runs on with stale edges
+          break;
+        }
+      }
+    } else if (wave == P + 1) {
+      // ================= publisher: the spine waves' last columns -> HBM =================
+      // 16 lanes per spine wave: lanes 0..7 the rows of a trip, lane 8 its exponent
+      worker = false;
+      doze();
+      const int grp = lane >> 4, sub = lane & 15;
+      const int jw = jw0 + grp;
+      const bool mine = grp < P && jw < X.JW && sub <= U;
+      int tw = mine ? ck_first_trip(2 + jw * WS) : G;
+      // (nobody reads the last strip's edge: its trips are only released)
+      const bool stores = mine && jw + 1 < X.JW;
+      unsigned long long *ev_out = X.edge_v + (strip0 + 1 + (mine ? jw : 0)) * X.EV;
+      unsigned long long *ee_out = X.edge_e + (strip0 + 1 + (mine ? jw : 0)) * X.NP + 1;
+      unsigned idle = 0;
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      while (__any(tw < G)) {
+        const int pdw = (tw < G) ? lds_peek(&prod_done[grp & 3]) : 0;
+        asm volatile("" ::: "memory");
+        const bool go = tw < G && tw < pdw;
+        if (go) {
+          if (stores) {
+            unsigned long long b;
+            unsigned long long *dst;
+            if (sub < U) {
+              b = (unsigned long long)__double_as_longlong(xedge[grp & 3][(tw & (RE - 1)) * U + sub]);
+              if ((b << 1) == 0) b = CH_NEGZERO;
+              dst = ev_out + 3 + tw * U + sub;
+            } else {
+              b = (unsigned long long)((long long)xexp[grp & 3][tw & (RE - 1)] + (long long)CH_EOFF);
+              dst = ee_out + tw;
+            }
+            __hip_atomic_store(dst, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          tw++;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring entries are in registers
+          if (sub == 0) __hip_atomic_store(&pub_done[grp & 3], tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (__any(go)) {
+          idle = 0;
+          timing = false;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if ((++idle & 255) != 0) continue;
+        if (lds_peek(&s_abort)) {
+          // the spine runs to its end whatever happens: keep releasing its ring without the clock
+          continue;
+        }
+        if (!timing) {
+          timing = true;
+          t_begin = wall_clock64();
+        } else if (X.timeout != 0 && (unsigned long long)wall_clock64() - t_begin >= 16 * X.timeout) {
+          break;  // (cannot happen unless a spine wave died)
+        }
+      }
+    } else if (!X.spare_work) {
+      worker = false;
+    }
+  }
+
+  if (!worker) return;
+  // =========================================================================================
+  // tile workers (every wave for itself)
+  {
+    const int wslot = wave;
+    double *le = &w_le[wslot][0];
+    int *lee = &w_lee[wslot][0];
+    int one_hi = 0x3ff00000;
+    asm volatile("" : "+v"(one_hi));
+    const unsigned total = X.n_tiles * (unsigned)X.D;
+    for (;;) {
+      unsigned k = 0;
+      if (lane == 0) k = atomicAdd(X.hdr + 3, 1u);
+      k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+      if (k >= total) break;
+      const int d = (int)(k % (unsigned)X.D);
+      const unsigned ord = X.order[k / (unsigned)X.D];
+      const int jw = (int)(ord & 0xffffu), b = (int)(ord >> 16);
+      const int c0w = 2 + jw * WS;
+      const int g0w = ck_first_trip(c0w);
+      const int gs = max(b * RB, g0w), ge = min((b + 1) * RB, G);
+      const int nt = ge - gs, nrows = nt * U;
+      const unsigned who = (unsigned)jw | ((unsigned)d << 16);
+      unsigned long long *wdbg =
+          (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)X.JW * (X.NBK + 2) + (size_t)(k / (unsigned)X.D) * 4 : nullptr;
+      if (wdbg) wdbg[0] = wall_clock64();
+      // ---- wait until the spine has finished the block (a hint: the data below is its own flag) ----
+      bool ok = true;
+      {
+        const unsigned *prog = X.progress + (size_t)d * X.JW + jw;
+        unsigned spins = 0;
+        unsigned long long t_begin = 0;
+        for (;;) {
+          const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (done >= (unsigned)(b + 1)) break;
+          // Thousands of waves wait here while a table's first rows are walked, and every poll is a
+          // request to the memory side that the spine's own hand-offs queue behind: sleep for about as
+          // long as the blocks still missing take (a block: ~3 us), at most ~50 us, then look again.
+          const int missing = min((int)((unsigned)(b + 1) - done), 16);
+          for (int i = 0; i < missing; i++) __builtin_amdgcn_s_sleep(100);
+          if ((++spins & 3u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = false;
+            break;
+          }
+        }
+      }
+      if (!ok) break;
+      // ---- the tile's inputs: left edges (rows 2 + 8 gs ..) and the checkpoint ----
+      const size_t sleft = (size_t)d * (X.JW + 1) + jw;  // strip jw - 1 (+1: the virtual strip is index 0)
+      const unsigned long long *ev = X.edge_v + sleft * X.EV + 2 + gs * U;
+      const unsigned long long *ee = X.edge_e + sleft * X.NP + 1;
+      const bool fresh = (gs == g0w);  // the strip's first tile starts from the empty row
+      const unsigned long long *ckv = X.ck_v + (((size_t)d * X.JW + jw) * X.NBK + b) * (64 * C) + lane * C;
+      const unsigned *cke = X.ck_e + (((size_t)d * X.JW + jw) * X.NBK + b) * 64 + lane;
+      double v[C], coef[C];
+      int ep = 1 + PC_BIAS;
+      {
+        unsigned spins = 0;
+        unsigned long long t_begin = 0;
+        for (;;) {
+          bool have = true;
+          for (int k0 = 0; k0 < nrows; k0 += 64) {
+            const int kk = k0 + lane;
+            const bool act = kk < nrows;
+            const int kc = act ? kk : 0;
+            const int tc = gs + (kc >> 3);
+            const unsigned long long va = __hip_atomic_load(ev + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long e1 = __hip_atomic_load(ee + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long e0 = __hip_atomic_load(ee + tc - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = have && (va != 0 && e1 != 0 && e0 != 0);
+            if (act) {
+              const int ex = (int)(long long)(e1 - CH_EOFF);
+              double xa = __longlong_as_double((long long)va);
+              if ((kc & 7) == 0) {
+                xa = ldexp(xa, (int)(long long)(e0 - CH_EOFF) - ex);
+                lee[kc >> 3] = ex;
+              }
+              le[kc] = xa;
+            }
+          }
+          if (!fresh) {
+#pragma unroll
+            for (int i = 0; i < C; i++) {
+              const unsigned long long bv = __hip_atomic_load(ckv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              have = have && bv != 0;
+              v[i] = __longlong_as_double((long long)bv);
+            }
+            const unsigned be = __hip_atomic_load(cke, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = have && be != 0;
+            ep = (int)(be - CK_EOFF32);
+          }
+          if (__all(have)) break;
+          __builtin_amdgcn_s_sleep(8);
+          if ((++spins & 15u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0xB00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = false;
+            break;
+          }
+        }
+      }
+      if (!ok) break;
+      if (wdbg) wdbg[1] = wall_clock64();
+      const double a = A.a[d];
+      const int cl = c0w + lane * C;
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const int c = cl + i;
+        if (fresh) v[i] = (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
+        coef[i] = (double)(2 + gs * U) - (double)c * a;
+      }
+      double s = 1.0;
+      int tin = gs % TP;
+      double *table = A.tables + (uint64_t)d * A.tstride;
+      const unsigned voff = (unsigned)(lane * C) * 8u;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own LDS writes above)
+      for (int g = gs; g < ge; g++) {
+        if (g == g0w || tin == 0) {
+          if (g != g0w) ck_renorm<C>(v, ep);
+          const int el = lee[g - gs];
+          int dl = wave_shr1(ep, ep) - ep;
+          if (lane == 0) dl = el - ep;
+          s = ldexp(1.0, min(max(dl, -1100), 220));
+        }
+        const int r0 = 3 + g * U;
+        const unsigned pitch = stb_row_pitch((unsigned)r0, M);
+        const bool fast = (unsigned)(r0 + U - 1) <= N;
+        double *rowp = table + stb_row_offset((unsigned)r0, M) + (size_t)(c0w - 2);
+        const double *lrow = le + (g - gs) * U;
+        double e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = lrow[u];
+        constexpr int RS = 8 / C;  // rows converted together: eight cells in flight
+#pragma unroll
+        for (int h = 0; h < U; h += RS) {
+          double x[8], val[8];
+#pragma unroll
+          for (int u = 0; u < RS; u++) {
+            const double t0 = wave_shr1(v[C - 1], e[h + u]) * s;
+#pragma unroll
+            for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+            v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+            for (int i = 0; i < C; i++) {
+              coef[i] += 1.0;
+              x[u * C + i] = v[i];
+            }
+          }
+          ck_logs<8>(x, ep, lt, one_hi, val);
+#pragma unroll
+          for (int u = 0; u < RS; u++) {
+            if (fast || (unsigned)(r0 + h + u) <= N) {
+              double *rp = rowp + (size_t)(h + u) * pitch;
+              if constexpr (C == 1) {
+                store_sbase(rp, voff, val[u]);
+              } else if constexpr (C == 2) {
+                store_sbase16(rp, voff, val[u * 2], val[u * 2 + 1]);
+              } else {
+                store_sbase16(rp, voff, val[u * 4], val[u * 4 + 1]);
+                store_sbase16(rp + 2, voff, val[u * 4 + 2], val[u * 4 + 3]);
+              }
+            }
+          }
+        }
+        if (++tin == TP) tin = 0;
+      }
+      if (wdbg) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wdbg[2] = wall_clock64();
+        wdbg[3] = (unsigned long long)hw | ((unsigned long long)(xcc & 15u) << 32);
+      }
+    }
+  }
+}
+
+// ---- column 1 as an edge stream: x_n = S^n_1 = prod_{k=1}^{n-1} (k - a), rows 2 .. R ---------------
+//
+// One workgroup per table.  Every thread multiplies up a contiguous chunk of rows as (mantissa,
+// exponent) pairs, the chunk totals are scanned across the workgroup, and the rows are written in the
+// format the spine's fetcher and the workers read: the significand relative to the exponent of the
+// row's trip -- frozen per period, so that a period starts at 2^-PC_BIAS * [0.5,1) -- as an 8-byte
+// granule per row, and that exponent + CH_EOFF per trip.
+struct me_t {
+  double m;
+  int e;
+};
+__device__ __forceinline__ me_t me_mul(me_t x, me_t y) {
+  double m = x.m * y.m;
+  const int k = __builtin_amdgcn_frexp_exp(m);
+  me_t r;
+  r.m = __builtin_amdgcn_frexp_mant(m);
+  r.e = x.e + y.e + k;
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void k_col1(const double *a_dev, ck_args X, double *tmp_m, int *tmp_e, int R) {
+  // rows 1 .. R; tmp_m / tmp_e: [D][R + 1]
+  __shared__ double sm[1024];
+  __shared__ int se[1024];
+  const int d = blockIdx.x, t = threadIdx.x;
+  const double a = a_dev[d];
+  const int chunk = (R + 1023) / 1024;
+  const int n_lo = 1 + t * chunk, n_hi = min(R, n_lo + chunk - 1);
+  double *tm = tmp_m + (size_t)d * (R + 1);
+  int *te = tmp_e + (size_t)d * (R + 1);
+  // factor of row n: x_n = x_{n-1} * (n - 1 - a) for n >= 2, x_1 = 1
+  me_t acc = {0.5, 1};  // 1.0
+  for (int n = n_lo; n <= n_hi; n++) {
+    if (n >= 2) {
+      me_t f = {(double)(n - 1) - a, 0};
+      acc = me_mul(acc, f);
+    }
+  }
+  sm[t] = acc.m;
+  se[t] = acc.e;
+  __syncthreads();
+  // inclusive scan of the chunk totals
+  for (int off = 1; off < 1024; off <<= 1) {
+    me_t mine = {sm[t], se[t]};
+    me_t other = {0.5, 1};
+    if (t >= off) other = {sm[t - off], se[t - off]};
+    __syncthreads();
+    if (t >= off) mine = me_mul(mine, other);
+    sm[t] = mine.m;
+    se[t] = mine.e;
+    __syncthreads();
+  }
+  me_t pre = {0.5, 1};
+  if (t > 0) pre = {sm[t - 1], se[t - 1]};
+  for (int n = n_lo; n <= n_hi; n++) {
+    if (n >= 2) {
+      me_t f = {(double)(n - 1) - a, 0};
+      pre = me_mul(pre, f);
+    }
+    tm[n] = pre.m;
+    te[n] = pre.e;
+  }
+  __threadfence_block();
+  __syncthreads();
+  unsigned long long *ev = X.edge_v + (size_t)d * (X.JW + 1) * X.EV;
+  unsigned long long *ee = X.edge_e + (size_t)d * (X.JW + 1) * X.NP + 1;
+  const int TP = X.TP;
+  auto trip_exp = [&](int tr) {  // the exponent of the values produced in trip tr (rows 3 + 8 tr ..)
+    if (tr < 0) return te[2] + PC_BIAS;
+    const int p = tr / TP;
+    const int nfirst = min(3 + CK_U * TP * p, R);
+    return te[nfirst] + PC_BIAS;
+  };
+  for (int n = 2 + t; n <= R; n += 1024) {
+    const int tr = (n >= 3) ? (n - 3) / CK_U : -1;
+    const int E = trip_exp(tr);
+    const double g = ldexp(tm[n], te[n] - E);
+    ev[n] = (unsigned long long)__double_as_longlong(g);
+  }
+  const int last_trip = (R - 3) / CK_U;
+  for (int tr = -1 + t; tr <= last_trip; tr += 1024) ee[tr] = (unsigned long long)((long long)trip_exp(tr) + (long long)CH_EOFF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+static inline int ck_first_trip_h(int c) { return (c <= 3) ? 0 : (c - 3) / CK_U; }
+
+struct ck_geom {
+  int C, P, B, JW, G, TP, RB, NBK, R;
+  uint64_t EV, NP;
+  unsigned n_tiles;
+  size_t off_prog, off_ee, off_ev, off_cke, off_ckv, zero_bytes, off_tm, off_te, bytes;
+  bool ok;
+};
+
+// strip shape: C columns per lane, P spine waves per workgroup, blocks of RB trips
+static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
+  ck_geom g;
+  memset(&g, 0, sizeof(g));
+  g.ok = false;
+  if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return g;
+  const uint64_t cols = (uint64_t)D * M;
+  g.C = stb_env_int("STB_CK_C", cols <= 200000 ? 2 : 4);
+  if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
+  g.P = stb_env_int("STB_CK_P", 4);
+  if (g.P < 1 || g.P > 4) g.P = 4;
+  int Pc = stb_period_rows(N);
+  const int Penv = stb_env_int("STB_FILL_P", 0);
+  if (Penv > 0 && Penv < Pc) Pc = Penv;
+  g.TP = Pc / CK_U;
+  if (g.TP < 1) return g;
+  if (g.TP > CK_MAXRB) g.TP = CK_MAXRB;
+  const int target = stb_env_int("STB_CK_BLOCK_ROWS", 96) / CK_U;
+  int K = (target + g.TP / 2) / g.TP;
+  if (K < 1) K = 1;
+  while (K > 1 && K * g.TP > CK_MAXRB) K--;
+  g.RB = K * g.TP;
+  const unsigned cmax = (M < N - 1) ? M : N - 1;  // columns 2..cmax hold stored cells
+  const int WS = 64 * g.C;
+  g.JW = (int)((cmax - 1 + WS - 1) / WS);
+  if (g.JW < 1) g.JW = 1;
+  g.B = (g.JW + g.P - 1) / g.P;
+  g.G = (int)((N - 2 + CK_U - 1) / CK_U);
+  g.NBK = (g.G + g.RB - 1) / g.RB;
+  if (g.JW >= 65536 || g.NBK >= 65536) return g;
+  g.R = CK_U * g.G + 2;
+  g.EV = (uint64_t)3 + (uint64_t)g.G * CK_U + 136;
+  g.NP = (uint64_t)g.G + 26;
+  long nt = 0;
+  for (int jw = 0; jw < g.JW; jw++) nt += g.NBK - ck_first_trip_h(2 + jw * WS) / g.RB;
+  g.n_tiles = (unsigned)nt;
+  size_t o = 256;
+  g.off_prog = o;
+  o += stb_align_up((size_t)D * g.JW * sizeof(unsigned), 256);
+  g.off_ee = o;
+  o += stb_align_up((size_t)D * (g.JW + 1) * g.NP * 8, 256);
+  g.off_ev = o;
+  o += stb_align_up((size_t)D * (g.JW + 1) * g.EV * 8, 256);
+  g.off_cke = o;
+  o += stb_align_up((size_t)D * g.JW * g.NBK * 64 * sizeof(unsigned), 256);
+  g.off_ckv = o;
+  o += stb_align_up((size_t)D * g.JW * g.NBK * 64 * g.C * 8, 256);
+  g.zero_bytes = o;
+  g.off_tm = o;
+  o += stb_align_up((size_t)D * (g.R + 1) * sizeof(double), 256);
+  g.off_te = o;
+  o += stb_align_up((size_t)D * (g.R + 1) * sizeof(int), 256);
+  g.bytes = o;
+  g.ok = true;
+  return g;
+}
+
+bool stb_ck_eligible(unsigned N, unsigned M, int D) { return ck_geometry(N, M, D).ok; }
+
+size_t stb_ck_workspace(unsigned N, unsigned M, int D) {
+  size_t need = 0;
+  // (the strip shape is a tunable and depends on the batch: size for every shape)
+  static const int shapes[3] = {1, 2, 4};
+  const ck_geom g0 = ck_geometry(N, M, D);
+  if (!g0.ok) return 0;
+  need = g0.bytes;
+  const char *cenv = getenv("STB_CK_C");
+  (void)cenv;
+  for (int c : shapes) {
+    // the same sizes with C forced: edge streams scale with 1/C, checkpoints do not
+    const int WS = 64 * c;
+    const unsigned cmax = (M < N - 1) ? M : N - 1;
+    const size_t JW = (cmax - 1 + WS - 1) / WS + 1;
+    const size_t b = 256 + 4096 + (size_t)D * (JW + 1) * (g0.NP + g0.EV) * 8 + (size_t)D * JW * g0.NBK * 64 * (4 + 8 * c) +
+                     (size_t)D * (g0.R + 1) * 12 + 4096;
+    if (b > need) need = b;
+  }
+  return need + 256;
+}
+
+// the order in which the tiles of a table become ready, as jw | b << 16: strip jw finishes block b at
+// about (b + 1) RB 8 r + (jw / P) L + (jw % P) lag
+struct ck_order_entry {
+  int dev;
+  unsigned N, M;
+  int C, P, RB, NBK, JW;
+  int r_ns, L_ns, lag_ns;
+  unsigned n;
+  unsigned *d_order;
+};
+static std::mutex g_order_mu;
+static std::vector<ck_order_entry> g_orders;
+
+static int ck_order_list(const ck_geom &g, unsigned N, unsigned M, const unsigned **out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  const int r_ns = stb_env_int("STB_CK_ORDER_R", 30), L_ns = stb_env_int("STB_CK_ORDER_L", 2700),
+            lag_ns = stb_env_int("STB_CK_ORDER_LAG", 400);
+  std::lock_guard<std::mutex> lock(g_order_mu);
+  for (const ck_order_entry &e : g_orders)
+    if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.RB == g.RB && e.NBK == g.NBK && e.JW == g.JW &&
+        e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
+      *out = e.d_order;
+      return 0;
+    }
+  struct item {
+    long key;
+    unsigned code;
+  };
+  std::vector<item> v;
+  v.reserve(g.n_tiles);
+  const int WS = 64 * g.C;
+  for (int jw = 0; jw < g.JW; jw++) {
+    const int b0 = ck_first_trip_h(2 + jw * WS) / g.RB;
+    for (int b = b0; b < g.NBK; b++) {
+      item it;
+      it.key = (long)(b + 1) * g.RB * CK_U * r_ns + (long)(jw / g.P) * L_ns + (long)(jw % g.P) * lag_ns;
+      it.code = (unsigned)jw | ((unsigned)b << 16);
+      v.push_back(it);
+    }
+  }
+  std::stable_sort(v.begin(), v.end(), [](const item &x, const item &y) { return x.key < y.key; });
+  if (v.size() != g.n_tiles) return stb_fail("stb_fill_S: tile count %zu != %u", v.size(), g.n_tiles);
+  std::vector<unsigned> codes(v.size());
+  for (size_t i = 0; i < v.size(); i++) codes[i] = v[i].code;
+  ck_order_entry e;
+  e.dev = dev;
+  e.N = N;
+  e.M = M;
+  e.C = g.C;
+  e.P = g.P;
+  e.RB = g.RB;
+  e.NBK = g.NBK;
+  e.JW = g.JW;
+  e.r_ns = r_ns;
+  e.L_ns = L_ns;
+  e.lag_ns = lag_ns;
+  e.n = g.n_tiles;
+  e.d_order = nullptr;
+  HIPCHK(hipMalloc((void **)&e.d_order, codes.size() * sizeof(unsigned) + 16));
+  HIPCHK(hipMemcpy(e.d_order, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  if (g_orders.size() >= 16) {  // (shapes come and go in tests: keep the table small)
+    (void)hipFree(g_orders.front().d_order);
+    g_orders.erase(g_orders.begin());
+  }
+  g_orders.push_back(e);
+  *out = e.d_order;
+  return 0;
+}
+
+int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st) {
+  const unsigned N = A.N, M = A.M;
+  const ck_geom g = ck_geometry(N, M, D);
+  if (!g.ok) return stb_fail("stb_fill_S: the checkpointed form does not take N=%u M=%u D=%d", N, M, D);
+  if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the checkpointed form");
+  ck_args X;
+  memset(&X, 0, sizeof(X));
+  X.hdr = (unsigned *)ws;
+  X.progress = (unsigned *)(ws + g.off_prog);
+  X.edge_e = (unsigned long long *)(ws + g.off_ee);
+  X.edge_v = (unsigned long long *)(ws + g.off_ev);
+  X.ck_e = (unsigned *)(ws + g.off_cke);
+  X.ck_v = (unsigned long long *)(ws + g.off_ckv);
+  X.EV = g.EV;
+  X.NP = g.NP;
+  X.D = D;
+  X.B = g.B;
+  X.JW = g.JW;
+  X.NBK = g.NBK;
+  X.TP = g.TP;
+  X.RB = g.RB;
+  X.G = g.G;
+  X.n_tiles = g.n_tiles;
+  X.n_spine = (unsigned)g.B * (unsigned)D;
+  X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
+  X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
+  X.spare_work = stb_env_int("STB_CK_SPARE", 0);
+  if (ck_order_list(g, N, M, &X.order)) return 1;
+  const char *tl_file = getenv("STB_CK_TIMELINE");
+  const size_t dbg_words = (size_t)g.JW * (g.NBK + 2) + (size_t)g.n_tiles * 4;
+  if (tl_file && *tl_file) {
+    HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
+    HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
+  }
+  HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  *hdr_out = X.hdr;
+  stb_launch_s1(A, D, st);
+  hipLaunchKernelGGL(k_col1, dim3(D), dim3(1024), 0, st, A.a, X, (double *)(ws + g.off_tm), (int *)(ws + g.off_te), g.R);
+  // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
+  int dev = 0, cus = 256;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int per_cu = stb_env_int("STB_CK_WG_PER_CU", g.C == 4 ? 1 : 2);
+  unsigned grid = (unsigned)(cus * per_cu);
+  const unsigned min_workers = (unsigned)stb_env_int("STB_CK_MIN_WORKERS", 64);
+  if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
+  const int shape = g.C * 10 + g.P;
+#define CKL(CC, PP) STB_LAUNCH((k_fill_ck<CC, PP>), dim3(grid), dim3(64 * CK_NW), st, A, X)
+  switch (shape) {
+    case 11: CKL(1, 1); break;
+    case 12: CKL(1, 2); break;
+    case 14: CKL(1, 4); break;
+    case 21: CKL(2, 1); break;
+    case 22: CKL(2, 2); break;
+    case 24: CKL(2, 4); break;
+    case 41: CKL(4, 1); break;
+    case 42: CKL(4, 2); break;
+    case 44: CKL(4, 4); break;
+    default: return stb_fail("stb_fill_S: no checkpointed kernel for C=%d P=%d", g.C, g.P);
+  }
+#undef CKL
+  HIPCHK(hipGetLastError());
+  if (X.dbg) {
+    // spine: one line per wave strip "S jw start b1 b2 ... end"; workers: "W jw b claimed loaded done hwid"
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(dbg_words);
+    std::vector<unsigned> ord(g.n_tiles);
+    HIPCHK(hipMemcpy(h.data(), X.dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ord.data(), X.order, g.n_tiles * 4, hipMemcpyDeviceToHost));
+    FILE *f = fopen(tl_file, "w");
+    if (f) {
+      fprintf(f, "G %d %d %d %d %d %d %d %d\n", g.C, g.P, g.JW, g.NBK, g.RB, g.TP, g.G, D);
+      for (int jw = 0; jw < g.JW; jw++) {
+        fprintf(f, "S %d", jw);
+        for (int b = 0; b < g.NBK + 2; b++) fprintf(f, " %llu", h[(size_t)jw * (g.NBK + 2) + b]);
+        fprintf(f, "\n");
+      }
+      const unsigned long long *w = h.data() + (size_t)g.JW * (g.NBK + 2);
+      for (unsigned k = 0; k < g.n_tiles; k++)
+        fprintf(f, "W %u %u %llu %llu %llu %llu\n", ord[k] & 0xffffu, ord[k] >> 16, w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+      fclose(f);
+    }
+    (void)hipFree(X.dbg);
+  }
+  return 0;
+}

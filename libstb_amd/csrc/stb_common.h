@@ -5,6 +5,7 @@
 //   abi.hip          error text, device selection, buffer cache, memory helpers, layout exports
 //   fill.hip         stb_fill_S / stb_fill_V: choice of form, workspace, status, per-launch timing
 //   fill_chain.hip   k_fill_chain (default S fill, also the fused aterms sum), k_fillv_chain (V)
+//   fill_ck.hip      k_fill_ck (spine + tile workers: few tables), k_col1
 //   fill_pc.hip      k_fill_pc (launch-per-128-rows form: many tables, and the fallback), k_s1
 //   fill_rows.hip    k_fill_rows: the reference's own operation order (log domain / V ratios)
 //   sweep_terms.hip  k_lookup, k_to_float, k_sweep_partial, k_terms_partial, reductions
@@ -122,6 +123,10 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
                      hipStream_t st);
 int stb_launch_vchain(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
 int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out);  // columns per strip
+// checkpointed form (fill_ck.hip): spine + tile workers, one launch
+bool stb_ck_eligible(unsigned N, unsigned M, int D);
+size_t stb_ck_workspace(unsigned N, unsigned M, int D);
+int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
