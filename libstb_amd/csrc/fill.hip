@@ -3,8 +3,10 @@
 // workspace, keeps the status of the last chain-form fill and the optional per-launch timing.
 //
 // Forms (kernels in their own translation units):
-//   chain   k_fill_chain / k_fillv_chain   one launch per fill (default while D*M <= STB_CHAIN_MAX_COLS)
-//   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of the chain)
+//   chain   k_fill_chain / k_fillv_chain   one launch per fill (default for small fills, and the fused aterms)
+//   ck      k_fill_ck                      one launch: recurrence-only spine + tile workers (default from
+//                                          ~10^8 to ~10^9 cells: 2-20 tables of 10^4 columns)
+//   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of chain and ck)
 //   rows    k_fill_rows                    the reference's own operation order (STB_FILL_LOGDOMAIN)
 //   + the superseded forms of ablation.hip in `make ABLATION=1` builds
 
@@ -125,9 +127,25 @@ extern "C" int stb_has_ablation(void) { return stb_ablation_fill != nullptr; }
 // launch, no halo) up to STB_CHAIN_MAX_COLS columns over all tables, the producer/consumer form
 // beyond.  (MI355X, tools/ab_chain.py: 16 tables of 10^4 columns 2.01 ms pc against 2.11 chain, 12
 // tables 1.78 against 1.68; 32 tables of 4000 columns 0.78 against 0.70.)
+static bool g_dot_req_active();  // (a fused aterms evaluation is pending on this thread: that is the chain form's)
 static bool chain_wins(unsigned N, unsigned M, int D) {
   const uint64_t cap = (uint64_t)stb_env_int("STB_CHAIN_MAX_COLS", 150000);
   return (uint64_t)D * M <= cap && N >= 3 && N < (1u << 27);
+}
+
+// ... and between the two, by cells in all: the checkpointed form (spine + tile workers) from ~10^8 cells
+// (2 tables of 10^4 columns, 12 of 4000) to ~10^9 (20 tables of 10^4), where the table traffic of the
+// producer/consumer form's many launches catches up.  (MI355X, tools/sweep_forms.sh, N = M = 10^4: 4 tables
+// 0.79 ms against 1.03 chain, 8 tables 0.98 against 1.36, 16 tables 1.68 against 2.02 pc, 24 tables 2.48
+// against 2.40 pc; N = M = 4000: 8 tables 0.33 = chain, 16 tables 0.36 against 0.47, 64 tables 1.04 = pc.)
+// STB_CK=0 / 1 switches it off / on wherever it is eligible.
+static bool ck_wins(unsigned N, unsigned M, int D) {
+  const int force = stb_env_int("STB_CK", -1);
+  if (force == 0 || g_dot_req_active() || !stb_ck_eligible(N, M, D)) return false;
+  if (force > 0) return true;
+  const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
+  return cells >= (uint64_t)stb_env_int("STB_CK_MIN_MCELLS", 80) * 1000000ull &&
+         cells <= (uint64_t)stb_env_int("STB_CK_MAX_MCELLS", 1000) * 1000000ull;
 }
 
 enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK };
@@ -147,6 +165,7 @@ static int pick_form(int variant, unsigned N, unsigned M, int D) {
     default:
       // the block-floating forms bound the scale between lanes for N < 2^27 (see k_fill_pc)
       if (N >= (1u << 27)) return FORM_ROWS_LOG;
+      if (ck_wins(N, M, D)) return FORM_CK;
       return chain_wins(N, M, D) ? FORM_CHAIN : FORM_PC;
   }
 }
@@ -161,6 +180,14 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
     if (launches) *launches = 1;
     return 3;
   }
+  if (form == FORM_CK) {
+    int W = 0, rows = 0;
+    stb_ck_tuning(N, M, D, &W, &rows);
+    if (C_out) *C_out = W;     // columns of a wave strip
+    if (R_out) *R_out = rows;  // rows of a tile
+    if (launches) *launches = 1;
+    return 4;
+  }
   int C = (form == FORM_PC) ? 4 : stb_env_int("STB_FILL_C", 2);
   int R = stb_env_int("STB_FILL_R", form == FORM_PC ? 128 : 64);
   if (form == FORM_PC && R > 128) R = 128;
@@ -168,7 +195,7 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
   if (C_out) *C_out = C;
   if (R_out) *R_out = R;
   if (launches) *launches = ((int)N - 1 + R - 1) / R;
-  return form == FORM_PC ? 2 : 5; /* 2 producer/consumer (k_fill_pc), 3 chain, 5 another form */
+  return form == FORM_PC ? 2 : 5; /* 2 producer/consumer (k_fill_pc), 3 chain, 4 checkpointed, 5 another form */
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +215,7 @@ static thread_local unsigned g_fallbacks = 0;
 static thread_local const dot_request *g_dot_req = nullptr;
 
 void stb_set_dot_request(const dot_request *r) { g_dot_req = r; }
+static bool g_dot_req_active() { return g_dot_req != nullptr; }
 
 extern "C" unsigned stb_fill_fallbacks(void) { return g_fallbacks; }
 

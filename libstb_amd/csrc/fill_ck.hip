@@ -50,6 +50,12 @@
 #define CK_NW 8        // waves per workgroup
 #define CK_EOFF32 (1u << 30)
 #define CK_MAXRB 16    // trips per block at most (worker edge buffer: 128 rows)
+#ifndef CK_DIAG
+#define CK_DIAG 0      // diagnostic builds (results wrong): 1 no edge posts, 2 no left inputs, 4 no left counter, 8 no progress post
+#endif
+#ifndef CK_LOOK
+#define CK_LOOK 4      // the row of a trip after which the next trip's left inputs and the left counter are read
+#endif
 
 struct ck_args {
   unsigned *hdr;               // [0] role ticket, [1] error code, [2] error detail, [3] tile ticket; zeroed per fill
@@ -58,6 +64,7 @@ struct ck_args {
   unsigned long long *ck_v;    // [D][JW][NBK][64*C]  checkpoint: significands at the start of a block
   unsigned *ck_e;              // [D][JW][NBK][64]    ... and lane exponents + CK_EOFF32
   unsigned *progress;          // [D][JW]  blocks a spine wave has finished (scheduling hint)
+  unsigned *cu_busy;           // [4096]   spine waves walking on a compute unit (key: XCC id, SE/SH/CU id), or null
   const unsigned *order;       // [n_tiles] jw | b << 16, in the order the tiles become ready
   uint64_t EV, NP;
   int D, B, JW, NBK;           // tables, spine workgroups per table, wave strips per table, blocks
@@ -66,7 +73,10 @@ struct ck_args {
   unsigned n_spine;            // spine workgroups in all (B * D)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
   int poll_nap;
+  int pub_nap;                 // s_sleep argument between two looks of the publisher
+  unsigned tp_magic;           // ceil(2^32 / TP): trip / TP = umulhi(trip, tp_magic)
   int spare_work;              // 1: the spare waves of a spine workgroup work as tile workers meanwhile
+  int diag;                    // STB_CK_DIAG: 1 the workers wait for the whole spine
   unsigned long long *dbg;     // STB_CK_TIMELINE: wall-clock stamps, table 0: [JW][NBK + 2] spine (start, block ends, end),
                                // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
 };
@@ -134,15 +144,15 @@ __device__ __forceinline__ void ck_renorm(double (&v)[C], int &ep) {
 }
 
 template <int C, int P>
-__global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_args A, ck_args X) {
+__global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args X) {
   constexpr int U = CK_U, RE = CK_RE;
   constexpr int WS = 64 * C;  // columns of a wave strip
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
   static_assert(P >= 1 && P <= 4, "spine waves per workgroup");
   __shared__ double2 lt[128];
   // spine workgroups
-  __shared__ __attribute__((aligned(16))) double xedge[4][RE * U];  // last column of spine wave w, ring indexed by row
-  __shared__ int xexp[4][RE];                                       // its lane exponent per trip
+  __shared__ __attribute__((aligned(16))) double xedge[4][RE * U];  // last column of spine wave w: row r at entry r mod 256
+  __shared__ int xexp[4][16];                                       // its lane exponent per period (ring of 16)
   __shared__ __attribute__((aligned(16))) double edge_in[RE * U];   // what the fetcher delivers to spine wave 0
   __shared__ int edge_e[RE];
   __shared__ __attribute__((aligned(16))) double pad8[64 + RE * U + 8];  // where lanes 0..62 of a masked post go
@@ -161,9 +171,15 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
   for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
   __syncthreads();
   const unsigned ticket = s_ticket;
+  unsigned *cu_busy = nullptr;
+  if (X.cu_busy) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    cu_busy = X.cu_busy + (((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
+  }
   const unsigned N = A.N, M = A.M;
   const int TP = X.TP, RB = X.RB, G = X.G;
-  bool worker = true;
 
   if (ticket < X.n_spine) {
     // =========================================================================================
@@ -197,7 +213,6 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
 
     if (wave < P) {
       // ================= spine waves =================
-      worker = false;
       doze();
       __builtin_amdgcn_s_setprio(3);
       auto spine = [&](auto wc) {
@@ -221,10 +236,13 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
         int bnext = g0w / RB + 1;  // the next block boundary is trip bnext * RB
         unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (X.NBK + 2) : nullptr;
         if (dbg) dbg[0] = wall_clock64();
+        if (cu_busy && lane == 0) atomicAdd(cu_busy, 1u);
         const bool has_next = (w < P - 1) && (jw + 1 < X.JW);
         const int *left_cnt = (w == 0) ? &edge_ready : &prod_done[w > 0 ? w - 1 : 0];
         const int *next_cnt = &prod_done[(w < P - 1) ? w + 1 : w];
-        int n_left, n_next = 0x7fffffff, n_pub;
+        // the ring the left inputs come from
+        const double *left_ring = (w == 0) ? edge_in : &xedge[w > 0 ? w - 1 : 0][0];
+        const int *left_exp = &xexp[w > 0 ? w - 1 : 0][0];
         // masked posts: lane 63 writes the ring, lane 0 the counter, the other lanes scratch
         const unsigned edge_base = (lane == 63) ? lds_addr_of(&xedge[w][0]) : lds_addr_of(&pad8[lane]);
         int *exp_base = (lane == 63) ? &xexp[w][0] : &pad4[lane];
@@ -232,76 +250,77 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
         unsigned long long *ckv = X.ck_v + (((size_t)d * X.JW + jw) * X.NBK) * (64 * C) + lane * C;
         unsigned *cke = X.ck_e + (((size_t)d * X.JW + jw) * X.NBK) * 64 + lane;
         unsigned *prog = X.progress + (size_t)d * X.JW + jw;
-        auto peek_counters = [&]() {
-          n_left = lds_peek(left_cnt);
-          if (has_next) n_next = lds_peek(next_cnt);
-          n_pub = lds_peek(&pub_done[w]);
-          asm volatile("" ::: "memory");
-        };
+        int n_left;
         auto load_left = [&](double(&x)[U], int g) {
-          // the input of row u of trip g is the left column one row up: ring entry 8 g + u - 1
-          const double *src = (w == 0) ? edge_in : &xedge[w > 0 ? w - 1 : 0][0];
           if (w == 0) {
+            // (the fetcher stores a row at the entry of the row it feeds: aligned)
+            const ck_double2 *src = reinterpret_cast<const ck_double2 *>(left_ring + (g & (RE - 1)) * U);
 #pragma unroll
-            for (int u = 0; u < U; u++) x[u] = src[(g & (RE - 1)) * U + u];  // (the fetcher stores it shifted)
+            for (int q = 0; q < U / 2; q++) {
+              const ck_double2 t2 = src[q];
+              x[2 * q] = t2.x;
+              x[2 * q + 1] = t2.y;
+            }
           } else {
-            x[0] = src[((g - 1) & (RE - 1)) * U + U - 1];
+            // the spine wave to the left stores row r at entry r mod 256: the input of row u is entry 8 g + u - 1
+            x[0] = left_ring[(g * U - 1) & (RE * U - 1)];
 #pragma unroll
-            for (int u = 1; u < U; u++) x[u] = src[(g & (RE - 1)) * U + u - 1];
+            for (int u = 1; u < U; u++) x[u] = left_ring[(g & (RE - 1)) * U + u - 1];
           }
         };
-        auto counters_ok = [&](int g) {
-          return n_left >= g + 1 && n_next >= g - RE + 2 && n_pub >= g - RE + 1;
-        };
+        // A lone wave pays ~20 cycles for an LDS store and 35-50 for a branch on a vector compare
+        // (tools/ubench/spine.hip: 16 ns of arithmetic a row, 9 for a ds_write_b64 a row, 8 for three tests
+        // a trip), so: two rows go out with one ds_write2_b64, and everything that can stop a trip -- the
+        // left neighbour not far enough (its counter is read with the next trip's inputs at row CK_LOOK),
+        // a period or block boundary, the ring guard every 8th trip -- sits behind ONE branch.
         auto trip = [&](int g, double(&e)[U], double(&en)[U]) {
-          if (__builtin_expect(!counters_ok(g), 0)) {
-            peek_counters();
-            load_left(e, g);
-            if (!counters_ok(g)) {
+          const int stop = (int)(n_left < g + 1) | (int)(tin == 0) | (int)((g & 7) == 0) | (int)(g == g0w);
+          if (__builtin_expect(stop != 0, 0)) {
+            if (n_left < g + 1) {
               wait_ge(left_cnt, g + 1, 0x100u, 1);
-              if (has_next) wait_ge(next_cnt, g - RE + 2, 0x400u, 1);
-              wait_ge(&pub_done[w], g - RE + 1, 0x500u, 1);
               asm volatile("" ::: "memory");
               load_left(e, g);
             }
-          }
-          // what the next trip needs from the other waves is read now, under this trip's arithmetic
-          peek_counters();
-          load_left(en, g + 1);
-          if (__builtin_expect(g == g0w || tin == 0, 0)) {
-            if (g != g0w) {
-              if (g == bnext * RB) {
-                // ---- checkpoint: the row as it stands before trip g, for the worker of block bnext ----
-                unsigned long long *dst = ckv + (size_t)bnext * (64 * C);
+            if ((g & 7) == 0) {
+              if (has_next) wait_ge(next_cnt, g - RE + 9, 0x400u, 1);
+              wait_ge(&pub_done[w], g - RE + 8, 0x500u, 1);
+            }
+            if (g == g0w || tin == 0) {
+              if (g != g0w) {
+                if (g == bnext * RB) {
+                  // ---- checkpoint: the row as it stands before trip g, for the worker of block bnext ----
+                  unsigned long long *dst = ckv + (size_t)bnext * (64 * C);
 #pragma unroll
-                for (int i = 0; i < C; i++) {
-                  unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
-                  if ((b << 1) == 0) b = CH_NEGZERO;
-                  __hip_atomic_store(dst + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  for (int i = 0; i < C; i++) {
+                    unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+                    if ((b << 1) == 0) b = CH_NEGZERO;
+                    __hip_atomic_store(dst + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                  __hip_atomic_store(cke + (size_t)bnext * 64, (unsigned)ep + CK_EOFF32, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                  if (lane == 0) __hip_atomic_store(prog, (unsigned)bnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (dbg) dbg[bnext] = wall_clock64();
+                  bnext++;
                 }
-                __hip_atomic_store(cke + (size_t)bnext * 64, (unsigned)ep + CK_EOFF32, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) __hip_atomic_store(prog, (unsigned)bnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dbg) dbg[bnext] = wall_clock64();
-                bnext++;
+                ck_renorm<C>(v, ep);
               }
-              ck_renorm<C>(v, ep);
+              // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
+              int el;
+              if (w == 0) {
+                el = edge_e[g & (RE - 1)];
+              } else {
+                el = left_exp[p & 15];
+                // the row above the first row of a period was produced under the previous period's exponent
+                if (tin == 0 && p > 0) e[0] = ldexp(e[0], left_exp[(p - 1) & 15] - el);
+              }
+              int dl = wave_shr1(ep, ep) - ep;
+              if (lane == 0) dl = el - ep;
+              s = ldexp(1.0, min(max(dl, -1100), 220));
+              exp_base[p & 15] = ep;
             }
-            // freeze the scale of the cross-lane input for the period (bounds: see k_fill_pc)
-            int el;
-            if (w == 0) {
-              el = edge_e[g & (RE - 1)];
-            } else {
-              el = xexp[w > 0 ? w - 1 : 0][g & (RE - 1)];
-              // the row above the first row of a trip was produced under the previous trip's exponent
-              e[0] = ldexp(e[0], xexp[w > 0 ? w - 1 : 0][(g - 1) & (RE - 1)] - el);
-            }
-            int dl = wave_shr1(ep, ep) - ep;
-            if (lane == 0) dl = el - ep;
-            s = ldexp(1.0, min(max(dl, -1100), 220));
           }
-          exp_base[g & (RE - 1)] = ep;
-          const unsigned ebase = edge_base + (unsigned)((g & (RE - 1)) * U * 8);
+          const unsigned wa = edge_base + (unsigned)((g & (RE - 1)) * U * 8);
+          double hold = 0.0;  // (the even row of a pair, until its odd row is there)
           auto row = [&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const double t0 = wave_shr1(v[C - 1], e[u]) * s;
@@ -310,7 +329,16 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
             v[0] = fma(coef[0], v[0], t0);
 #pragma unroll
             for (int i = 0; i < C; i++) coef[i] += 1.0;
-            lds_store1<u * 8>(ebase, v[C - 1]);
+            if constexpr (!(CK_DIAG & 1)) {
+              if constexpr ((u & 1) == 0) hold = v[C - 1];
+              else lds_store2<u - 1>(wa, hold, v[C - 1]);
+            }
+            if constexpr (u == CK_LOOK) {
+              // what the next trip needs from the left is read now, under this trip's arithmetic
+              if constexpr (!(CK_DIAG & 4)) n_left = lds_peek(left_cnt);
+              asm volatile("" ::: "memory");
+              if constexpr (!(CK_DIAG & 2)) load_left(en, g + 1);
+            }
           };
           static_assert(U == 8, "rows of a trip");
           row(std::integral_constant<int, 0>{});
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
           row(std::integral_constant<int, 6>{});
           row(std::integral_constant<int, 7>{});
           asm volatile("" ::: "memory");
-          __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if constexpr (!(CK_DIAG & 8)) __hip_atomic_store(post_addr, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
           if (++tin == TP) {
             tin = 0;
@@ -330,7 +358,8 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
           }
         };
         double ea[U], eb[U];
-        peek_counters();
+        n_left = lds_peek(left_cnt);
+        asm volatile("" ::: "memory");
         load_left(ea, g0w);
         int g = g0w;
         for (; g + 1 < G; g += 2) {
@@ -340,6 +369,8 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
         if (g < G) trip(g, ea, eb);
         if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[X.NBK + 1] = wall_clock64();
+        if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
+        if (cu_busy && lane == 0) atomicSub(cu_busy, 1u);
       };
       if (P == 1 || wave == 0) spine(std::integral_constant<int, 0>{});
       else if (wave == 1) spine(std::integral_constant<int, (P >= 2) ? 1 : 0>{});
@@ -348,7 +379,6 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
       __builtin_amdgcn_s_setprio(0);
     } else if (wave == P) {
       // ================= fetcher: the left strip's edge stream -> LDS, for spine wave 0 =================
-      worker = false;
       const unsigned long long *ev_in = X.edge_v + (strip0 + jw0) * X.EV;      // strip jw0 - 1 (virtual for j = 0)
       const unsigned long long *ee_in = X.edge_e + (strip0 + jw0) * X.NP + 1;  // [t] for trip t >= -1
       struct edge_poll {
@@ -450,7 +480,6 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
     } else if (wave == P + 1) {
       // ================= publisher: the spine waves' last columns -> HBM =================
       // 16 lanes per spine wave: lanes 0..7 the rows of a trip, lane 8 its exponent
-      worker = false;
       doze();
       const int grp = lane >> 4, sub = lane & 15;
       const int jw = jw0 + grp;
@@ -476,7 +505,8 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
               if ((b << 1) == 0) b = CH_NEGZERO;
               dst = ev_out + 3 + tw * U + sub;
             } else {
-              b = (unsigned long long)((long long)xexp[grp & 3][tw & (RE - 1)] + (long long)CH_EOFF);
+              const int pw = (TP == 1) ? tw : (int)__umulhi((unsigned)tw, X.tp_magic);
+              b = (unsigned long long)((long long)xexp[grp & 3][pw & 15] + (long long)CH_EOFF);
               dst = ee_out + tw;
             }
             __hip_atomic_store(dst, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -490,8 +520,12 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
           timing = false;
           continue;
         }
-        __builtin_amdgcn_s_sleep(1);
-        if ((++idle & 255) != 0) continue;
+        // (a trip takes the spine ~0.3 us: looking more often only takes issue slots from it)
+        if (X.pub_nap >= 8) __builtin_amdgcn_s_sleep(8);
+        else if (X.pub_nap >= 4) __builtin_amdgcn_s_sleep(4);
+        else if (X.pub_nap >= 2) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(1);
+        if ((++idle & 63) != 0) continue;
         if (lds_peek(&s_abort)) {
           // the spine runs to its end whatever happens: keep releasing its ring without the clock
           continue;
@@ -504,11 +538,12 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
         }
       }
     } else if (!X.spare_work) {
-      worker = false;
+      // spare waves: asleep while the spine walks (they would take issue slots from it), workers afterwards
+      while (lds_peek(&prod_done[0]) < G && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(127);
     }
+    // whoever is through with its part of the spine works on tiles
   }
 
-  if (!worker) return;
   // =========================================================================================
   // tile workers (every wave for itself)
   {
@@ -518,8 +553,24 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
     int one_hi = 0x3ff00000;
     asm volatile("" : "+v"(one_hi));
     const unsigned total = X.n_tiles * (unsigned)X.D;
+    if (X.diag & 1) {
+      // diagnostic: the workers start when every spine wave is through (what the tiles cost with the chip to themselves)
+      unsigned spins = 0;
+      while (__hip_atomic_load(X.hdr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(X.JW * X.D) && ++spins < 400000u)
+        __builtin_amdgcn_s_sleep(100);
+    }
     for (;;) {
       unsigned k = 0;
+      if (cu_busy) {
+        // A spine wave runs at the pace of a lone wave and anything else that issues on its compute unit
+        // slows it (8 tables: 1.5 ms with the spare waves of the spine's workgroups working, 1.2 without):
+        // while one walks here, this wave sleeps.  The other compute units carry two workgroups of workers.
+        unsigned spins = 0;
+        while (__hip_atomic_load(cu_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __builtin_amdgcn_s_sleep(127);
+          if ((++spins & 63u) == 0 && __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        }
+      }
       if (lane == 0) k = atomicAdd(X.hdr + 3, 1u);
       k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
       if (k >= total) break;
@@ -671,7 +722,11 @@ __global__ __launch_bounds__(64 * CK_NW, (C == 4) ? 2 : 4) void k_fill_ck(fill_a
           ck_logs<8>(x, ep, lt, one_hi, val);
 #pragma unroll
           for (int u = 0; u < RS; u++) {
-            if (fast || (unsigned)(r0 + h + u) <= N) {
+            if constexpr ((CK_DIAG & 16) != 0) {
+              // (diagnostic: the values are kept alive, the table is not written except for a tile's last row)
+              if (g == ge - 1 && h + u == U - 1) store_sbase(rowp + (size_t)(h + u) * pitch, voff, val[u * C] + val[u * C + C - 1]);
+              else asm volatile("" ::"v"(val[u * C]), "v"(val[u * C + C - 1]));
+            } else if (fast || (unsigned)(r0 + h + u) <= N) {
               double *rp = rowp + (size_t)(h + u) * pitch;
               if constexpr (C == 1) {
                 store_sbase(rp, voff, val[u]);
@@ -789,7 +844,7 @@ struct ck_geom {
   int C, P, B, JW, G, TP, RB, NBK, R;
   uint64_t EV, NP;
   unsigned n_tiles;
-  size_t off_prog, off_ee, off_ev, off_cke, off_ckv, zero_bytes, off_tm, off_te, bytes;
+  size_t off_cu, off_prog, off_ee, off_ev, off_cke, off_ckv, zero_bytes, off_tm, off_te, bytes;
   bool ok;
 };
 
@@ -799,8 +854,10 @@ static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
   memset(&g, 0, sizeof(g));
   g.ok = false;
   if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return g;
-  const uint64_t cols = (uint64_t)D * M;
-  g.C = stb_env_int("STB_CK_C", cols <= 200000 ? 2 : 4);
+  // (MI355X, tools/sweep_forms.sh: at 10^4 columns 4 columns a lane win from 2 tables on, 0.98 against 1.03 ms at
+  // 8; at 4000 columns 2 win up to 16 tables, 0.36 against 0.38 ms, and lose at 32, 0.62 against 0.58)
+  const uint64_t total_cells = (uint64_t)D * stb_table_cells(N, M);
+  g.C = stb_env_int("STB_CK_C", total_cells < 150000000ull ? 2 : 4);
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
   g.P = stb_env_int("STB_CK_P", 4);
   if (g.P < 1 || g.P > 4) g.P = 4;
@@ -808,7 +865,7 @@ static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
   const int Penv = stb_env_int("STB_FILL_P", 0);
   if (Penv > 0 && Penv < Pc) Pc = Penv;
   g.TP = Pc / CK_U;
-  if (g.TP < 1) return g;
+  if (g.TP < 2) return g;  // (the exponent ring of 16 periods must span the CK_RE trips two waves may be apart)
   if (g.TP > CK_MAXRB) g.TP = CK_MAXRB;
   const int target = stb_env_int("STB_CK_BLOCK_ROWS", 96) / CK_U;
   int K = (target + g.TP / 2) / g.TP;
@@ -830,6 +887,8 @@ static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
   for (int jw = 0; jw < g.JW; jw++) nt += g.NBK - ck_first_trip_h(2 + jw * WS) / g.RB;
   g.n_tiles = (unsigned)nt;
   size_t o = 256;
+  g.off_cu = o;
+  o += 4096 * sizeof(unsigned);
   g.off_prog = o;
   o += stb_align_up((size_t)D * g.JW * sizeof(unsigned), 256);
   g.off_ee = o;
@@ -852,6 +911,13 @@ static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
 
 bool stb_ck_eligible(unsigned N, unsigned M, int D) { return ck_geometry(N, M, D).ok; }
 
+int stb_ck_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out) {
+  const ck_geom g = ck_geometry(N, M, D);
+  if (W_out) *W_out = 64 * g.C;
+  if (rows_out) *rows_out = g.RB * CK_U;
+  return g.ok ? 0 : 1;
+}
+
 size_t stb_ck_workspace(unsigned N, unsigned M, int D) {
   size_t need = 0;
   // (the strip shape is a tunable and depends on the batch: size for every shape)
@@ -866,7 +932,7 @@ size_t stb_ck_workspace(unsigned N, unsigned M, int D) {
     const int WS = 64 * c;
     const unsigned cmax = (M < N - 1) ? M : N - 1;
     const size_t JW = (cmax - 1 + WS - 1) / WS + 1;
-    const size_t b = 256 + 4096 + (size_t)D * (JW + 1) * (g0.NP + g0.EV) * 8 + (size_t)D * JW * g0.NBK * 64 * (4 + 8 * c) +
+    const size_t b = 256 + 4096 * 5 + (size_t)D * (JW + 1) * (g0.NP + g0.EV) * 8 + (size_t)D * JW * g0.NBK * 64 * (4 + 8 * c) +
                      (size_t)D * (g0.R + 1) * 12 + 4096;
     if (b > need) need = b;
   }
@@ -952,6 +1018,16 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
   memset(&X, 0, sizeof(X));
   X.hdr = (unsigned *)ws;
   X.progress = (unsigned *)(ws + g.off_prog);
+  {
+    // compute units with a spine wave on them take no tile work while it walks, unless the spine needs
+    // so many of them that too few would be left for the tiles
+    int dev0 = 0, cus0 = 256;
+    HIPCHK(hipGetDevice(&dev0));
+    HIPCHK(hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0));
+    const int excl = stb_env_int("STB_CK_EXCL", -1);
+    const bool on = (excl < 0) ? ((unsigned)g.B * (unsigned)D * 10u <= (unsigned)cus0 * 4u) : (excl != 0);
+    X.cu_busy = on ? (unsigned *)(ws + g.off_cu) : nullptr;
+  }
   X.edge_e = (unsigned long long *)(ws + g.off_ee);
   X.edge_v = (unsigned long long *)(ws + g.off_ev);
   X.ck_e = (unsigned *)(ws + g.off_cke);
@@ -970,6 +1046,9 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
   X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
   X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
   X.spare_work = stb_env_int("STB_CK_SPARE", 0);
+  X.diag = stb_env_int("STB_CK_DIAG", 0);
+  X.pub_nap = stb_env_int("STB_CK_PUB_NAP", 4);
+  X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
   if (ck_order_list(g, N, M, &X.order)) return 1;
   const char *tl_file = getenv("STB_CK_TIMELINE");
   const size_t dbg_words = (size_t)g.JW * (g.NBK + 2) + (size_t)g.n_tiles * 4;
@@ -985,10 +1064,13 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
   int dev = 0, cus = 256;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int per_cu = stb_env_int("STB_CK_WG_PER_CU", g.C == 4 ? 1 : 2);
+  // one workgroup per compute unit: a second one slows the spine (clock, memory latency of its hand-offs)
+  // by more than its tiles gain -- 8 tables: 0.98 ms against 1.17
+  const int per_cu = stb_env_int("STB_CK_WG_PER_CU", 1);
   unsigned grid = (unsigned)(cus * per_cu);
   const unsigned min_workers = (unsigned)stb_env_int("STB_CK_MIN_WORKERS", 64);
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
+  if (stb_env_int("STB_CK_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_CK_GRID", 0);  // (diagnostic: spine alone)
   const int shape = g.C * 10 + g.P;
 #define CKL(CC, PP) STB_LAUNCH((k_fill_ck<CC, PP>), dim3(grid), dim3(64 * CK_NW), st, A, X)
   switch (shape) {

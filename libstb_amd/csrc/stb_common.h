@@ -126,6 +126,7 @@ int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out);  // columns per
 // checkpointed form (fill_ck.hip): spine + tile workers, one launch
 bool stb_ck_eligible(unsigned N, unsigned M, int D);
 size_t stb_ck_workspace(unsigned N, unsigned M, int D);
+int stb_ck_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // columns of a wave strip, rows of a tile
 int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);

@@ -21,7 +21,7 @@ def test_library_sees_gpu():
     assert L.stb_device_count() >= 1, capi.last_error()
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
 def test_small_tables_batched_vs_golden(golden_dir, variant):
     """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
     if not capi.has_variant(variant):
@@ -38,7 +38,7 @@ def test_small_tables_batched_vs_golden(golden_dir, variant):
         assert orc.close(T.S1[d].cpu().numpy(), z[k + "_S1"], TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
 @pytest.mark.parametrize("N,M", [(2, 2), (3, 2), (3, 3), (10, 10), (64, 64), (65, 33), (97, 96), (130, 129), (500, 7),
                                  (1000, 1000), (1500, 260)])
 def test_ragged_shapes_vs_oracle(N, M, variant):
@@ -67,7 +67,7 @@ def test_tunings_agree(monkeypatch, C, R):
     assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
 @pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
 def test_4000_full_table_vs_oracle(golden_dir, a, variant):
     if not capi.has_variant(variant):
@@ -152,7 +152,7 @@ def test_10000_batched_config3_eight_per_gpu(golden_dir, rank):
     T = capi.DeviceTables(10000, 10000, D=8)
     T.tables.fill_(float("nan"))
     before = L.stb_fill_fallbacks()
-    assert L.stb_fill_tuning(10000, 10000, 8, None, None, None) == 3      # chain form
+    assert L.stb_fill_tuning(10000, 10000, 8, None, None, None) == 4      # checkpointed form (spine + tile workers)
     T.fill(mine)
     T.status()
     assert L.stb_fill_fallbacks() == before
@@ -216,7 +216,7 @@ def test_v_table_big_vs_oracle():
     assert np.array_equal(T.packed_host(0), want)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX])
+@pytest.mark.parametrize("variant", [capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
 @pytest.mark.parametrize("a", [0.0, 0.01, 0.07, 0.5, 0.98])
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the

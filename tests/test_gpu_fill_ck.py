@@ -1,0 +1,164 @@
+"""GPU parity of the checkpointed fill form (k_fill_ck: recurrence-only spine + tile workers,
+libstb_amd/csrc/fill_ck.hip) through the C ABI, and the full-size cell-by-cell checks of the table
+fill (reference lib/stable.c:380-388) whatever form stb_fill_S picks.
+Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _check_tables(T, a, N, M):
+    for d in range(T.D):
+        S1, tab = orc.fill_S(float(a[d]), N, M)
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got)), (N, M, d)
+        assert orc.close(got, tab, TOL), (N, M, d, orc.max_err(got, tab))
+        assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
+
+
+@pytest.mark.parametrize("C,P", [(1, 1), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4)])
+def test_ck_geometries_agree(monkeypatch, C, P):
+    """every strip shape (columns per lane, spine waves per workgroup) computes the same tables, no
+    wave gives up waiting (several wave strips, several workgroups per table, several tables)"""
+    monkeypatch.setenv("STB_CK_C", str(C))
+    monkeypatch.setenv("STB_CK_P", str(P))
+    L = capi.lib()
+    a = np.array([0.05, 0.5, 0.93])
+    T = capi.DeviceTables(900, 700, D=3)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_CK)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    _check_tables(T, a, 900, 700)
+
+
+@pytest.mark.parametrize("rows,period", [(48, 0), (96, 24), (128, 0), (64, 16)])
+def test_ck_block_and_period_lengths(monkeypatch, rows, period):
+    """tiles of other heights and shorter renormalisation periods: checkpoints fall on period
+    boundaries whatever the two are"""
+    monkeypatch.setenv("STB_CK_BLOCK_ROWS", str(rows))
+    if period:
+        monkeypatch.setenv("STB_FILL_P", str(period))
+    a = np.array([0.2, 0.8])
+    T = capi.DeviceTables(1300, 1100, D=2)
+    T.tables.fill_(float("nan"))
+    T.fill(a, capi.FILL_CK)
+    T.status()
+    _check_tables(T, a, 1300, 1100)
+
+
+def test_ck_random_shapes_vs_oracle():
+    rng = np.random.default_rng(20261004)
+    L = capi.lib()
+    before = L.stb_fill_fallbacks()
+    for _ in range(14):
+        N = int(rng.integers(3, 2600))
+        M = int(rng.integers(2, N + 1))
+        D = int(rng.integers(1, 5))
+        a = np.round(rng.uniform(0.0, 0.99, size=D), 6)
+        T = capi.DeviceTables(N, M, D=D)
+        T.tables.fill_(float("nan"))
+        T.fill(a, capi.FILL_CK)
+        T.status()
+        _check_tables(T, a, N, M)
+    assert L.stb_fill_fallbacks() == before
+
+
+def test_ck_more_spine_workgroups_than_compute_units(monkeypatch):
+    """one-wave spine workgroups of 64 columns, 40 tables of 3000 columns: 1880 spine workgroups for a
+    grid that holds a few hundred at once -- a strip only ever waits for a strip with a smaller ticket"""
+    monkeypatch.setenv("STB_CK_C", "1")
+    monkeypatch.setenv("STB_CK_P", "1")
+    D, N = 40, 3000
+    a = synth.discount_grid(64)[:D]
+    T = capi.DeviceTables(N, N, D=D)
+    T.tables.fill_(float("nan"))
+    T.fill(a, capi.FILL_CK)
+    T.status()
+    T2 = capi.DeviceTables(N, N, D=D)
+    T2.fill(a, capi.FILL_PC)
+    for d in (0, 7, D - 1):
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got))
+        assert orc.max_err(got, T2.packed_host(d)) <= TOL
+
+
+def test_ck_gives_up_instead_of_hanging(monkeypatch):
+    """every wait of the checkpointed form is bounded: with the bound at zero whoever has to wait
+    records an error and everybody runs to the end; stb_fill_status then repeats the fill with the
+    producer/consumer form -- or reports the failure when that is switched off"""
+    L = capi.lib()
+    S1, tab = orc.fill_S(0.5, 3000, 3000)
+    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    monkeypatch.setenv("STB_CHAIN_NO_FALLBACK", "1")
+    T = capi.DeviceTables(3000, 3000, D=1)
+    T.fill([0.5], capi.FILL_CK)
+    with pytest.raises(capi.StbError):
+        T.status()
+    monkeypatch.delenv("STB_CHAIN_NO_FALLBACK")
+    before = L.stb_fill_fallbacks()
+    T.tables.fill_(float("nan"))
+    T.fill([0.5], capi.FILL_CK)
+    T.status()
+    assert L.stb_fill_fallbacks() == before + 1
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
+    monkeypatch.delenv("STB_CHAIN_TIMEOUT_MS")
+    T.tables.fill_(float("nan"))
+    T.fill([0.5], capi.FILL_CK)
+    T.status()
+    assert L.stb_fill_fallbacks() == before + 1
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
+
+
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_CK])
+def test_10000_full_table_vs_oracle(variant):
+    """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's
+    (reference recurrence lib/stable.c:380-388), in the form stb_fill_S picks and in the checkpointed one"""
+    N, a = 10000, 0.5
+    T = capi.DeviceTables(N, N, D=1)
+    T.tables.fill_(float("nan"))
+    T.fill([a], variant)
+    T.status()
+    S1, tab = orc.fill_S(a, N, N)
+    got = T.packed_host(0)
+    assert got.shape[0] == 49985001
+    err = np.abs(got - tab) / np.maximum(1.0, np.abs(tab))
+    assert np.all(np.isfinite(got))
+    assert float(err.max()) <= TOL, float(err.max())
+    assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
+
+
+@pytest.mark.parametrize("D", [8, 64])
+def test_10000_batch_every_table_vs_oracle(D):
+    """configs[2]: EVERY table of the 8-per-GPU share (checkpointed form) and of the whole 64-discount
+    batch on one GPU (producer/consumer form) against the oracle: the last row, an interior row and
+    the row where the table turns rectangular-free (n = N/3), per-row maximum relative error"""
+    N = 10000
+    grid = synth.discount_grid(64)
+    a = np.ascontiguousarray(grid[:D])
+    T = capi.DeviceTables(N, N, D=D)
+    T.fill(a)
+    T.status()
+    rows = (N, 6311, N // 3)
+
+    def oracle_rows(ad):
+        S1, tab = orc.fill_S(float(ad), N, N)
+        return [tab[orc.row_offset(n, N):orc.row_offset(n, N) + n - 2].copy() for n in rows], S1[-1]
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(oracle_rows, a))
+    for d in range(D):
+        for n, w in zip(rows, want[d][0]):
+            got = T.row(d, n).cpu().numpy()
+            err = np.abs(got - w) / np.maximum(1.0, np.abs(w))
+            assert np.all(np.isfinite(got)) and float(err.max()) <= TOL, (d, n, float(err.max()))
+        assert abs(float(T.S1[d, N - 1]) - want[d][1]) <= TOL * abs(want[d][1])

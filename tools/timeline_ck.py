@@ -13,9 +13,10 @@ from libstb_amd import capi, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/timeline_ck.txt"
+M = int(sys.argv[4]) if len(sys.argv) > 4 else N
 raw = out + ".raw"
 a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
-T = capi.DeviceTables(N, N, D=D)
+T = capi.DeviceTables(N, M, D=D)
 for _ in range(3):
     T.fill(a, capi.FILL_CK)
 torch.cuda.synchronize()
