@@ -148,6 +148,14 @@ stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *T, const ui
 void stb_groups_free(stb_groups_t *g);
 /* out_host[D] = aterms(x_d) for every d: table build + sweep + restaurant terms.  D <= Dmax. */
 int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host);
+/* The same evaluation in two calls, so that ONE host thread can keep several GPUs (or several group sets)
+ * busy: _async queues it on the set's own stream -- behind whatever `stream` (a hipStream_t, or NULL)
+ * holds at this moment -- and returns without waiting; stb_groups_wait blocks until it is through and
+ * only then writes out_host[0..D-1].  x_host may be reused at once, out_host must stay valid until the
+ * wait; one evaluation per set at a time.  (All entry points of this library may be called from several
+ * host threads at once -- one per GPU, or several on one GPU; see INTEGRATION.md.) */
+int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, int D, double *out_host, void *stream);
+int stb_groups_wait(stb_groups_t *g);
 /* the same values through stored tables and the sorted gather whatever D is (stb_groups_aterms sums
  * inside the fill when D >= 2, which needs a set-up pass over the pairs on first use) */
 int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host);
@@ -178,8 +186,10 @@ size_t stb_samplea2_partition(const uint16_t **m);
  * i-th (abscissa, value) pair */
 /* samplea() keeps the device copy of the (n,t) pairs of its last call (sorted, 6 bytes a pair, plus
  * the tables' scratch) and reuses it when the next call brings the same pairs -- the reference's
- * callers resample a many times over unchanged counts; only T and bpar are refreshed.  This drops
- * the kept set (STB_SAMPLEA_CACHE=0 in the environment never keeps one). */
+ * callers resample a many times over unchanged counts; only T and bpar are refreshed.  The set is
+ * kept per calling thread (its device memory stays allocated until the thread's next samplea with
+ * other pairs, or this call) and recognised by a 64-bit hash of K, n, t and the shapes.  This drops
+ * the calling thread's kept set (STB_SAMPLEA_CACHE=0 in the environment never keeps one). */
 void stb_sampler_cache_clear(void);
 int stb_sampler_trace_count(void);
 int stb_sampler_trace_code(void);

@@ -116,6 +116,8 @@ def lib() -> C.CDLL:
     sig("stb_groups_free", None, [vp])
     sig("stb_groups_aterms", i, [vp, c_double_p, i, c_double_p])
     sig("stb_groups_aterms_tables", i, [vp, c_double_p, i, c_double_p])
+    sig("stb_groups_aterms_async", i, [vp, c_double_p, i, c_double_p, vp])
+    sig("stb_groups_wait", i, [vp])
     sig("stb_groups_update_restaurants", i, [vp, c_u32_p, c_double_p])
     sig("stb_groups_shape", i, [vp, c_int_p, C.POINTER(u64), C.POINTER(u), C.POINTER(u), c_int_p])
     sig("stb_sampler_cache_clear", None, [])

@@ -26,18 +26,21 @@ extern "C" const char *stb_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------
 // rand() guard (see stb_common.h)
 
-static std::recursive_mutex g_rand_mu;
+// The lock covers only the count and the hand-over of the state: entry points of different threads run
+// side by side (one host thread per GPU, or two threads on one GPU, overlap their device work), the
+// caller's state goes away with the first one in and comes back with the last one out.
+static std::mutex g_rand_mu;
 static int g_rand_depth = 0;
 static char g_rand_buf[128];
 static char *g_rand_old = nullptr;
 
 stb_rand_guard::stb_rand_guard() {
-  g_rand_mu.lock();
+  std::lock_guard<std::mutex> lk(g_rand_mu);
   if (g_rand_depth++ == 0) g_rand_old = initstate(0x5eedu, g_rand_buf, sizeof g_rand_buf);
 }
 stb_rand_guard::~stb_rand_guard() {
+  std::lock_guard<std::mutex> lk(g_rand_mu);
   if (--g_rand_depth == 0 && g_rand_old) setstate(g_rand_old);
-  g_rand_mu.unlock();
 }
 
 // ------------------------------------------------------------------------------------------------

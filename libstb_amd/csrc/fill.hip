@@ -202,14 +202,8 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
 // the fill
 
 // what the last fill of this thread was, so that stb_fill_status can wait for it, report a chain
-// form that gave up, and repeat the fill with the producer/consumer form
-struct last_fill {
-  unsigned *hdr = nullptr;  // chain header (ticket, error code, error detail), or null
-  fill_args A;
-  int D = 0;
-  bool s_table = false, can_fall_back = false;
-  hipStream_t st = nullptr;
-};
+// form that gave up, and repeat the fill with the producer/consumer form (struct in stb_common.h: an
+// object that queues a fill and checks it later, possibly after other fills, keeps a copy)
 static thread_local last_fill g_last;
 static thread_local unsigned g_fallbacks = 0;
 static thread_local const dot_request *g_dot_req = nullptr;
@@ -228,26 +222,35 @@ static void pc_geometry(fill_args &A) {
   A.Wv = 256 - A.H;
 }
 
-extern "C" int stb_fill_status(void) {
-  STB_ENTRY;
-  if (!g_last.hdr) return 0;
+void stb_fill_last(last_fill *out) { *out = g_last; }
+
+// Waits for the fill on ITS stream (a copy on the null stream does not wait for a non-blocking stream,
+// and torch's side streams are non-blocking), reads the header, and on a give-up repeats the fill with
+// the form that has no waits between workgroups.
+int stb_fill_status_of(last_fill *lf) {
+  if (!lf->hdr) return 0;
   unsigned h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpy(h, g_last.hdr, sizeof(h), hipMemcpyDeviceToHost));  // waits for the fill
+  HIPCHK(hipMemcpyAsync(h, lf->hdr, sizeof(h), hipMemcpyDeviceToHost, lf->st));
+  HIPCHK(hipStreamSynchronize(lf->st));
   if (h[1] == 0) return 0;
-  stb_fail("%s: chain fill gave up waiting for a neighbour block (code 0x%x, block %u of table %u)",
-           g_last.s_table ? "stb_fill_S" : "stb_fill_V", h[1], h[2] & 0xffffu, h[2] >> 16);
-  if (!g_last.can_fall_back || stb_env_int("STB_CHAIN_NO_FALLBACK", 0)) {
-    g_last.hdr = nullptr;
+  stb_fail("%s: the fill gave up waiting for a neighbour block (code 0x%x, block %u of table %u)",
+           lf->s_table ? "stb_fill_S" : "stb_fill_V", h[1], h[2] & 0xffffu, h[2] >> 16);
+  if (!lf->can_fall_back || stb_env_int("STB_CHAIN_NO_FALLBACK", 0)) {
+    lf->hdr = nullptr;
     return 1;
   }
-  // the same tables once more with the form that has no waits between workgroups
-  g_last.hdr = nullptr;
+  lf->hdr = nullptr;
   g_fallbacks++;
-  fill_args A = g_last.A;
+  fill_args A = lf->A;
   pc_geometry(A);
-  if (stb_launch_pc(A, g_last.D, g_last.st)) return 1;
-  HIPCHK(hipStreamSynchronize(g_last.st));
+  if (stb_launch_pc(A, lf->D, lf->st)) return 1;
+  HIPCHK(hipStreamSynchronize(lf->st));
   return 0;
+}
+
+extern "C" int stb_fill_status(void) {
+  STB_ENTRY;
+  return stb_fill_status_of(&g_last);
 }
 
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables, uint64_t table_stride,
@@ -290,6 +293,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       unsigned *hdr = nullptr;
       if (stb_launch_vchain(A, D, ws, ws_left, &hdr, st)) return 1;
       g_last.hdr = hdr;
+      g_last.st = st;
       g_last.s_table = false;
       g_last.can_fall_back = false;
       return 0;
@@ -349,6 +353,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
       unsigned *hdr = nullptr;
       if (stb_ablation_fill(A, D, variant, ws, ws_left, &hdr, st)) return 1;
       g_last.hdr = hdr;
+      g_last.st = st;
       g_last.s_table = true;
       g_last.can_fall_back = false;
       return 0;

@@ -41,6 +41,14 @@ struct stb_groups {
   unsigned *d_ent_cnt;
   unsigned nsg;
   int sparse;
+  // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
+  double *h_out;  // pinned, [2][Dmax]: what the stream copies the sums to
+  hipEvent_t ev_dep;
+  int pending, pend_D, pend_fuse, pend_v;
+  unsigned pend_fb0;
+  double *pend_out;
+  double pend_x[STB_TERMS_DMAX];
+  last_fill pend_fill;
 };
 
 // The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
@@ -108,6 +116,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                   g->d_item_ptr, g->d_ent_pos, g->d_ent_cnt};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
+  stb_pool_free(g->h_out);
+  if (g->ev_dep) (void)hipEventDestroy(g->ev_dep);
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   if (g->st) (void)hipStreamDestroy(g->st);
@@ -187,6 +197,8 @@ static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, 
   GCHK(stb_pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * Dmax));
   GCHK(stb_pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)N * Dmax));
   GCHK(stb_pool_malloc((void **)&g->d_out, sizeof(double) * 2 * Dmax));
+  GCHK(stb_pool_malloc((void **)&g->h_out, sizeof(double) * 2 * Dmax, 1));
+  GCHK(hipEventCreateWithFlags(&g->ev_dep, hipEventDisableTiming));
   g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
   g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
   g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
@@ -455,12 +467,12 @@ static int groups_fused_setup(stb_groups_t *g) {
   return 0;
 }
 
-// one evaluation; returns 0, 1 (error) or 2 (the fused chain fill gave up waiting: the caller
-// repeats the evaluation through stored tables)
-static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v,
-                       float *ms_fill, float *ms_sweep, float *ms_terms) {
-  double h[2 * STB_TERMS_DMAX];
-  const unsigned fb0 = stb_fill_fallbacks();
+// one evaluation in two halves: queue everything on the set's stream, the sums ending in pinned host
+// memory; then wait, check the fill and hand the values over.  aterms_finish returns 0, 1 (error) or 2
+// (the fused chain fill gave up waiting: the caller repeats the evaluation through stored tables).
+static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v) {
+  g->pending = 0;
+  g->pend_fb0 = stb_fill_fallbacks();
   HIPCHK(hipEventRecord(g->ev[0], g->st));
   if (fuse) {
     // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
@@ -480,6 +492,7 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
                               g->ws_fill, STB_FILL_CHAIN, g->st);
     stb_set_dot_request(nullptr);
     if (rc) return 1;
+    stb_fill_last(&g->pend_fill);
     if ((size_t)D * req.parts_per_table > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
     HIPCHK(hipEventRecord(g->ev[1], g->st));
     if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
@@ -490,6 +503,7 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
     if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
                    g->ws_fill, v, g->st))
       return 1;
+    stb_fill_last(&g->pend_fill);
     HIPCHK(hipEventRecord(g->ev[1], g->st));
     if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
                     g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
@@ -500,41 +514,106 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
                            g->d_ws_terms, g->ws_terms, g->st))
     return 1;
   HIPCHK(hipEventRecord(g->ev[3], g->st));
-  HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * 2 * g->Dmax, hipMemcpyDeviceToHost, g->st));
+  HIPCHK(hipMemcpyAsync(g->h_out, g->d_out, sizeof(double) * 2 * g->Dmax, hipMemcpyDeviceToHost, g->st));
+  g->pending = 1;
+  g->pend_D = D;
+  g->pend_fuse = fuse ? 1 : 0;
+  g->pend_v = v;
+  g->pend_out = out_host;
+  memcpy(g->pend_x, x_host, sizeof(double) * D);
+  return 0;
+}
+
+static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float *ms_terms) {
+  if (!g->pending) return stb_fail("stb_groups_wait: nothing queued");
+  g->pending = 0;
+  const int D = g->pend_D;
   HIPCHK(hipStreamSynchronize(g->st));
-  if (stb_fill_status()) return fuse ? 2 : 1;
-  if (stb_fill_fallbacks() != fb0) {
-    // the chain fill gave up and stb_fill_status refilled the tables with the producer/consumer
-    // form: the sum above read unfinished tables, take it again
+  if (stb_fill_status_of(&g->pend_fill)) return g->pend_fuse ? 2 : 1;
+  if (stb_fill_fallbacks() != g->pend_fb0) {
+    // the one-launch fill gave up and was repeated with the producer/consumer form: the sum above
+    // read unfinished tables, take it again
     if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
                     g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
       return 1;
-    HIPCHK(hipMemcpyAsync(h, g->d_out, sizeof(double) * g->Dmax, hipMemcpyDeviceToHost, g->st));
+    HIPCHK(hipMemcpyAsync(g->h_out, g->d_out, sizeof(double) * g->Dmax, hipMemcpyDeviceToHost, g->st));
     HIPCHK(hipStreamSynchronize(g->st));
   }
-  for (int d = 0; d < D; d++) out_host[d] = h[g->Dmax + d] + h[d];
+  for (int d = 0; d < D; d++) g->pend_out[d] = g->h_out[g->Dmax + d] + g->h_out[d];
   if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
   if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));
   if (ms_terms) HIPCHK(hipEventElapsedTime(ms_terms, g->ev[2], g->ev[3]));
   return 0;
 }
 
-static int groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host, bool allow_fuse, float *ms_fill,
-                         float *ms_sweep, float *ms_terms) {
+static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v,
+                       float *ms_fill, float *ms_sweep, float *ms_terms) {
+  if (aterms_issue(g, x_host, D, out_host, fuse, v)) return 1;
+  return aterms_finish(g, ms_fill, ms_sweep, ms_terms);
+}
+
+// which form an evaluation of D discounts takes, with the one-off set-up of the fused form done
+static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_out, int *v_out) {
   if (!g) return stb_fail("stb_groups_aterms: null group set");
   if (D < 1 || D > g->Dmax) return stb_fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
-  const int prev_dev = stb_device_enter(g->dev);
+  if (g->pending) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int v = stb_default_variant();
   // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
   const bool fuse = allow_fuse && g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
-  int rc = 0;
   if (fuse && !g->fused_ready) {
-    if (stb_env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) rc = 1;
-    if (!rc && !g->fused_ready && groups_fused_setup(g)) rc = 1;
+    if (stb_env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) return 1;
+    if (!g->fused_ready && groups_fused_setup(g)) return 1;
   }
+  *fuse_out = fuse;
+  *v_out = v;
+  return 0;
+}
+
+static int groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_host, bool allow_fuse, float *ms_fill,
+                         float *ms_sweep, float *ms_terms) {
+  if (!g) return stb_fail("stb_groups_aterms: null group set");
+  const int prev_dev = stb_device_enter(g->dev);
+  bool fuse = false;
+  int v = 0;
+  int rc = aterms_prepare(g, D, allow_fuse, &fuse, &v);
   if (!rc) rc = aterms_once(g, x_host, D, out_host, fuse, v, ms_fill, ms_sweep, ms_terms);
   if (rc == 2)  // no waits between workgroups in this form
     rc = aterms_once(g, x_host, D, out_host, false, STB_FILL_PC, ms_fill, ms_sweep, ms_terms) ? 1 : 0;
+  stb_device_leave(prev_dev);
+  return rc;
+}
+
+// The same evaluation in two calls, so that one host thread can keep several GPUs (or several group
+// sets) busy: _async queues it on the set's own stream -- behind whatever `stream` holds at this moment,
+// when `stream` is not NULL -- and returns; stb_groups_wait blocks until it is through and only then
+// writes out_host[0..D-1].  x_host may be reused at once; out_host must stay valid until the wait.
+// One evaluation per set at a time.
+extern "C" int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, int D, double *out_host, void *stream) {
+  STB_ENTRY;
+  if (!g) return stb_fail("stb_groups_aterms_async: null group set");
+  const int prev_dev = stb_device_enter(g->dev);
+  bool fuse = false;
+  int v = 0;
+  int rc = aterms_prepare(g, D, true, &fuse, &v);
+  if (!rc && stream) {
+    if (hipEventRecord(g->ev_dep, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(g->st, g->ev_dep, 0) != hipSuccess)
+      rc = stb_fail("stb_groups_aterms_async: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (!rc) rc = aterms_issue(g, x_host, D, out_host, fuse, v);
+  stb_device_leave(prev_dev);
+  return rc;
+}
+
+extern "C" int stb_groups_wait(stb_groups_t *g) {
+  STB_ENTRY;
+  if (!g) return stb_fail("stb_groups_wait: null group set");
+  const int prev_dev = stb_device_enter(g->dev);
+  double *out = g->pend_out;
+  const int D = g->pend_D;
+  double x[STB_TERMS_DMAX];
+  memcpy(x, g->pend_x, sizeof(x));
+  int rc = aterms_finish(g, nullptr, nullptr, nullptr);
+  if (rc == 2) rc = aterms_once(g, x, D, out, false, STB_FILL_PC, nullptr, nullptr, nullptr) ? 1 : 0;
   stb_device_leave(prev_dev);
   return rc;
 }

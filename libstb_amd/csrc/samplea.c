@@ -58,7 +58,7 @@ static double aterms(double x, void *vp) {
  * that change slowly or not at all, and uploading and sorting 10^6 pairs costs as much as four
  * posterior evaluations.  Kept only while the next call brings exactly the same pairs (64-bit hash
  * of K, n, t plus the shapes); T and bpar are refreshed on every call. */
-static struct {
+static _Thread_local struct { /* (one per calling thread: samplers of different threads do not share a set) */
   stb_groups_t *dev;
   uint64_t hash;
   int I;

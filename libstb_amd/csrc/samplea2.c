@@ -62,8 +62,8 @@ static int use_slice2(void) {
 /* the table sizes the most recent samplea2 call sampled, in the reference's layout (for every pair
  * with 1 < t < n, in (i,k) order, t-1 entries: m[M-1] = customers at the M-th table instantiated);
  * kept for tests and callers that want the partition */
-static stcnt_int *last_m;
-static size_t last_m_count;
+static _Thread_local stcnt_int *last_m; /* (of the calling thread's last samplea2) */
+static _Thread_local size_t last_m_count;
 size_t stb_samplea2_partition(const stcnt_int **m) {
   if (m) *m = last_m;
   return last_m_count;

@@ -3,8 +3,9 @@
 #include "sampler_trace.h"
 
 #define CAP 1024
-static double xs[CAP], ys[CAP];
-static int count = 0, code = 0;
+/* (per calling thread: samplea / sampleb of two threads keep separate records) */
+static _Thread_local double xs[CAP], ys[CAP];
+static _Thread_local int count = 0, code = 0;
 
 void stb_trace_reset(void) {
   count = 0;

@@ -340,16 +340,18 @@ static int build(stable_t *sp, double a, unsigned N, unsigned M) {
     if (stb_fill_S(&a, 1, N, M, im->d_S, im->d_S_elems, im->d_S1, N, im->d_ws, im->ws_bytes,
                    stb_default_variant(), NULL))
       return 1;
+    /* waits for the fill and, if a one-launch form gave up, repeats it in the other form: only then
+     * may anything read the table (the narrowing below included) */
+    if (stb_fill_status()) return 1;
     /* all arithmetic was done in double (as lib/stable.c:389-449 does through its frontier
      * vectors); only the stored values are narrowed, on the device */
     if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
-    if (stb_fill_status()) return 1; /* (waits for the fill; repeats it in the other form if it gave up) */
   }
   if (sp->flags & S_UVTABLE) {
     if (stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL)) return 1;
+    if (stb_fill_status()) return 1; /* before anything reads it or a later fill reuses the workspace and its header */
     if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
-    if (stb_fill_status()) return 1; /* before any later fill reuses the workspace and its header */
   }
   if (!(sp->flags & S_STABLE)) {
     /* U/V-only tables still keep S1 (lib/stable.c:155, :337-348): take it from a width-2 S fill

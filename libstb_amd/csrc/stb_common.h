@@ -44,9 +44,11 @@ int stb_fail(const char *fmt, ...);  // records the message for stb_last_error()
 // consume (reference lib/arms.c:913-918).  Every entry point that can reach the runtime runs with
 // rand()'s state swapped to a private buffer (glibc: rand() and random() share the state that
 // initstate/setstate switch) and puts the caller's state back on exit.  That state is one per
-// process, so the swap is too: entry points nest and may come from several threads, hence one
-// recursive lock, a depth count, and a buffer that is not on anybody's stack; the state changes
-// hands only at depth 0 <-> 1.
+// process, so the swap is too: entry points nest and come from several threads at once, hence a
+// depth count under a lock that is held for the count only -- NOT for the call -- and a buffer that
+// is not on anybody's stack; the state changes hands at depth 0 <-> 1.  (A thread of the caller that
+// draws from rand() while another is inside the library draws from the private state: libc's rand()
+// has one state per process, and the reference's samplers are single-threaded for the same reason.)
 struct stb_rand_guard {
   stb_rand_guard();
   ~stb_rand_guard();
@@ -90,6 +92,18 @@ struct fill_args {
   int H;              // halo columns (>= R, multiple of C)
   int Wv;             // owned columns per strip = 64*C - H
 };
+
+// what a fill left behind to be checked: the header of a one-launch form (null for the forms that
+// cannot give up), and what is needed to repeat the fill with k_fill_pc
+struct last_fill {
+  unsigned *hdr = nullptr;  // [0] ticket, [1] error code, [2] error detail
+  fill_args A;
+  int D = 0;
+  bool s_table = false, can_fall_back = false;
+  hipStream_t st = nullptr;
+};
+void stb_fill_last(last_fill *out);       // the calling thread's last fill
+int stb_fill_status_of(last_fill *lf);    // waits for it on its stream; 0, or 1 with stb_last_error() set
 
 // per-launch timing (fill.hip): when armed, a launch gets a begin/end event pair
 void stb_prof_events(hipEvent_t *e0, hipEvent_t *e1);

@@ -119,6 +119,25 @@ def test_ck_gives_up_instead_of_hanging(monkeypatch):
     assert orc.max_err(T.packed_host(0), tab) <= TOL
 
 
+def test_float_table_after_a_fill_that_gave_up(monkeypatch):
+    """S_FLOAT through S_make when the one-launch fill gives up (bound on its waits set to zero): the
+    float slab must be narrowed from the table the producer/consumer form rebuilt, not from what the
+    aborted fill left behind (the narrowing is queued only after the status check)"""
+    L = capi.lib()
+    N, M, a = 1500, 1400, 0.45
+    S1, tab = orc.fill_S(a, N, M)
+    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    before = L.stb_fill_fallbacks()
+    t = capi.Table(N, M, N, M, a, capi.S_STABLE | capi.S_FLOAT)
+    assert L.stb_fill_fallbacks() == before + 1          # the chain form did give up and was replaced
+    for n, m in ((3, 2), (100, 57), (700, 699), (1499, 1000), (1500, 1399), (1500, 2)):
+        want = tab[orc.row_offset(n, M) + m - 2]
+        got = t.S(n, m)
+        assert got == float(np.float32(got))             # stored as float
+        assert abs(got - want) <= 2e-7 * max(1.0, abs(want)), (n, m, got, want)
+    t.free()
+
+
 @pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_CK])
 def test_10000_full_table_vs_oracle(variant):
     """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's

@@ -252,7 +252,7 @@ def test_concurrent_readers_while_the_table_grows():
     readers to it.  Two reader threads hammer cells inside the initial bounds (and whatever has been
     published since) while the main thread makes the table grow step by step; every value read must
     equal the oracle's, and the rand() stream of the process must come out untouched by the HIP
-    runtime calls the threads make (the guard is one process-wide lock)."""
+    runtime calls the threads make (the guard swaps the state at depth 0 <-> 1, see csrc/abi.hip)."""
     import ctypes as C
     import threading
     import time

@@ -1,0 +1,104 @@
+"""The C ABI from several host threads, and the two-call (queue / wait) form of the grid evaluation.
+
+The reference's callers (hca/tca) are single C processes (lib/samplea.c:155, lib/srng.h:4-6); a
+one-process multi-GPU caller drives each GPU from its own host thread, or all of them from one
+thread through stb_groups_aterms_async / stb_groups_wait.  Entry points must therefore (i) overlap
+across threads -- the guard around libc's rand() state (lib/arms.c:913-918 draws from it) may not
+serialise them -- and (ii) leave the caller's rand() stream untouched."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_set(L, g, N, M, Dmax):
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, Dmax)
+    assert h, capi.last_error()
+    return h
+
+
+def test_two_host_threads_on_one_gpu_overlap_and_leave_rand_alone():
+    """two threads, each with its own group set on the same GPU, each evaluating a 2-discount aterms
+    grid over and over: together they must take clearly less than one after the other (the evaluation
+    of one set leaves most of the chip idle), and rand() must continue as if nothing had happened"""
+    L = capi.lib()
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    libc.srand(777)
+    want_rand = [libc.rand() for _ in range(4)]
+    N = M = 3000
+    sets, xs, outs = [], [], []
+    for k in range(2):
+        g = synth.groups(200, 1000, N, "wide", seed=synth.SEED + k)
+        sets.append(make_set(L, g, N, M, 2))
+        xs.append(np.array([0.31 + 0.2 * k, 0.62 + 0.1 * k]))
+        outs.append(np.zeros(2))
+    ref = []
+    for k in range(2):                       # first use: one-off set-up of the fused form, module loads
+        capi.check(L.stb_groups_aterms(sets[k], capi.dp(xs[k]), 2, capi.dp(outs[k])))
+        ref.append(outs[k].copy())
+    reps = 60
+
+    def work(k):
+        for _ in range(reps):
+            capi.check(L.stb_groups_aterms(sets[k], capi.dp(xs[k]), 2, capi.dp(outs[k])))
+
+    libc.srand(777)
+    best_serial, best_par = 1e9, 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        work(0)
+        work(1)
+        best_serial = min(best_serial, time.perf_counter() - t0)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        best_par = min(best_par, time.perf_counter() - t0)
+    for k in range(2):
+        assert np.array_equal(outs[k], ref[k])            # same bits whoever else was running
+        L.stb_groups_free(sets[k])
+    assert [libc.rand() for _ in range(4)] == want_rand
+    assert best_par < 0.75 * best_serial, (best_par, best_serial)
+
+
+def test_async_then_wait_equals_the_blocking_call():
+    """one host thread, two group sets: both evaluations queued before either is waited for; the
+    values equal the blocking call's to the last bit, x may be reused at once, a second queue on a
+    busy set is refused, and a caller's stream is honoured as a dependency"""
+    import torch
+
+    L = capi.lib()
+    N = M = 2500
+    gs = [synth.groups(100, 1000, N, "wide", seed=synth.SEED + 7 + k) for k in range(2)]
+    hs = [make_set(L, g, N, M, 8) for g in gs]
+    grid = np.ascontiguousarray(synth.discount_grid(64)[8:16])
+    want = []
+    for h in hs:
+        o = np.zeros(8)
+        capi.check(L.stb_groups_aterms(h, capi.dp(grid), 8, capi.dp(o)))
+        want.append(o)
+    outs = [np.full(8, np.nan) for _ in hs]
+    side = torch.cuda.Stream()
+    x = grid.copy()
+    capi.check(L.stb_groups_aterms_async(hs[0], capi.dp(x), 8, capi.dp(outs[0]), None))
+    capi.check(L.stb_groups_aterms_async(hs[1], capi.dp(x), 8, capi.dp(outs[1]), C.c_void_p(side.cuda_stream)))
+    x[:] = 0.5                                             # the abscissae were copied at queue time
+    assert L.stb_groups_aterms_async(hs[0], capi.dp(grid), 8, capi.dp(outs[0]), None) != 0
+    assert b"not been waited for" in L.stb_last_error()
+    capi.check(L.stb_groups_wait(hs[1]))
+    capi.check(L.stb_groups_wait(hs[0]))
+    assert L.stb_groups_wait(hs[0]) != 0                   # nothing queued any more
+    for o, w in zip(outs, want):
+        assert np.array_equal(o, w)
+    for h in hs:
+        L.stb_groups_free(h)
