@@ -103,7 +103,9 @@ def test_10000_config2_vs_golden(golden_dir, a):
         rowsum[n] = np.sum(r)
         absmax[n] = (n - 2) * max(1.0, np.max(np.abs(r)))
     want = z[key + "_rowsum"]
-    assert np.all(np.abs(rowsum - want) <= TOL * np.maximum(absmax, 1.0))
+    # (every cell is also compared at 1e-10 in tests/test_gpu_fill_ck.py::test_10000_full_table_vs_oracle;
+    # here the bar on a row's sum is 1e-12 of n * max|row|, which a single cell off by 1e-7 relative breaks)
+    assert np.all(np.abs(rowsum - want) <= 1e-12 * np.maximum(absmax, 1.0))
     for n in (N // 3, N):
         o = T.rowoff(n)
         assert orc.close(t[o:o + n - 2], z[key + f"_row{n}"], TOL)
@@ -127,7 +129,7 @@ def _check_against_grid_fixture(T, dl, d, z, probes):
         rowsum[n] = np.sum(r)
         absmax[n] = (n - 2) * max(1.0, np.max(np.abs(r)))
     assert np.all(np.isfinite(rowsum))
-    assert np.all(np.abs(rowsum - z[f"d{d}_rowsum"]) <= TOL * np.maximum(absmax, 1.0)), d
+    assert np.all(np.abs(rowsum - z[f"d{d}_rowsum"]) <= 1e-12 * np.maximum(absmax, 1.0)), d
     for n in (N // 3, N):
         o = T.rowoff(n)
         assert orc.close(t[o:o + n - 2], z[f"d{d}_row{n}"], TOL), (d, n)

@@ -76,6 +76,61 @@ def test_samplea_vs_reference(golden_dir, rec_index):
     assert abs(got - fh(rec["a_out"])) <= 1e-6 * abs(fh(rec["a_out"]))
 
 
+@pytest.mark.parametrize("rec_index", range(11))
+def test_device_aterms_at_every_recorded_abscissa(golden_dir, rec_index):
+    """the device posterior aterms (lib/samplea.c:46-83) at EVERY abscissa the reference's ARMS visited in
+    the recorded run -- not only the three starting points that both runs share -- against the value the
+    reference computed there, at the parity bar 1e-10 (one discount at a time through a stored table, as
+    samplea does, and all of them in one grid call through the fused fill)"""
+    L = capi.lib()
+    rec = load(golden_dir, "samplers.json")["samplea"][rec_index]
+    g = synth.groups(*SETS[rec["set"]])
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    M = max(int(g.t.max()) + 1, 10)             # the table samplea builds (lib/samplea.c:60, lib/stable.c:118-129)
+    N = max(int(g.n.max()) + 1, M)
+    D = len(want_x)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
+    assert h, capi.last_error()
+    try:
+        one = np.zeros(1)
+        single = np.zeros(D)
+        for d in range(D):
+            capi.check(L.stb_groups_aterms(h, capi.dp(want_x[d:d + 1].copy()), 1, capi.dp(one)))
+            single[d] = one[0]
+        assert orc.close(single, want_y, 1e-10), orc.max_err(single, want_y)
+        if D >= 2:
+            grid = np.zeros(D)
+            capi.check(L.stb_groups_aterms(h, capi.dp(np.ascontiguousarray(want_x)), D, capi.dp(grid)))
+            assert orc.close(grid, want_y, 1e-10), orc.max_err(grid, want_y)
+    finally:
+        L.stb_groups_free(h)
+
+
+@pytest.mark.parametrize("rec_index", range(20))
+def test_device_bterms_at_every_recorded_abscissa(golden_dir, rec_index):
+    """the device posterior bterms (lib/sampleb.c:33-41) at every abscissa of the recorded run against the
+    reference's value, 1e-10.  Q = 1/scale - sum log Beta(b, N_i) (lib/sampleb.c:90-100) is drawn here as
+    sampleb draws it, from the same rand48 stream through the library's own (bit-identical) generator."""
+    L = capi.lib()
+    rec = load(golden_dir, "samplers.json")["sampleb"][rec_index]
+    apar = fh(rec["apar"])
+    if apar == 0.0:
+        pytest.skip("a = 0: sampleb draws b from a Gamma directly, no posterior is evaluated")
+    g = synth.groups(*SETS[rec["set"]])
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    orc.seed_libc(777, 12345)
+    Q = 1.0 / g.scale
+    b_in = fh(rec["b_in"])
+    for i in range(g.I):
+        if g.N[i] > 0:
+            Q -= float(np.log(L.gsl_rng_beta(b_in, float(int(g.N[i])))))
+    dg = capi.DeviceGroups(g)
+    got = capi.bterms(np.ascontiguousarray(want_x), Q, g.shape, apar, dg).cpu().numpy()
+    assert orc.close(got, want_y, 1e-10), orc.max_err(got, want_y)
+
+
 def test_samplea_keeps_the_pairs_between_calls(monkeypatch):
     """samplea keeps the sorted device copy of the (n,t) pairs while the next call brings the same
     pairs, refreshing T and bpar; a changed pair, shape or STB_SAMPLEA_CACHE=0 builds a new set.  The
