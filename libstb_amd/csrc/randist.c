@@ -14,7 +14,7 @@
  * f(x_i) = f(x_{i+1}) + v / x_{i+1}, and R is THE value for which the recursion closes at
  * f(x_0) = 1.  The published tables hold f(x_i), 2^-24 x_{i+1} and floor(2^24 x_i / x_{i+1})
  * printed to 12 significant digits, so computing them in long double and rounding the same way
- * reproduces them exactly (tests/test_host_rng.py checks all 384 numbers against the reference's
+ * reproduces them exactly (tests/test_host_logic.py checks all 384 numbers against the reference's
  * file when it is present, and the variate streams against golden draws everywhere).
  */
 #include <math.h>

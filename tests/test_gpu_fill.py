@@ -21,11 +21,9 @@ def test_library_sees_gpu():
     assert L.stb_device_count() >= 1, capi.last_error()
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
 def test_small_tables_batched_vs_golden(golden_dir, variant):
     """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
-    if not capi.has_variant(variant):
-        pytest.skip("superseded form: needs `make ABLATION=1`")
     z = np.load(os.path.join(golden_dir, "stable_200x50.npz"))
     keys = ["a0.5", "a0.125", "a0.05", "a0.95", "a2_3"]
     a = np.array([float(z[k + "_a"][0]) for k in keys])
@@ -38,13 +36,11 @@ def test_small_tables_batched_vs_golden(golden_dir, variant):
         assert orc.close(T.S1[d].cpu().numpy(), z[k + "_S1"], TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
 @pytest.mark.parametrize("N,M", [(2, 2), (3, 2), (3, 3), (10, 10), (64, 64), (65, 33), (97, 96), (130, 129), (500, 7),
                                  (1000, 1000), (1500, 260)])
 def test_ragged_shapes_vs_oracle(N, M, variant):
     """edge shapes: tiny, one strip / several strips, diagonal inside a strip, M << N"""
-    if not capi.has_variant(variant):
-        pytest.skip("superseded form: needs `make ABLATION=1`")
     a = np.array([0.31, 0.77])
     T = capi.DeviceTables(N, M, D=2)
     T.fill(a, variant)
@@ -67,11 +63,9 @@ def test_tunings_agree(monkeypatch, C, R):
     assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_SCALED_STEP, capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
 @pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
 def test_4000_full_table_vs_oracle(golden_dir, a, variant):
-    if not capi.has_variant(variant):
-        pytest.skip("superseded form: needs `make ABLATION=1`")
     N = 4000
     T = capi.DeviceTables(N, N, D=1)
     T.fill([a], variant)
@@ -218,13 +212,11 @@ def test_v_table_big_vs_oracle():
     assert np.array_equal(T.packed_host(0), want)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SPLIT, capi.FILL_FUSED, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CHAINX, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
 @pytest.mark.parametrize("a", [0.0, 0.01, 0.07, 0.5, 0.98])
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the
     renormalisation period must be sized for that, at every discount, with the longest launches"""
-    if not capi.has_variant(variant):
-        pytest.skip("superseded form: needs `make ABLATION=1`")
     monkeypatch.setenv("STB_FILL_R", "120")
     monkeypatch.setenv("STB_FILL_C", "2")
     N = 6000
@@ -273,26 +265,6 @@ def test_chain_more_blocks_than_fit_at_once():
     T2.fill(a, capi.FILL_PC)
     for d in (0, 7, D - 1):
         assert orc.max_err(T.packed_host(d), T2.packed_host(d)) <= TOL
-
-
-@pytest.mark.parametrize("P", [1, 2, 4])
-@pytest.mark.parametrize("N,M", [(900, 700), (2500, 2500), (3000, 130)])
-def test_chainx_geometries_agree(monkeypatch, P, N, M):
-    """chain form with converter blocks: every producer-block width computes the same tables"""
-    if not capi.has_variant(capi.FILL_CHAINX):
-        pytest.skip("superseded form: needs `make ABLATION=1`")
-    monkeypatch.setenv("STB_CHAINX_P", str(P))
-    a = np.array([0.07, 0.6])
-    T = capi.DeviceTables(N, M, D=2)
-    T.tables.fill_(float("nan"))
-    T.fill(a, capi.FILL_CHAINX)
-    T.status()
-    for d in range(2):
-        S1, tab = orc.fill_S(a[d], N, M)
-        got = T.packed_host(d)
-        assert np.all(np.isfinite(got))
-        assert orc.close(got, tab, TOL), (d, orc.max_err(got, tab))
-        assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
 
 
 def test_chain_random_shapes_vs_oracle():
