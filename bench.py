@@ -14,12 +14,16 @@ is fixed as N grows (weak scaling); value = cells filled by all ranks per second
 One JSON line on stdout (rank 0):
   value / roofline   configs[1]; the roofline prices the fill kernel against HBM (8 B per stored cell,
                      SURVEY 8d), kernel time from per-launch HIP start/stop events inside bench.py
-  roofline_sweep     the second half of the metric: the (n,t) gather-sum kernel over 64 tables of
-                     N=M=10000 and 10^6 pairs, (8 + 6/D) B per grid-eval
-  extra.batch64      at EVERY --gpus N: the north-star job -- the 64-discount grid (0.05,0.95) sharded
+  roofline_sweep     the second half of the metric, as the product runs it for a grid of discounts: the
+                     fused evaluation (the fill sums count * log S for the occurring cells itself, no
+                     table stored) of 64 discounts x 10^6 pairs at N=M=10000, (8 + 6/D) B per grid-eval;
+                     the two-pass form (stored tables + gather) and the CPU sweep are in extra
+  scale_job          at EVERY --gpus N: the north-star job -- the 64-discount grid (0.05,0.95) sharded
                      64/N per rank: batched fill, and the fused grid aterms over 10^6 pairs whose 64
-                     log-posteriors are all-gathered over RCCL.  A 1 -> 8 GPU curve of these numbers
-                     is the strong-scaling speed-up the north star asks for.
+                     log-posteriors are all-gathered over RCCL; >= 50 steps each, medians of the first
+                     and of the last five (the part slows under sustained load).  A 1 -> 8 GPU curve of
+                     scale_job.fill.ms / scale_job.grid_aterms.ms is the strong-scaling speed-up the
+                     north star asks for (`value` is weak scaling of one table per GPU and is not).
   cpu_baseline       the reference's (or the oracle's) fill of the same table on this box's host CPU
 """
 from __future__ import annotations
@@ -40,7 +44,8 @@ import torch
 from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-TRAFFIC_DB = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+TRAFFIC_DB = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+FORM_NAMES = {2: "pc", 3: "chain", 4: "ck"}
 
 
 def cpu_baseline(N: int, M: int, a: float):
@@ -107,6 +112,46 @@ def cpu_baseline(N: int, M: int, a: float):
     if many is not None:
         out["multi_core"] = many
     return out
+
+
+def cpu_sweep_baseline(g, N: int, M: int):
+    """the sampler sweep on the host -- aterms' gather-sum and restaurant terms over the same
+    10^6 pairs against a table already filled (lib/samplea.c:62-80 without the rebuild), on one core and on
+    the one-GPU job's share of the cores with one discount's table per thread (the oracle's restatement)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
+
+    import orc
+
+    L = orc.oracle()
+    share = len(os.sched_getaffinity(0))
+    nthr = max(1, min(16, share))
+    grid = synth.discount_grid(64)[:nthr]
+    tabs = [orc.fill_S(float(a), N, M) for a in grid]          # (S1, packed table) per discount
+
+    def one(i):
+        S1, tab = tabs[i]
+        return L.orc_aterms_sum(float(grid[i]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
+                                orc.dp(tab), orc.dp(S1), N, M)
+
+    best1 = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one(0)
+        best1 = min(best1, time.perf_counter() - t0)
+    bestn = 1e30
+    for _ in range(3):
+        th = [threading.Thread(target=one, args=(i,)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        bestn = min(bestn, time.perf_counter() - t0)
+    return {"kind": "port", "pairs": g.pairs, "N": N, "M": M,
+            "one_core": {"grid_evals_per_s": g.pairs / best1, "seconds": best1, "cores": 1},
+            "all_cores": {"grid_evals_per_s": g.pairs * nthr / bestn, "seconds": bestn, "cores": nthr, "discounts": nthr},
+            "sample": "orc_aterms_sum (gather-sum + restaurant terms, table already filled) over the same pairs, best of 3"}
 
 
 def traffic_lookup(key: str, kernel_prefix: str):
@@ -234,7 +279,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sweep (grid-evals/s) sections")
     ap.add_argument("--no-batch64", action="store_true", help="skip the 64-discount sharded batch")
-    ap.add_argument("--batch-steps", type=int, default=5, help="timed steps of the 64-discount batch")
+    ap.add_argument("--batch-steps", type=int, default=50, help="timed steps of the 64-discount batch (scale_job)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -308,13 +353,15 @@ def main():
     # start/stop event pair on every fill launch.  Kept out of the timed region above because an
     # event-carrying launch costs ~5 us of host time; the device durations themselves are unaffected
     # (profiles/ agrees).
+    # ... and the status of EVERY one of these fills is checked (a fill that gave up and was silently repeated
+    # in another form would make a timing meaningless; the timed region above runs the same launches)
     L.stb_fill_profile_begin()
     for _ in range(args.steps):
         step()
+        must_be_clean("profiled steps", fb0)
     fence()
     kms, kn = C.c_double(0.0), C.c_int(0)
     capi.check(L.stb_fill_profile_end(C.byref(kms), C.byref(kn)))
-    must_be_clean("profiled steps", fb0)
 
     dt = shard.max_over_ranks(dt, dev, dist)
     total_cells = cells_rank * world * args.steps
@@ -339,13 +386,23 @@ def main():
             pr = T64.tables.index_select(1, pidx).reshape(-1)
             return shard.gather_scalars(pr, 64, dist)
 
+        def first_last(ms):
+            """median of the first five and of the last five steps, slowest rank"""
+            k = min(5, len(ms))
+            return (shard.max_over_ranks(float(np.median(ms[:k])), dev, dist), shard.max_over_ranks(float(np.median(ms[-k:])), dev, dist))
+
         step64()
         fence()
+        per_step = []
         t0 = time.perf_counter()
         for _ in range(args.batch_steps):
+            t1 = time.perf_counter()
             got = step64()
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - t1) * 1e3)
         fence()
         dt64 = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
+        fill_first, fill_last = first_last(per_step)
         must_be_clean("batch64 fill", fb0)
         L.stb_fill_profile_begin()
         step64()
@@ -366,27 +423,36 @@ def main():
         post = np.zeros(D64)
         capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))  # set-up + warm-up
         fence()
+        per_step = []
         t0 = time.perf_counter()
         for _ in range(args.batch_steps):
+            t1 = time.perf_counter()
             capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))
             allpost = shard.gather_scalars(torch.as_tensor(post, device=dev), 64, dist)
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - t1) * 1e3)
         fence()
         dtg = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
+        grid_first, grid_last = first_last(per_step)
         L.stb_groups_free(h)
         batch64 = {
             "discounts_total": 64, "discounts_per_gpu": D64, "ranks": world, "ranks_seen": ranks_seen,
-            "fill": {"ms": dt64 * 1e3, "cells_per_s": cells64 / dt64, "form": {2: "pc", 3: "chain"}.get(fT, str(fT)),
+            "steps": args.batch_steps,
+            "fill": {"ms": dt64 * 1e3, "ms_first5_median": fill_first, "ms_last5_median": fill_last,
+                     "cells_per_s": cells64 / dt64, "form": FORM_NAMES.get(fT, str(fT)),
                      "kernel_ms_sum": k64, "kernel_span_ms": span64, "launches": n64.value,
                      "frac_of_hbm_peak_per_gpu": (8.0 * cells64 / world / (span64 * 1e-3) / 1e9 / HBM_PEAK_GBS) if span64 > 0 else None},
-            "grid_aterms": {"ms": dtg * 1e3, "pairs": g.pairs, "N": Ng, "M": Mg, "grid_evals_per_s": 64 * g.pairs / dtg,
+            "grid_aterms": {"ms": dtg * 1e3, "ms_first5_median": grid_first, "ms_last5_median": grid_last, "pairs": g.pairs, "N": Ng, "M": Mg, "grid_evals_per_s": 64 * g.pairs / dtg,
                             "log_posteriors_finite": int(torch.isfinite(allpost).sum().item()),
                             "log_posterior_d0_d63": [float(allpost[0]), float(allpost[63])]},
-            "note": "strong scaling: the same 64 tables / 64 x 10^6 grid-evals at every --gpus N; speed-up(N) = ms(1) / ms(N)",
+            "note": "strong scaling: the same 64 tables / 64 x 10^6 grid-evals at every --gpus N; speed-up(N) = ms(1) / ms(N); "
+                    "ms = mean over all steps (slowest rank, barriers outside), first5 / last5 = medians of single steps",
         }
 
     if rank == 0:
         FORMS = {2: ("pc", "k_fill_pc", "k_fill_pc (producer wave + consumer waves per column block, launched per 128 rows)"),
-                 3: ("chain", "k_fill_chain", "k_fill_chain (one launch per fill: producer, consumer and fetcher waves per column block)")}
+                 3: ("chain", "k_fill_chain", "k_fill_chain (one launch per fill: producer, consumer and fetcher waves per column block)"),
+                 4: ("ck", "k_fill_ck", "k_fill_ck (one launch per fill: recurrence-only spine waves + tile workers)")}
         fname, kprefix, knote = FORMS.get(form if args.variant == capi.FILL_SCALED else -1, ("other", "k_fill", f"fill variant {args.variant}"))
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches
@@ -436,7 +502,7 @@ def main():
         }
         extra = {}
         if batch64 is not None:
-            extra["batch64"] = batch64
+            out["scale_job"] = batch64
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, M, float(mine[0]))
         if world == 1 and not args.no_extra:
@@ -444,23 +510,36 @@ def main():
                 s10k, _ = sweep_section(10000)
                 tp = s10k["D64"]["two_pass"]
                 fu = s10k["D64"]["fused"]
-                alg = tp["grid_evals"] * (8 + 6.0 / 64)
-                tr, tr_src = traffic_lookup("sweep_N10000_D64", "k_sweep_partial")
+                alg = fu["grid_evals"] * (8 + 6.0 / 64)
+                dev_ms = fu["fill_ms"] + fu["sweep_ms"] + fu["terms_ms"]
+                tr, tr_src = traffic_lookup("grid_N10000_D64", "k_fill_chain")
                 out["roofline_sweep"] = {
                     "metric": "sampler grid-evals/s", "bound": "hbm",
-                    "kernel": "k_sweep_partial (+ k_reduce_final): sum of S_S(n,t) over 10^6 sorted pairs x 64 stored tables of N=M=10000",
-                    "grid_evals": tp["grid_evals"], "device_ms": tp["sweep_ms"],
-                    "value": tp["grid_evals"] / (tp["sweep_ms"] * 1e-3), "unit": "grid-evals/s",
-                    "algorithmic_bytes": alg, "achieved": alg / (tp["sweep_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "frac": alg / (tp["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
-                    "end_to_end": {"two_pass_grid_evals_per_s": tp["grid_evals_per_s_end_to_end"],
-                                   "fused_grid_evals_per_s": fu["grid_evals_per_s_end_to_end"], "fused_wall_ms": fu["wall_ms"],
-                                   "note": "fused = the table is never stored: k_fill_chain sums count*log S for the occurring cells itself"},
+                    "kernel": "k_fill_chain<...,DOT>: the chain fill of 64 discounts at N=M=10000 summing count * log S over the "
+                              "occurring cells itself (no table stored), + the restaurant terms; what stb_groups_aterms runs for D >= 2",
+                    "grid_evals": fu["grid_evals"], "device_ms": dev_ms, "fill_ms": fu["fill_ms"],
+                    "value": fu["grid_evals"] / (dev_ms * 1e-3), "unit": "grid-evals/s",
+                    "algorithmic_bytes": alg, "achieved": alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "frac": alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
+                    "note": "not an HBM-bound kernel: its time is the recurrence's serial row chain (N rows x row time + one hand-off "
+                            "per column strip) and its traffic the edge streams and the cell lists, not the tables; see DESIGN.md",
+                    "end_to_end": {"fused_grid_evals_per_s": fu["grid_evals_per_s_end_to_end"], "fused_wall_ms": fu["wall_ms"],
+                                   "two_pass_grid_evals_per_s": tp["grid_evals_per_s_end_to_end"], "two_pass_wall_ms": tp["wall_ms"]},
                 }
+                atr, atr_src = traffic_lookup("sweep_N10000_D64", "k_sweep_partial")
+                extra["two_pass_sweep_N10000_D64"] = {
+                    "kernel": "k_sweep_partial (+ k_reduce_final): sum of S_S(n,t) over 10^6 sorted pairs x 64 STORED tables",
+                    "device_ms": tp["sweep_ms"], "grid_evals_per_s_sweep_only": tp["grid_evals"] / (tp["sweep_ms"] * 1e-3),
+                    "algorithmic_GBs": tp["grid_evals"] * (8 + 6.0 / 64) / (tp["sweep_ms"] * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": tp["grid_evals"] * (8 + 6.0 / 64) / (tp["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": atr, "traffic_source": atr_src,
+                    "note": "the form the product takes only when tables are wanted anyway (one discount, samplea's ARMS); each 8-byte gather moves a line"}
                 extra["sampler_sweep_N10000"] = s10k
                 s4k, g4k = sweep_section(4000)
                 extra["sampler_sweep"] = s4k
                 extra["sampler_sweep"].update(sampler_calls(g4k))
+                if not args.no_cpu_baseline:
+                    extra["sampler_sweep"]["cpu_sweep_baseline"] = cpu_sweep_baseline(g4k, s4k["N"], s4k["M"])
             except Exception as e:  # the extras must never take the contract line down
                 extra["sampler_error"] = repr(e)
         if extra:

@@ -50,6 +50,7 @@
 #define CK_NW 8        // waves per workgroup
 #define CK_EOFF32 (1u << 30)
 #define CK_MAXRB 16    // trips per block at most (worker edge buffer: 128 rows)
+#define CK_ORDER_LDS 8192  // tiles of a table whose order list is copied to LDS (32 KB)
 #ifndef CK_DIAG
 #define CK_DIAG 0      // diagnostic builds (results wrong): 1 no edge posts, 2 no left inputs, 4 no left counter, 8 no progress post
 #endif
@@ -163,12 +164,16 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
   // workers: the left inputs of a tile, per wave
   __shared__ __attribute__((aligned(16))) double w_le[CK_NW][CK_MAXRB * U];
   __shared__ int w_lee[CK_NW][CK_MAXRB];
+  __shared__ unsigned s_order[CK_ORDER_LDS];  // the tile order, when it fits (a ticket then costs no dependent global load)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
   for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
+  const bool order_in_lds = X.n_tiles <= CK_ORDER_LDS;
+  if (order_in_lds)
+    for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
   __syncthreads();
   const unsigned ticket = s_ticket;
   unsigned *cu_busy = nullptr;
@@ -575,7 +580,8 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
       k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
       if (k >= total) break;
       const int d = (int)(k % (unsigned)X.D);
-      const unsigned ord = X.order[k / (unsigned)X.D];
+      const unsigned oi = k / (unsigned)X.D;
+      const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane((int)(order_in_lds ? s_order[oi] : X.order[oi]));
       const int jw = (int)(ord & 0xffffu), b = (int)(ord >> 16);
       const int c0w = 2 + jw * WS;
       const int g0w = ck_first_trip(c0w);
@@ -585,19 +591,74 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
       unsigned long long *wdbg =
           (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)X.JW * (X.NBK + 2) + (size_t)(k / (unsigned)X.D) * 4 : nullptr;
       if (wdbg) wdbg[0] = wall_clock64();
-      // ---- wait until the spine has finished the block (a hint: the data below is its own flag) ----
+      // ---- the tile's inputs: left edges (rows 2 + 8 gs ..) and the checkpoint.  Everything is asked for at
+      // once, without looking at the spine's progress first: what has been written is non-zero.  Only when
+      // something is missing is the progress word read, to sleep about as long as the missing blocks take. ----
+      const size_t sleft = (size_t)d * (X.JW + 1) + jw;  // strip jw - 1 (+1: the virtual strip is index 0)
+      const unsigned long long *ev = X.edge_v + sleft * X.EV + 2 + gs * U;
+      const unsigned long long *ee = X.edge_e + sleft * X.NP + 1;
+      const bool fresh = (gs == g0w);  // the strip's first tile starts from the empty row
+      const unsigned long long *ckv = X.ck_v + (((size_t)d * X.JW + jw) * X.NBK + b) * (64 * C) + lane * C;
+      const unsigned *cke = X.ck_e + (((size_t)d * X.JW + jw) * X.NBK + b) * 64 + lane;
+      const unsigned *prog = X.progress + (size_t)d * X.JW + jw;
+      double v[C], coef[C];
+      int ep = 1 + PC_BIAS;
       bool ok = true;
       {
-        const unsigned *prog = X.progress + (size_t)d * X.JW + jw;
         unsigned spins = 0;
         unsigned long long t_begin = 0;
+        const bool two = nrows > 64;
+        const int k1 = 64 + lane;
+        const bool act0 = lane < nrows, act1 = two && k1 < nrows;
+        const int kc0 = act0 ? lane : 0, kc1 = act1 ? k1 : 0;
+        const int tc0 = gs + (kc0 >> 3), tc1 = gs + (kc1 >> 3);
         for (;;) {
-          const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (done >= (unsigned)(b + 1)) break;
+          const unsigned long long va0 = __hip_atomic_load(ev + kc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long e10 = __hip_atomic_load(ee + tc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long e00 = __hip_atomic_load(ee + tc0 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long va1 = 1, e11 = 1, e01 = 1, bv[C];
+          unsigned be = 1;
+          if (two) {
+            va1 = __hip_atomic_load(ev + kc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e11 = __hip_atomic_load(ee + tc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e01 = __hip_atomic_load(ee + tc1 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int i = 0; i < C; i++) bv[i] = 1;
+          if (!fresh) {
+#pragma unroll
+            for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(ckv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            be = __hip_atomic_load(cke, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          bool have = va0 != 0 && e10 != 0 && e00 != 0 && va1 != 0 && e11 != 0 && e01 != 0 && be != 0;
+#pragma unroll
+          for (int i = 0; i < C; i++) have = have && bv[i] != 0;
+          if (__all(have)) {
+            auto put = [&](bool act, int kc, unsigned long long va, unsigned long long e1, unsigned long long e0) {
+              if (!act) return;
+              const int ex = (int)(long long)(e1 - CH_EOFF);
+              double xa = __longlong_as_double((long long)va);
+              if ((kc & 7) == 0) {
+                xa = ldexp(xa, (int)(long long)(e0 - CH_EOFF) - ex);
+                lee[kc >> 3] = ex;
+              }
+              le[kc] = xa;
+            };
+            put(act0, kc0, va0, e10, e00);
+            put(act1, kc1, va1, e11, e01);
+            if (!fresh) {
+#pragma unroll
+              for (int i = 0; i < C; i++) v[i] = __longlong_as_double((long long)bv[i]);
+              ep = (int)(be - CK_EOFF32);
+            }
+            break;
+          }
           // Thousands of waves wait here while a table's first rows are walked, and every poll is a
           // request to the memory side that the spine's own hand-offs queue behind: sleep for about as
           // long as the blocks still missing take (a block: ~3 us), at most ~50 us, then look again.
-          const int missing = min((int)((unsigned)(b + 1) - done), 16);
+          const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int missing = (done >= (unsigned)(b + 1)) ? 0 : min((int)((unsigned)(b + 1) - done), 16);
+          if (missing == 0) __builtin_amdgcn_s_sleep(8);
           for (int i = 0; i < missing; i++) __builtin_amdgcn_s_sleep(100);
           if ((++spins & 3u) != 0 && X.timeout != 0) continue;
           if (t_begin == 0) t_begin = wall_clock64();
@@ -606,66 +667,6 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
             if (err == 0 && lane == 0) {
               __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ok = false;
-            break;
-          }
-        }
-      }
-      if (!ok) break;
-      // ---- the tile's inputs: left edges (rows 2 + 8 gs ..) and the checkpoint ----
-      const size_t sleft = (size_t)d * (X.JW + 1) + jw;  // strip jw - 1 (+1: the virtual strip is index 0)
-      const unsigned long long *ev = X.edge_v + sleft * X.EV + 2 + gs * U;
-      const unsigned long long *ee = X.edge_e + sleft * X.NP + 1;
-      const bool fresh = (gs == g0w);  // the strip's first tile starts from the empty row
-      const unsigned long long *ckv = X.ck_v + (((size_t)d * X.JW + jw) * X.NBK + b) * (64 * C) + lane * C;
-      const unsigned *cke = X.ck_e + (((size_t)d * X.JW + jw) * X.NBK + b) * 64 + lane;
-      double v[C], coef[C];
-      int ep = 1 + PC_BIAS;
-      {
-        unsigned spins = 0;
-        unsigned long long t_begin = 0;
-        for (;;) {
-          bool have = true;
-          for (int k0 = 0; k0 < nrows; k0 += 64) {
-            const int kk = k0 + lane;
-            const bool act = kk < nrows;
-            const int kc = act ? kk : 0;
-            const int tc = gs + (kc >> 3);
-            const unsigned long long va = __hip_atomic_load(ev + kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long e1 = __hip_atomic_load(ee + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long e0 = __hip_atomic_load(ee + tc - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            have = have && (va != 0 && e1 != 0 && e0 != 0);
-            if (act) {
-              const int ex = (int)(long long)(e1 - CH_EOFF);
-              double xa = __longlong_as_double((long long)va);
-              if ((kc & 7) == 0) {
-                xa = ldexp(xa, (int)(long long)(e0 - CH_EOFF) - ex);
-                lee[kc >> 3] = ex;
-              }
-              le[kc] = xa;
-            }
-          }
-          if (!fresh) {
-#pragma unroll
-            for (int i = 0; i < C; i++) {
-              const unsigned long long bv = __hip_atomic_load(ckv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              have = have && bv != 0;
-              v[i] = __longlong_as_double((long long)bv);
-            }
-            const unsigned be = __hip_atomic_load(cke, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            have = have && be != 0;
-            ep = (int)(be - CK_EOFF32);
-          }
-          if (__all(have)) break;
-          __builtin_amdgcn_s_sleep(8);
-          if ((++spins & 15u) != 0 && X.timeout != 0) continue;
-          if (t_begin == 0) t_begin = wall_clock64();
-          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
-            if (err == 0 && lane == 0) {
-              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(X.hdr + 1, 0xB00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             ok = false;
             break;
@@ -925,15 +926,15 @@ size_t stb_ck_workspace(unsigned N, unsigned M, int D) {
   const ck_geom g0 = ck_geometry(N, M, D);
   if (!g0.ok) return 0;
   need = g0.bytes;
-  const char *cenv = getenv("STB_CK_C");
-  (void)cenv;
+  // ... and for the shortest blocks a tunable can ask for (one period: the most checkpoints)
+  const size_t nbk_max = ((size_t)g0.G + g0.TP - 1) / g0.TP + 1;
   for (int c : shapes) {
     // the same sizes with C forced: edge streams scale with 1/C, checkpoints do not
     const int WS = 64 * c;
     const unsigned cmax = (M < N - 1) ? M : N - 1;
     const size_t JW = (cmax - 1 + WS - 1) / WS + 1;
-    const size_t b = 256 + 4096 * 5 + (size_t)D * (JW + 1) * (g0.NP + g0.EV) * 8 + (size_t)D * JW * g0.NBK * 64 * (4 + 8 * c) +
-                     (size_t)D * (g0.R + 1) * 12 + 4096;
+    const size_t b = 256 + 4096 * 5 + (size_t)D * (JW + 1) * (g0.NP + g0.EV) * 8 + (size_t)D * JW * nbk_max * 64 * (4 + 8 * c) +
+                     (size_t)D * (g0.R + 1) * 12 + 4096 * 8;
     if (b > need) need = b;
   }
   return need + 256;
