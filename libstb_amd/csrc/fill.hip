@@ -308,7 +308,8 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   }
 
   const int form = pick_form(variant, N, M, D);
-  if (g_dot_req && form != FORM_CHAIN) return stb_fail("%s: the fused evaluation needs the chain form", who);
+  if (g_dot_req && form != FORM_CHAIN && form != FORM_CK)
+    return stb_fail("%s: the fused evaluation needs the chain or the checkpointed form", who);
   switch (form) {
     case FORM_CHAIN: {
       unsigned *hdr = nullptr;
@@ -323,13 +324,13 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     }
     case FORM_CK: {
       unsigned *hdr = nullptr;
-      if (stb_launch_ck(A, D, ws, ws_left, &hdr, st)) return 1;
+      if (stb_launch_ck(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
       g_last.hdr = hdr;
       g_last.A = A;
       g_last.D = D;
       g_last.st = st;
       g_last.s_table = true;
-      g_last.can_fall_back = true;
+      g_last.can_fall_back = (g_dot_req == nullptr);
       return 0;
     }
     case FORM_PC:

@@ -78,6 +78,13 @@ struct ck_args {
   unsigned tp_magic;           // ceil(2^32 / TP): trip / TP = umulhi(trip, tp_magic)
   int spare_work;              // 1: the spare waves of a spine workgroup work as tile workers meanwhile
   int diag;                    // STB_CK_DIAG: 1 the workers wait for the whole spine
+  // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs,
+  // grouped per (trip, 64-column slice counted from column 2) item, and where the sums go
+  const unsigned *item_ptr;        // [trips * nsg + 1] first entry of every item
+  const unsigned short *ent_pos;   // row-in-trip << 6 | column-in-slice of each occurring cell
+  const unsigned *ent_cnt;         // its occurrence count
+  unsigned nsg;                    // slices per trip in item_ptr
+  double *dotp;                    // [D][n_tiles] sum of count * log S per tile
   unsigned long long *dbg;     // STB_CK_TIMELINE: wall-clock stamps, table 0: [JW][NBK + 2] spine (start, block ends, end),
                                // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
 };
@@ -144,7 +151,7 @@ __device__ __forceinline__ void ck_renorm(double (&v)[C], int &ep) {
   }
 }
 
-template <int C, int P>
+template <int C, int P, int DOT>
 __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args X) {
   constexpr int U = CK_U, RE = CK_RE;
   constexpr int WS = 64 * C;  // columns of a wave strip
@@ -164,14 +171,22 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
   // workers: the left inputs of a tile, per wave
   __shared__ __attribute__((aligned(16))) double w_le[CK_NW][CK_MAXRB * U];
   __shared__ int w_lee[CK_NW][CK_MAXRB];
-  __shared__ unsigned s_order[CK_ORDER_LDS];  // the tile order, when it fits (a ticket then costs no dependent global load)
+  // dynamic segment.  Storing form: the tile order, when it fits (a ticket then costs no dependent global
+  // load).  Summing form: per wave a trip's 8 rows x WS significands, and the first 64 cells of every trip's
+  // list of the tile in hand (position, count); see ck_dyn_lds().
+  extern __shared__ __attribute__((aligned(16))) double ck_dyn[];
+  unsigned *s_order = reinterpret_cast<unsigned *>(ck_dyn);
+  double *ck_stage = ck_dyn;
+  unsigned *ck_ecnt = reinterpret_cast<unsigned *>(ck_dyn + (size_t)CK_NW * U * WS);
+  unsigned short *ck_epos = reinterpret_cast<unsigned short *>(ck_ecnt + (size_t)CK_NW * CK_MAXRB * 64);
+  __shared__ int w_se[DOT ? CK_NW : 1][64];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
   for (int i = tid; i < RE * U; i += blockDim.x) edge_in[i] = 0.0;
-  const bool order_in_lds = X.n_tiles <= CK_ORDER_LDS;
+  const bool order_in_lds = DOT == 0 && X.n_tiles <= CK_ORDER_LDS;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
   __syncthreads();
@@ -546,7 +561,11 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
       // spare waves: asleep while the spine walks (they would take issue slots from it), workers afterwards
       while (lds_peek(&prod_done[0]) < G && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(127);
     }
-    // whoever is through with its part of the spine works on tiles
+    // Whoever is through with its part of the spine works on tiles -- but only once every workgroup of the
+    // grid has started (each takes a ticket when it does): while spine workgroups are still waiting for a
+    // free compute unit, this one must give its place up, or its waves would sit on tiles of strips whose
+    // spine cannot start.
+    if (__hip_atomic_load(X.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) return;
   }
 
   // =========================================================================================
@@ -683,6 +702,104 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
         if (fresh) v[i] = (c == 2) ? ldexp(1.0, -1 - PC_BIAS) : 0.0;
         coef[i] = (double)(2 + gs * U) - (double)c * a;
       }
+      if constexpr (DOT != 0) {
+        // ---- the tile as a sum: no logs but those of the cells that occur, nothing stored ----
+        static_assert(DOT == 0 || C <= 2, "the staging area of a DOT worker holds 8 rows of at most 128 columns");
+        double *stage = ck_stage + (size_t)wslot * (U * WS);
+        int *se = &w_se[DOT ? wslot : 0][0];
+        // first entry of every (trip, slice) item of the tile and of the item after the trip's last: lane
+        // tt * (C + 1) + sl holds item_ptr[(gs + tt) * nsg + jw * C + sl]
+        unsigned ip = 0;
+        if (lane < nt * (C + 1)) ip = X.item_ptr[(size_t)(gs + lane / (C + 1)) * X.nsg + (unsigned)(jw * C + lane % (C + 1))];
+        double s = 1.0, acc = 0.0;
+        int tin = gs % TP;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (nothing of the tile has to be walked beyond the last trip that has an occurring cell)
+        const unsigned ipn = (unsigned)__shfl_down((int)ip, C);
+        const unsigned long long hm = __ballot(lane < nt * (C + 1) && lane % (C + 1) == 0 && ipn != ip);
+        const int ge2 = hm ? gs + (63 - __builtin_clzll(hm)) / (C + 1) + 1 : gs;
+        auto range = [&](int tt, unsigned &b0, unsigned &b1, unsigned &mid) {
+          b0 = (unsigned)__builtin_amdgcn_readlane((int)ip, tt * (C + 1));
+          b1 = (unsigned)__builtin_amdgcn_readlane((int)ip, tt * (C + 1) + C);
+          mid = (C == 2) ? (unsigned)__builtin_amdgcn_readlane((int)ip, tt * (C + 1) + 1) : b1;
+        };
+        // The first 64 cells of every trip's list are asked for now, all at once (a list is fetched in ~1.5 us,
+        // a trip walked in 0.2: one trip ahead is not early enough), and parked in LDS.
+        unsigned short *epos = ck_epos + (size_t)wslot * (CK_MAXRB * 64);
+        unsigned *ecnt = ck_ecnt + (size_t)wslot * (CK_MAXRB * 64);
+        {
+          unsigned short pp[CK_MAXRB];
+          unsigned cc[CK_MAXRB];
+#pragma unroll
+          for (int tt = 0; tt < CK_MAXRB; tt++) {
+            pp[tt] = 0;
+            cc[tt] = 0;
+            if (tt < ge2 - gs) {
+              unsigned b0, b1, mid;
+              range(tt, b0, b1, mid);
+              if (b0 + lane < b1) {
+                pp[tt] = X.ent_pos[b0 + lane];
+                cc[tt] = X.ent_cnt[b0 + lane];
+              }
+            }
+          }
+#pragma unroll
+          for (int tt = 0; tt < CK_MAXRB; tt++)
+            if (tt < ge2 - gs) {
+              epos[tt * 64 + lane] = pp[tt];
+              ecnt[tt * 64 + lane] = cc[tt];
+            }
+        }
+        for (int g = gs; g < ge2; g++) {
+          if (g == g0w || tin == 0) {
+            if (g != g0w) ck_renorm<C>(v, ep);
+            const int el = lee[g - gs];
+            int dl = wave_shr1(ep, ep) - ep;
+            if (lane == 0) dl = el - ep;
+            s = ldexp(1.0, min(max(dl, -1100), 220));
+            se[lane] = ep;
+          }
+          unsigned b0, b1, mid;
+          range(g - gs, b0, b1, mid);
+          unsigned pos = epos[(g - gs) * 64 + lane], cnt = ecnt[(g - gs) * 64 + lane];
+          const double *lrow = le + (g - gs) * U;
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const double t0 = wave_shr1(v[C - 1], lrow[u]) * s;
+#pragma unroll
+            for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+            v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+            for (int i = 0; i < C; i++) coef[i] += 1.0;
+            if (b0 != b1) {  // (a trip none of whose cells occurs is only walked)
+              if constexpr (C == 2) *reinterpret_cast<ck_double2 *>(stage + u * WS + lane * 2) = ck_double2{v[0], v[1]};
+              else stage[u * WS + lane] = v[0];
+            }
+          }
+          if (b0 != b1) {
+            unsigned kk = b0 + lane;
+            for (;;) {
+              if (kk < b1) {
+                const int cx = ((C == 2 && kk >= mid) ? 64 : 0) + (int)(pos & 63u);
+                const double val = bfp_log(stage[(pos >> 6) * WS + cx], se[cx / C], lt);
+                acc += (double)cnt * val;
+              }
+              if (kk - lane + 64 >= b1) break;  // (wave-uniform)
+              kk += 64;
+              pos = cnt = 0;
+              if (kk < b1) {
+                pos = X.ent_pos[kk];
+                cnt = X.ent_cnt[kk];
+              }
+            }
+          }
+          if (++tin == TP) tin = 0;
+        }
+        // fixed-shape tree over the wave: the same bits on every run, whoever computed the tile
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) X.dotp[(size_t)d * X.n_tiles + oi] = acc;
+      } else {
       double s = 1.0;
       int tin = gs % TP;
       double *table = A.tables + (uint64_t)d * A.tstride;
@@ -741,6 +858,7 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
           }
         }
         if (++tin == TP) tin = 0;
+      }
       }
       if (wdbg) {
         unsigned hw, xcc;
@@ -850,7 +968,7 @@ struct ck_geom {
 };
 
 // strip shape: C columns per lane, P spine waves per workgroup, blocks of RB trips
-static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
+static ck_geom ck_geometry(unsigned N, unsigned M, int D, bool summing = false) {
   ck_geom g;
   memset(&g, 0, sizeof(g));
   g.ok = false;
@@ -860,6 +978,9 @@ static ck_geom ck_geometry(unsigned N, unsigned M, int D) {
   const uint64_t total_cells = (uint64_t)D * stb_table_cells(N, M);
   g.C = stb_env_int("STB_CK_C", total_cells < 150000000ull ? 2 : 4);
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
+  // (a summing fill stores nothing: its tiles are cheap, the spine decides, and narrow strips walk faster;
+  // its workers stage 8 rows of a strip in LDS, which holds them for up to 128 columns)
+  if (summing) g.C = (stb_env_int("STB_CK_DOT_C", 2) == 1) ? 1 : 2;
   g.P = stb_env_int("STB_CK_P", 4);
   if (g.P < 1 || g.P > 4) g.P = 4;
   int Pc = stb_period_rows(N);
@@ -1010,9 +1131,20 @@ static int ck_order_list(const ck_geom &g, unsigned N, unsigned M, const unsigne
   return 0;
 }
 
-int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st) {
+// tiles per table of the summing form (the partial sums a caller has to provide room for: D times as many)
+unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D) {
+  const ck_geom g = ck_geometry(N, M, D, true);
+  return g.ok ? g.n_tiles : 0;
+}
+// spine workgroups the summing form would launch for D tables (it pays while they all fit on the chip)
+unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D) {
+  const ck_geom g = ck_geometry(N, M, D, true);
+  return g.ok ? (unsigned)g.B * (unsigned)D : 0xffffffffu;
+}
+
+int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
   const unsigned N = A.N, M = A.M;
-  const ck_geom g = ck_geometry(N, M, D);
+  const ck_geom g = ck_geometry(N, M, D, dot != nullptr);
   if (!g.ok) return stb_fail("stb_fill_S: the checkpointed form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the checkpointed form");
   ck_args X;
@@ -1048,6 +1180,16 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
   X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
   X.spare_work = stb_env_int("STB_CK_SPARE", 0);
   X.diag = stb_env_int("STB_CK_DIAG", 0);
+  if (dot) {
+    if (!dot->item_ptr || dot->col0 != 2)
+      return stb_fail("stb_fill_S: the checkpointed form sums over cell lists built for strips that start at column 2");
+    X.item_ptr = dot->item_ptr;
+    X.ent_pos = dot->ent_pos;
+    X.ent_cnt = dot->ent_cnt;
+    X.nsg = dot->nsg;
+    X.dotp = dot->dotp;
+    const_cast<dot_request *>(dot)->parts_per_table = (int)g.n_tiles;
+  }
   X.pub_nap = stb_env_int("STB_CK_PUB_NAP", 4);
   X.tp_magic = (unsigned)((0x100000000ull + (unsigned)X.TP - 1) / (unsigned)X.TP);
   if (ck_order_list(g, N, M, &X.order)) return 1;
@@ -1073,7 +1215,21 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
   if (stb_env_int("STB_CK_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_CK_GRID", 0);  // (diagnostic: spine alone)
   const int shape = g.C * 10 + g.P;
-#define CKL(CC, PP) STB_LAUNCH((k_fill_ck<CC, PP>), dim3(grid), dim3(64 * CK_NW), st, A, X)
+  // dynamic LDS: the tile order (storing form), or the staging rows and the cell lists of a tile (summing form)
+  const size_t shm_fill = (g.n_tiles <= CK_ORDER_LDS) ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
+  if (dot) {
+    const size_t shm = (size_t)CK_U * CK_NW * 64 * g.C * sizeof(double) + (size_t)CK_NW * CK_MAXRB * 64 * (sizeof(unsigned) + sizeof(unsigned short));
+#define CKD(CC, PP) STB_LAUNCH_SHM((k_fill_ck<CC, PP, 1>), dim3(grid), dim3(64 * CK_NW), shm, st, A, X)
+    switch (shape) {
+      case 14: CKD(1, 4); break;
+      case 21: CKD(2, 1); break;
+      case 22: CKD(2, 2); break;
+      case 24: CKD(2, 4); break;
+      default: return stb_fail("stb_fill_S: no summing checkpointed kernel for C=%d P=%d", g.C, g.P);
+    }
+#undef CKD
+  } else {
+#define CKL(CC, PP) STB_LAUNCH_SHM((k_fill_ck<CC, PP, 0>), dim3(grid), dim3(64 * CK_NW), shm_fill, st, A, X)
   switch (shape) {
     case 11: CKL(1, 1); break;
     case 12: CKL(1, 2); break;
@@ -1087,6 +1243,7 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_
     default: return stb_fail("stb_fill_S: no checkpointed kernel for C=%d P=%d", g.C, g.P);
   }
 #undef CKL
+  }
   HIPCHK(hipGetLastError());
   if (X.dbg) {
     // spine: one line per wave strip "S jw start b1 b2 ... end"; workers: "W jw b claimed loaded done hwid"

@@ -35,11 +35,13 @@ struct stb_groups {
   double *d_dotp;
   size_t dotp_elems;
   int fused, fused_ready;
-  // sparse form of the fused evaluation: CSR of the occurring cells per (trip, slice) item
-  unsigned *d_item_ptr;
-  unsigned short *d_ent_pos;
-  unsigned *d_ent_cnt;
+  // sparse form of the fused evaluation: CSR of the occurring cells per (trip, slice) item, in two layouts,
+  // each built when first needed: [0] slices from column 1 (k_fill_chain), [1] from column 2 (k_fill_ck)
+  unsigned *d_item_ptr[2];
+  unsigned short *d_ent_pos[2];
+  unsigned *d_ent_cnt[2];
   unsigned nsg;
+  int lists_ready[2];
   int sparse;
   // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
   double *h_out;  // pinned, [2][Dmax]: what the stream copies the sums to
@@ -113,7 +115,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   const int prev_dev = stb_device_enter(g->dev);
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
-                  g->d_item_ptr, g->d_ent_pos, g->d_ent_cnt};
+                  g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -238,7 +240,7 @@ extern "C" stb_groups_t *stb_groups_create(int I, const int *K, const uint32_t *
 
 // key of a pair: (item index << 9) | (row in trip << 6) | column in slice, item = trip * nsg + slice
 __global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, unsigned nsg,
-                            uint64_t *key, uint32_t *payload) {
+                            unsigned col0, uint64_t *key, uint32_t *payload) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const unsigned nn = n[g], tt = t[g];
@@ -246,7 +248,7 @@ __global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, un
   if (nn <= 1) k = STB_KEY_SKIP;
   else if (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
   else {
-    const unsigned trip = (nn - 3) >> 3, u = (nn - 3) & 7, sg = (tt - 1) >> 6, ln = (tt - 1) & 63;
+    const unsigned trip = (nn - 3) >> 3, u = (nn - 3) & 7, sg = (tt - col0) >> 6, ln = (tt - col0) & 63;  // (tt >= 2)
     k = (((uint64_t)trip * nsg + sg) << 9) | (u << 6) | ln;
   }
   key[g] = k;
@@ -305,10 +307,11 @@ __global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned 
 
 // Returns 0 and sets g->sparse = 1 when the sparse form was built, 0 with g->sparse = 0 when the
 // pairs are too dense for it to pay (the caller then builds the count slab), non-zero on error.
-static int groups_fused_setup_sparse(stb_groups_t *g) {
+static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
   const unsigned N = g->N, M = g->M;
   const uint64_t G = g->G;
-  g->sparse = 0;
+  if (g->lists_ready[which]) return 0;
+  if (!g->fused_ready) g->sparse = 0;
   if (G == 0 || G >= 0xffffffffull) return 0;
   const unsigned nsg = (M + 63) / 64 + 4;
   const unsigned trips = (N - 2 + 7) / 8;
@@ -330,7 +333,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g) {
       stb_fail("stb_groups_aterms: out of device memory");
       break;
     }
-    hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, k0, p0);
+    hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, which ? 2u : 1u, k0, p0);
     size_t b1 = 0, b2 = 0;
     if (rocprim::radix_sort_pairs(nullptr, b1, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
     if (rocprim::run_length_encode(nullptr, b2, k1, (unsigned)G, uk, cnt, runs, g->st) != hipSuccess) break;
@@ -352,16 +355,18 @@ static int groups_fused_setup_sparse(stb_groups_t *g) {
       rc = 0;
       break;
     }
-    // the pairs outside the table, in their sorted order
-    g->G2 = n_other;
-    if (stb_pool_malloc((void **)&g->d_n2, 4 * (n_other ? n_other : 1)) != hipSuccess ||
-        stb_pool_malloc((void **)&g->d_t2, 2 * (n_other ? n_other : 1)) != hipSuccess) {
-      stb_fail("stb_groups_aterms: out of device memory");
-      break;
+    // the pairs outside the table, in their sorted order (the same whichever layout is built first)
+    if (!g->d_n2) {
+      g->G2 = n_other;
+      if (stb_pool_malloc((void **)&g->d_n2, 4 * (n_other ? n_other : 1)) != hipSuccess ||
+          stb_pool_malloc((void **)&g->d_t2, 2 * (n_other ? n_other : 1)) != hipSuccess) {
+        stb_fail("stb_groups_aterms: out of device memory");
+        break;
+      }
+      if (n_other)
+        hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t,
+                           p1 + n_in, n_other, g->d_n2, g->d_t2);
     }
-    if (n_other)
-      hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, g->st, g->d_n, g->d_t,
-                         p1 + n_in, n_other, g->d_n2, g->d_t2);
     // distinct cells with their counts
     unsigned h_runs = 0;
     if (n_in) {
@@ -373,25 +378,32 @@ static int groups_fused_setup_sparse(stb_groups_t *g) {
     } else if (hipMemsetAsync(runs, 0, 4, g->st) != hipSuccess) {
       break;
     }
-    if (stb_pool_malloc((void **)&g->d_ent_pos, 2 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
-        stb_pool_malloc((void **)&g->d_ent_cnt, 4 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
-        stb_pool_malloc((void **)&g->d_item_ptr, 4 * ((size_t)nitems + 2)) != hipSuccess) {
+    if (stb_pool_malloc((void **)&g->d_ent_pos[which], 2 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        stb_pool_malloc((void **)&g->d_ent_cnt[which], 4 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
+        stb_pool_malloc((void **)&g->d_item_ptr[which], 4 * ((size_t)nitems + 2)) != hipSuccess) {
       stb_fail("stb_groups_aterms: out of device memory");
       break;
     }
     if (h_runs) {
-      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos, item);
-      if (hipMemcpyAsync(g->d_ent_cnt, cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
+      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item);
+      if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
-    hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr);
-    g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
-    if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
-      stb_fail("stb_groups_aterms: out of device memory");
-      break;
+    hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
+    if (!g->d_dotp) {
+      // partial sums: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
+      // checkpointed one
+      g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+      const size_t ckp = (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax);
+      if (ckp > g->dotp_elems) g->dotp_elems = ckp;
+      if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
+        stb_fail("stb_groups_aterms: out of device memory");
+        break;
+      }
     }
     if (hipStreamSynchronize(g->st) != hipSuccess || hipGetLastError() != hipSuccess) break;
     g->nsg = nsg;
     g->sparse = 1;
+    g->lists_ready[which] = 1;
     g->fused_ready = 1;
     rc = 0;
   } while (0);
@@ -471,6 +483,8 @@ static int groups_fused_setup(stb_groups_t *g) {
 // memory; then wait, check the fill and hand the values over.  aterms_finish returns 0, 1 (error) or 2
 // (the fused chain fill gave up waiting: the caller repeats the evaluation through stored tables).
 static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v) {
+  // (v = STB_FILL_CK with fuse: the summing checkpointed form and its cell lists)
+  const int which = (fuse && v == STB_FILL_CK) ? 1 : 0;
   g->pending = 0;
   g->pend_fb0 = stb_fill_fallbacks();
   HIPCHK(hipEventRecord(g->ev[0], g->st));
@@ -479,17 +493,18 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
     // then the few pairs that address no cell (t = 1 -> S1, t = n -> 0, out of bounds -> -inf)
     dot_request req;
     if (g->sparse) {
-      req.item_ptr = g->d_item_ptr;
-      req.ent_pos = g->d_ent_pos;
-      req.ent_cnt = g->d_ent_cnt;
+      req.item_ptr = g->d_item_ptr[which];
+      req.ent_pos = g->d_ent_pos[which];
+      req.ent_cnt = g->d_ent_cnt[which];
       req.nsg = g->nsg;
+      req.col0 = which ? 2 : 1;
     } else {
       req.cnt = g->d_cnt;
     }
     req.dotp = g->d_dotp;
     stb_set_dot_request(&req);
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
-                              g->ws_fill, STB_FILL_CHAIN, g->st);
+                              g->ws_fill, which ? STB_FILL_CK : STB_FILL_CHAIN, g->st);
     stb_set_dot_request(nullptr);
     if (rc) return 1;
     stb_fill_last(&g->pend_fill);
@@ -559,13 +574,22 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   if (g->pending) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int v = stb_default_variant();
   // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
-  const bool fuse = allow_fuse && g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN);
-  if (fuse && !g->fused_ready) {
-    if (stb_env_int("STB_ATERMS_SPARSE", 1) && groups_fused_setup_sparse(g)) return 1;
-    if (!g->fused_ready && groups_fused_setup(g)) return 1;
-  }
+  const bool fuse = allow_fuse && g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK);
+  // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
+  // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine
+  // workgroups all fit on the chip.  It is not the default: MI355X, 10^6 pairs, N = M = 10^4, its 0.66 ms
+  // at 2-4 discounts and 0.85-0.96 at 8 against the chain form's 0.73-0.77 and 0.87-0.97 (tools/time_grid.py)
+  // -- the tiles' requests for edges, checkpoints and cell lists stretch the spine's hand-offs between
+  // workgroups from 2 to ~17 us, which eats what the lighter spine gains.
+  int which = 0;
+  if (fuse && (stb_env_int("STB_ATERMS_CK", 0) || v == STB_FILL_CK) && v != STB_FILL_CHAIN && stb_ck_eligible(g->N, g->M, D) &&
+      stb_ck_dot_spine(g->N, g->M, D) <= (unsigned)stb_env_int("STB_ATERMS_CK_MAX_SPINE", 208))
+    which = 1;
+  if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which)) return 1;
+  if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
+  if (fuse && !g->sparse) which = 0;  // (dense pair sets: the count slab, chain form only)
   *fuse_out = fuse;
-  *v_out = v;
+  *v_out = (fuse && which) ? STB_FILL_CK : (fuse ? STB_FILL_CHAIN : v);
   return 0;
 }
 

@@ -128,6 +128,7 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   const unsigned short *ent_pos = nullptr; //         row-in-trip << 6 | column-in-slice
   const unsigned *ent_cnt = nullptr;       //         occurrence count
   unsigned nsg = 0;                        //         slices per trip in item_ptr
+  int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck)
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
 };
@@ -141,7 +142,9 @@ int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out);  // columns per
 bool stb_ck_eligible(unsigned N, unsigned M, int D);
 size_t stb_ck_workspace(unsigned N, unsigned M, int D);
 int stb_ck_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // columns of a wave strip, rows of a tile
-int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
+int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
+unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D);  // partial sums per table of the summing form
+unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D);  // spine workgroups it launches for D tables
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);

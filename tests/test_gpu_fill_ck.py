@@ -79,11 +79,14 @@ def test_ck_more_spine_workgroups_than_compute_units(monkeypatch):
     monkeypatch.setenv("STB_CK_C", "1")
     monkeypatch.setenv("STB_CK_P", "1")
     D, N = 40, 3000
+    L = capi.lib()
     a = synth.discount_grid(64)[:D]
     T = capi.DeviceTables(N, N, D=D)
     T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
     T.fill(a, capi.FILL_CK)
     T.status()
+    assert L.stb_fill_fallbacks() == before       # (finished, not rescued by the other form after a time-out)
     T2 = capi.DeviceTables(N, N, D=D)
     T2.fill(a, capi.FILL_PC)
     for d in (0, 7, D - 1):
