@@ -133,18 +133,19 @@ static bool chain_wins(unsigned N, unsigned M, int D) {
   return (uint64_t)D * M <= cap && N >= 3 && N < (1u << 27);
 }
 
-// ... and between the two, by cells in all: the checkpointed form (spine + tile workers) from ~10^8 cells
-// (2 tables of 10^4 columns, 12 of 4000) to ~10^9 (20 tables of 10^4), where the table traffic of the
-// producer/consumer form's many launches catches up.  (MI355X, tools/sweep_forms.sh, N = M = 10^4: 4 tables
-// 0.79 ms against 1.03 chain, 8 tables 0.98 against 1.36, 16 tables 1.68 against 2.02 pc, 24 tables 2.48
-// against 2.40 pc; N = M = 4000: 8 tables 0.33 = chain, 16 tables 0.36 against 0.47, 64 tables 1.04 = pc.)
+// ... and between the two, by cells in all: the checkpointed form (spine + tile workers) from ~4 x 10^7 cells
+// (one table of 10^4 columns, 8 of 4000) to ~10^9 (20 tables of 10^4), where the table traffic of the
+// producer/consumer form's many launches catches up.  (MI355X, tools/sweep_forms.sh / tools/ab_ck.py,
+// N = M = 10^4: 1 table 0.65 ms against 0.68 chain, 4 tables 0.75-0.79 against 1.03, 8 tables 0.90-0.98
+// against 1.16-1.36, 16 tables 1.68-1.73 against 2.02 pc, 24 tables 2.48 against 2.40 pc; N = M = 4000:
+// 8 tables 0.33 = chain, 16 tables 0.36 against 0.47, 64 tables 1.04 = pc.)
 // STB_CK=0 / 1 switches it off / on wherever it is eligible.
 static bool ck_wins(unsigned N, unsigned M, int D) {
   const int force = stb_env_int("STB_CK", -1);
   if (force == 0 || g_dot_req_active() || !stb_ck_eligible(N, M, D)) return false;
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
-  return cells >= (uint64_t)stb_env_int("STB_CK_MIN_MCELLS", 80) * 1000000ull &&
+  return cells >= (uint64_t)stb_env_int("STB_CK_MIN_MCELLS", 40) * 1000000ull &&
          cells <= (uint64_t)stb_env_int("STB_CK_MAX_MCELLS", 1000) * 1000000ull;
 }
 

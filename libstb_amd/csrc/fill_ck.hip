@@ -891,16 +891,17 @@ __device__ __forceinline__ me_t me_mul(me_t x, me_t y) {
   return r;
 }
 
-__global__ __launch_bounds__(1024) void k_col1(const double *a_dev, ck_args X, double *tmp_m, int *tmp_e, int R) {
-  // rows 1 .. R; tmp_m / tmp_e: [D][R + 1]
-  __shared__ double sm[1024];
-  __shared__ int se[1024];
+__global__ __launch_bounds__(1024) void k_col1(const double *a_dev, ck_args X, int *period_e, int R) {
+  // rows 1 .. R in 1024 contiguous chunks, one per thread; period_e: [D][periods + 2] scratch
+  __shared__ double sm[16];
+  __shared__ int se[16];
   const int d = blockIdx.x, t = threadIdx.x;
   const double a = a_dev[d];
   const int chunk = (R + 1023) / 1024;
   const int n_lo = 1 + t * chunk, n_hi = min(R, n_lo + chunk - 1);
-  double *tm = tmp_m + (size_t)d * (R + 1);
-  int *te = tmp_e + (size_t)d * (R + 1);
+  const int TP = X.TP;
+  const int periods = (X.G + TP - 1) / TP;
+  int *pe = period_e + (size_t)d * (periods + 2);  // [0]: the row before the table (trip -1), [1 + p]: period p
   // factor of row n: x_n = x_{n-1} * (n - 1 - a) for n >= 2, x_1 = 1
   me_t acc = {0.5, 1};  // 1.0
   for (int n = n_lo; n <= n_hi; n++) {
@@ -909,49 +910,83 @@ __global__ __launch_bounds__(1024) void k_col1(const double *a_dev, ck_args X, d
       acc = me_mul(acc, f);
     }
   }
-  sm[t] = acc.m;
-  se[t] = acc.e;
-  __syncthreads();
-  // inclusive scan of the chunk totals
-  for (int off = 1; off < 1024; off <<= 1) {
-    me_t mine = {sm[t], se[t]};
-    me_t other = {0.5, 1};
-    if (t >= off) other = {sm[t - off], se[t - off]};
-    __syncthreads();
-    if (t >= off) mine = me_mul(mine, other);
-    sm[t] = mine.m;
-    se[t] = mine.e;
-    __syncthreads();
+  // exclusive scan of the chunk totals: inside the wave with shuffles, across the 16 waves through LDS
+  // (barriers of a 1024-thread workgroup are what this kernel's time is made of: three, not twenty)
+  const int lane = t & 63, wv = t >> 6;
+  me_t inc = acc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    me_t y = {__shfl_up(inc.m, off), __shfl_up(inc.e, off)};
+    if (lane >= off) inc = me_mul(inc, y);
   }
-  me_t pre = {0.5, 1};
-  if (t > 0) pre = {sm[t - 1], se[t - 1]};
+  if (lane == 63) {
+    sm[wv] = inc.m;
+    se[wv] = inc.e;
+  }
+  __syncthreads();
+  me_t wp = {0.5, 1};
+  for (int w = 0; w < wv; w++) {
+    me_t y = {sm[w], se[w]};
+    wp = me_mul(wp, y);
+  }
+  me_t up = {__shfl_up(inc.m, 1), __shfl_up(inc.e, 1)};
+  me_t pre0 = (lane == 0) ? wp : me_mul(wp, up);
+  // the exponent a period is written under is that of its first row, 3 + 8 TP p (of row 2 for the row
+  // before the table): whoever owns that row says so
+  // (rows are walked with running counters: an integer division per row would cost more than the row)
+  const int PR = CK_U * TP;  // rows of a period
+  me_t pre = pre0;
+  int p_of = (n_lo >= 3) ? (n_lo - 3) / PR : -1, r_in = (n_lo >= 3) ? (n_lo - 3) - p_of * PR : 0;  // period of row n, row within it
   for (int n = n_lo; n <= n_hi; n++) {
     if (n >= 2) {
       me_t f = {(double)(n - 1) - a, 0};
       pre = me_mul(pre, f);
     }
-    tm[n] = pre.m;
-    te[n] = pre.e;
+    if (n == 2) pe[0] = pre.e + PC_BIAS;
+    if (n >= 3) {
+      if (r_in == 0) pe[1 + p_of] = pre.e + PC_BIAS;
+      if (++r_in == PR) {
+        r_in = 0;
+        p_of++;
+      }
+    } else if (n == 2) {
+      p_of = 0;
+      r_in = 0;
+    }
   }
   __threadfence_block();
   __syncthreads();
   unsigned long long *ev = X.edge_v + (size_t)d * (X.JW + 1) * X.EV;
   unsigned long long *ee = X.edge_e + (size_t)d * (X.JW + 1) * X.NP + 1;
-  const int TP = X.TP;
-  auto trip_exp = [&](int tr) {  // the exponent of the values produced in trip tr (rows 3 + 8 tr ..)
-    if (tr < 0) return te[2] + PC_BIAS;
-    const int p = tr / TP;
-    const int nfirst = min(3 + CK_U * TP * p, R);
-    return te[nfirst] + PC_BIAS;
-  };
-  for (int n = 2 + t; n <= R; n += 1024) {
-    const int tr = (n >= 3) ? (n - 3) / CK_U : -1;
-    const int E = trip_exp(tr);
-    const double g = ldexp(tm[n], te[n] - E);
-    ev[n] = (unsigned long long)__double_as_longlong(g);
+  // the chunk once more, now written out: the significand relative to its trip's exponent as an 8-byte
+  // granule per row, the exponent + CH_EOFF per trip (by the owner of the trip's first row)
+  pre = pre0;
+  p_of = (n_lo >= 3) ? (n_lo - 3) / PR : -1;
+  r_in = (n_lo >= 3) ? (n_lo - 3) - p_of * PR : 0;
+  int cur_p = -2, E = 0;
+  for (int n = n_lo; n <= n_hi; n++) {
+    if (n >= 2) {
+      me_t f = {(double)(n - 1) - a, 0};
+      pre = me_mul(pre, f);
+      const int p = (n >= 3) ? p_of : -1;
+      if (p != cur_p) {
+        cur_p = p;
+        E = pe[1 + p];
+      }
+      ev[n] = (unsigned long long)__double_as_longlong(ldexp(pre.m, pre.e - E));
+      if (n == 2) ee[-1] = (unsigned long long)((long long)E + (long long)CH_EOFF);
+      else if ((r_in & (CK_U - 1)) == 0) ee[p_of * TP + (r_in >> 3)] = (unsigned long long)((long long)E + (long long)CH_EOFF);
+    }
+    if (n >= 3) {
+      if (++r_in == PR) {
+        r_in = 0;
+        p_of++;
+      }
+    } else if (n == 2) {
+      p_of = 0;
+      r_in = 0;
+    }
   }
-  const int last_trip = (R - 3) / CK_U;
-  for (int tr = -1 + t; tr <= last_trip; tr += 1024) ee[tr] = (unsigned long long)((long long)trip_exp(tr) + (long long)CH_EOFF);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,7 +1237,7 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
   *hdr_out = X.hdr;
   stb_launch_s1(A, D, st);
-  hipLaunchKernelGGL(k_col1, dim3(D), dim3(1024), 0, st, A.a, X, (double *)(ws + g.off_tm), (int *)(ws + g.off_te), g.R);
+  hipLaunchKernelGGL(k_col1, dim3(D), dim3(1024), 0, st, A.a, X, (int *)(ws + g.off_tm), g.R);
   // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
   int dev = 0, cus = 256;
   HIPCHK(hipGetDevice(&dev));

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Soak test of the checkpointed form: thousands of fills must give bit-identical tables, never give up (no
+fallback to the producer/consumer form), alone and next to a background load of copies and fp64 matmuls.
+usage: python tools/soak_ck.py [seconds]      (repo root, GPU box)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from libstb_amd import capi, synth
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+L = capi.lib()
+cases = [(777, 500, 5), (6000, 900, 2), (10000, 10000, 1), (3000, 3000, 3), (4000, 4000, 8), (10000, 10000, 8), (2000, 2000, 40), (10000, 10000, 16)]
+fb0 = L.stb_fill_fallbacks()
+total = 0
+side = torch.cuda.Stream()
+big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+mm = torch.randn(2048, 2048, dtype=torch.float64, device="cuda")
+for load in (False, True):
+    for N, M, D in cases:
+        a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
+        T = capi.DeviceTables(N, M, D=D)
+        T.tables.zero_()
+        T.fill(a, capi.FILL_CK); torch.cuda.synchronize(); T.status()
+        ref = T.tables.clone(); refS1 = T.S1.clone()
+        n = 0
+        t_case = time.time() + budget / (2 * len(cases))
+        while time.time() < t_case:
+            for _ in range(10):
+                if load:
+                    with torch.cuda.stream(side):
+                        big[: 128 << 20].copy_(big[128 << 20:])
+                        mm2 = mm @ mm
+                T.tables.zero_()
+                T.fill(a, capi.FILL_CK)
+                if not torch.equal(T.tables, ref) or not torch.equal(T.S1, refS1):
+                    bad = (T.tables != ref).nonzero()
+                    print(f"MISMATCH N={N} M={M} D={D} load={load} after {n} fills: {bad.shape[0]} elements differ, first {bad[0].tolist()}", flush=True)
+                    sys.exit(1)
+                n += 1
+            T.status()
+        if L.stb_fill_fallbacks() != fb0:
+            print(f"FELL BACK N={N} M={M} D={D} load={load}: {capi.last_error()}", flush=True)
+            sys.exit(1)
+        total += n
+        print(f"N={N} M={M} D={D} load={load}: {n} fills identical, none gave up", flush=True)
+        del T
+print(f"soak ok: {total} checkpointed fills", flush=True)
