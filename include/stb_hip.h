@@ -78,6 +78,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
 #define STB_FILL_CHAIN 6       /* one launch: column blocks keep their columns for all rows, edges handed on in HBM */
 #define STB_FILL_CHAINX 7      /* (ablation build) the chain alone in its blocks; logs by converter blocks (D <= 2) */
 #define STB_FILL_CK 8          /* one launch: a recurrence-only spine publishes edges and checkpoints, tile workers convert and store */
+#define STB_FILL_HB 9          /* one launch: a spine that walks blocks of rows behind a halo, alone; tile workers convert and store */
 size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D);
 int stb_default_variant(void); /* STB_FILL_SCALED unless the environment says STB_FILL_VARIANT=1 */
 int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables,

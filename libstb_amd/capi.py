@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("STB_LIB_PATH") or os.path.join(_HERE, "lib", "libstb_
 
 # flag bits of include/stable.h
 S_STABLE, S_UVTABLE, S_FLOAT, S_VERBOSE, S_QUITONBOUND, S_THREADS, S_ASYMPT = 1, 2, 4, 8, 16, 32, 64
-FILL_SCALED, FILL_LOGDOMAIN, FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_PC, FILL_CHAIN, FILL_CHAINX, FILL_CK = 0, 1, 2, 3, 4, 5, 6, 7, 8
+FILL_SCALED, FILL_LOGDOMAIN, FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_PC, FILL_CHAIN, FILL_CHAINX, FILL_CK, FILL_HB = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)

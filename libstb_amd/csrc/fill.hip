@@ -93,6 +93,8 @@ static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
   size_t form = stb_chain_workspace(N, M, D);
   const size_t ck = stb_ck_workspace(N, M, D);
   if (ck > form) form = ck;
+  const size_t hb = stb_hb_workspace(N, M, D);
+  if (hb > form) form = hb;
   if (stb_ablation_workspace) {
     const size_t ab = stb_ablation_workspace(N, M, D);
     if (ab > form) form = ab;
@@ -116,7 +118,7 @@ extern "C" size_t stb_fill_workspace_bytes(unsigned N, unsigned M, int D) {
 extern "C" int stb_default_variant(void) {
   const int v = stb_env_int("STB_FILL_VARIANT", STB_FILL_SCALED);
   return (v == STB_FILL_LOGDOMAIN || v == STB_FILL_SCALED_STEP || v == STB_FILL_SPLIT || v == STB_FILL_FUSED ||
-          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX || v == STB_FILL_CK)
+          v == STB_FILL_PC || v == STB_FILL_CHAIN || v == STB_FILL_CHAINX || v == STB_FILL_CK || v == STB_FILL_HB)
              ? v
              : STB_FILL_SCALED;
 }
@@ -149,7 +151,15 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
          cells <= (uint64_t)stb_env_int("STB_CK_MAX_MCELLS", 1000) * 1000000ull;
 }
 
-enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK };
+// the halo-block form: STB_HB=1 wherever it is eligible (default: off until measured)
+static bool hb_wins(unsigned N, unsigned M, int D) {
+  const int force = stb_env_int("STB_HB", -1);
+  if (force == 0 || g_dot_req_active() || !stb_hb_eligible(N, M, D)) return false;
+  if (force > 0) return true;
+  return false;
+}
+
+enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK, FORM_HB };
 
 static int pick_form(int variant, unsigned N, unsigned M, int D) {
   switch (variant) {
@@ -157,6 +167,7 @@ static int pick_form(int variant, unsigned N, unsigned M, int D) {
     case STB_FILL_PC: return (N < (1u << 27)) ? FORM_PC : FORM_ROWS_LOG;
     case STB_FILL_CHAIN: return (N >= 3 && N < (1u << 27)) ? FORM_CHAIN : (N < 3 ? FORM_PC : FORM_ROWS_LOG);
     case STB_FILL_CK: return stb_ck_eligible(N, M, D) ? FORM_CK : pick_form(STB_FILL_CHAIN, N, M, D);
+    case STB_FILL_HB: return stb_hb_eligible(N, M, D) ? FORM_HB : pick_form(STB_FILL_CHAIN, N, M, D);
     case STB_FILL_CHAINX:  // (its converter blocks need a compute unit per 64-column chunk)
       if (D > 2) return pick_form(STB_FILL_CHAIN, N, M, D);
       return (N >= 3 && N < (1u << 27)) ? FORM_ABLATION : pick_form(STB_FILL_CHAIN, N, M, D);
@@ -166,6 +177,7 @@ static int pick_form(int variant, unsigned N, unsigned M, int D) {
     default:
       // the block-floating forms bound the scale between lanes for N < 2^27 (see k_fill_pc)
       if (N >= (1u << 27)) return FORM_ROWS_LOG;
+      if (hb_wins(N, M, D)) return FORM_HB;
       if (ck_wins(N, M, D)) return FORM_CK;
       return chain_wins(N, M, D) ? FORM_CHAIN : FORM_PC;
   }
@@ -188,6 +200,14 @@ extern "C" int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R
     if (R_out) *R_out = rows;  // rows of a tile
     if (launches) *launches = 1;
     return 4;
+  }
+  if (form == FORM_HB) {
+    int W = 0, rows = 0;
+    stb_hb_tuning(N, M, D, &W, &rows);
+    if (C_out) *C_out = W;     // own columns of a strip
+    if (R_out) *R_out = rows;  // rows of a block
+    if (launches) *launches = 1;
+    return 6;
   }
   int C = (form == FORM_PC) ? 4 : stb_env_int("STB_FILL_C", 2);
   int R = stb_env_int("STB_FILL_R", form == FORM_PC ? 128 : 64);
@@ -309,7 +329,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   }
 
   const int form = pick_form(variant, N, M, D);
-  if (g_dot_req && form != FORM_CHAIN && form != FORM_CK)
+  if (g_dot_req && form != FORM_CHAIN && form != FORM_CK && form != FORM_HB)
     return stb_fail("%s: the fused evaluation needs the chain or the checkpointed form", who);
   switch (form) {
     case FORM_CHAIN: {
@@ -326,6 +346,17 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     case FORM_CK: {
       unsigned *hdr = nullptr;
       if (stb_launch_ck(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
+      g_last.hdr = hdr;
+      g_last.A = A;
+      g_last.D = D;
+      g_last.st = st;
+      g_last.s_table = true;
+      g_last.can_fall_back = (g_dot_req == nullptr);
+      return 0;
+    }
+    case FORM_HB: {
+      unsigned *hdr = nullptr;
+      if (stb_launch_hb(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
       g_last.hdr = hdr;
       g_last.A = A;
       g_last.D = D;

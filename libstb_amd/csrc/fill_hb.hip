@@ -1,0 +1,819 @@
+// fill_hb.hip -- the halo-block form of the S-table fill: ONE launch; a spine that walks the rows
+// without talking to anybody inside a block of rows, and tile workers that do everything else.
+//
+// Replaces the table part of S_remake_part's double-S branch (reference lib/stable.c:321-388):
+//   S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1},   stored as log S^n_m for 2 <= m <= min(n-1, M).
+//
+// Why another form.  In k_fill_ck a spine wave hands the last column of its strip to its right
+// neighbour row by row: the post, the look at the left neighbour's counter and the bookkeeping of a trip
+// cost a lone wave more than the arithmetic of the row (42-49 ns a row of which 17-26 are the recurrence),
+// and that row time, times N, is the floor of a fill.  Information moves one column to the right per
+// row, so a wave that starts a block of R rows with R extra columns on its left -- a halo, copied from
+// its left neighbour's state at the start of the block -- needs nothing from anybody until the block
+// ends: the halo goes wrong from the left, one column per row, and the wave's own columns stay exact.
+//
+//   spine    a wave owns U = 64 - HL lanes (C adjacent columns each, block-floating, see k_fill_chain) of
+//            one table for all rows; lanes 0..HL-1 are the halo, HL = R / C.  Per block: renormalise,
+//            hand the rightmost HL lanes to the right neighbour (LDS inside a workgroup; the record below
+//            across workgroups, polled by the right workgroup's fetcher wave), store the own lanes as the
+//            block's RECORD (significands + lane exponents, HBM), take the halo from the left, then R rows
+//            of 2 DPP moves, 1 multiply, C fma and C adds each, and nothing else.
+//   workers  every other wave of the grid.  A worker takes a tile (table d, strip j, block b) from a
+//            ticket, loads the strip's record of the block and -- for its halo lanes -- the left strip's,
+//            recomputes the R rows in registers exactly as the spine does, and converts and stores the
+//            own lanes' cells row by row.  Tiles are independent of each other and of the spine's pace.
+//
+// Lanes hold aligned groups of C table elements (element e = m - 2): a lane's cells are one aligned
+// 8*C-byte store.  Column 1 (the S1 vector, not a table column) is the last element of group -1, i.e. of
+// the last halo lane of strip 0, whose halo needs no neighbour (column 0 is identically zero): strip 0
+// computes it along.  The state before block b is row 1 + b R; row 1 is S^1_1 = 1.
+//
+// A record word is its own flag: 0 means "not written yet" (an exact zero travels as -0.0, exponents
+// carry an offset); records are written with write-through stores and read with L1-bypassing loads.
+// Every wait is bounded; on expiry the waiter records an error in the header and everybody runs to the
+// end (stb_fill_status repeats the fill with k_fill_pc).
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "fill_chain.h"
+
+#define HB_NW 8          // waves per workgroup: up to 7 spine waves and a fetcher
+#define HB_SLOTS 4       // ring of hand-overs between two spine waves of a workgroup (blocks)
+#define HB_FSLOTS 8      // ring of hand-overs from the fetcher to spine wave 0
+#define HB_MAXHL 32      // halo lanes at most
+#define HB_EOFF32 (1u << 30)
+#define HB_ORDER_LDS 8192  // tiles of a table whose order list is copied to LDS (32 KB)
+#define HB_PROG_STRIDE 32  // words between two strips' progress words: a line each (a strip's waiting workers poll
+                           // the word its spine wave writes; 125 strips' words in four lines made those lines the
+                           // busiest of the chip and the spine's stores to them slow: its store queue filled up)
+#define HB_SPIN 48         // looks at a neighbour's counter, ~0.1 us apart, before the out-of-line wait
+#ifndef HB_DIAG
+#define HB_DIAG 0          // diagnostic builds: 1 the spine stores no records, 2 it stores every record twice, 8 the workers store nothing (results wrong)
+#endif
+
+struct hb_args {
+  unsigned *hdr;               // [0] role ticket, [1] error code, [2] error detail, [3] tile ticket, [4] spine waves through
+  unsigned long long *ck_v;    // [D][n_rec][U*C]  records: significands of the own lanes at the start of a block
+  unsigned *ck_e;              // [D][n_rec][U]    ... and their lane exponents + HB_EOFF32
+  unsigned *progress;          // [D][JW][HB_PROG_STRIDE]  blocks whose record a spine wave has written (scheduling hint)
+  const unsigned *order;       // [n_tiles] j | b << 16, in the order the tiles become ready
+  const unsigned *rec_off;     // [JW + 2]  first record of strip s (s = j + 1; s = 0: the halo of strip 0), per table
+  unsigned n_rec;              // records per table
+  int D, B, JW, NB;            // tables, spine workgroups per table, strips per table, blocks
+  int P, R, HL, U;             // spine waves per workgroup, rows per block, halo lanes, own lanes
+  unsigned n_tiles;            // per table
+  unsigned n_spine;            // spine workgroups in all (B * D)
+  unsigned long long timeout;  // wall_clock64 ticks a wait may last
+  int poll_nap;                // s_sleep argument between two polls of a fetcher
+  int nap_block;               // s_sleep argument of a worker per block its inputs are away
+  int diag;                    // STB_HB_DIAG: 1 the workers wait for the whole spine
+  int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
+  unsigned long long *dbg;     // STB_HB_TIMELINE: wall-clock stamps, table 0: [JW][NB + 2] spine (start, block starts, end),
+                               // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
+};
+
+typedef double hb_double2 __attribute__((ext_vector_type(2)));
+
+// aligned 16-byte store at (wave-uniform base) + (per-lane byte offset); see store_sbase
+__device__ __forceinline__ void hb_store16(const void *sbase, unsigned byte_off, double x, double y) {
+  unsigned long long base_copy;
+  hb_double2 v2 = {x, y};
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0\n\ts_nop 1"
+               : "=&s"(base_copy)
+               : "v"(byte_off), "v"(v2), "s"(sbase)
+               : "memory");
+}
+
+// ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
+__device__ __forceinline__ void hb_logs8(const double (&x)[8], int myep, const double2 *lt, int one_hi, double (&val)[8]) {
+  double z[8], kf[8], r[8], pl[8];
+  double2 tt[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int hi = __double2hiint(x[u]);
+    z[u] = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x[u]));
+    kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; u++) r[u] = fma(z[u], tt[u].x, -1.0);
+#pragma unroll
+  for (int u = 0; u < 8; u++) pl[u] = fma(r[u], 0.2, -0.25);
+#pragma unroll
+  for (int u = 0; u < 8; u++) pl[u] = fma(r[u], pl[u], 1.0 / 3.0);
+#pragma unroll
+  for (int u = 0; u < 8; u++) pl[u] = fma(r[u], pl[u], -0.5);
+#pragma unroll
+  for (int u = 0; u < 8; u++) pl[u] = fma(r[u], pl[u], 1.0);
+#pragma unroll
+  for (int u = 0; u < 8; u++) val[u] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
+}
+
+// renormalise a lane: the largest of its C significands back to 2^-PC_BIAS * [0.5,1)
+template <int C>
+__device__ __forceinline__ void hb_renorm(double (&v)[C], int &ep) {
+  int kmax = -4000;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
+  if (kmax > -4000) {
+#pragma unroll
+    for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
+    ep += kmax + PC_BIAS;
+  }
+}
+
+// eight rows of the recurrence: lane l takes the last column of lane l - 1 (lane 0: nothing), scaled
+// by s = 2^(exponent of lane l-1 - exponent of lane l), frozen for the block
+template <int C>
+__device__ __forceinline__ void hb_row(double (&v)[C], double (&coef)[C], double s) {
+  const double t0 = wave_shr1_zero(v[C - 1]) * s;
+#pragma unroll
+  for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+  v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+  for (int i = 0; i < C; i++) coef[i] += 1.0;
+}
+
+// first block of strip j: the state before it has nothing in the strip's own columns (2 + j U C and up)
+__host__ __device__ static inline int hb_first_block(int j, int UC, int R) { return (int)(((long long)j * UC) / R); }
+
+template <int C, int DOT>
+__global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
+  static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
+  static_assert(DOT == 0, "the summing form is not written yet");
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(16))) double xv[HB_NW - 1][HB_SLOTS][HB_MAXHL * C];
+  __shared__ int xe[HB_NW - 1][HB_SLOTS][HB_MAXHL];
+  __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
+  __shared__ int fe[HB_FSLOTS][HB_MAXHL];
+  __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
+  __shared__ unsigned s_ticket;
+  extern __shared__ unsigned s_order[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
+  if (tid < 128) lt[tid] = A.lt[tid];
+  const bool order_in_lds = X.n_tiles <= HB_ORDER_LDS;
+  if (order_in_lds)
+    for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
+  __syncthreads();
+  const unsigned ticket = s_ticket;
+  const unsigned N = A.N, M = A.M;
+  const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
+  const int UC = U * C;
+
+  if (ticket < X.n_spine) {
+    // =========================================================================================
+    // spine workgroup: strips j*P .. j*P + P - 1 of table d
+    const int j = (int)(ticket / (unsigned)X.D);
+    const int d = (int)(ticket % (unsigned)X.D);
+    const int jw0 = j * P;
+    if (tid < HB_NW) {
+      const int jw = jw0 + tid;
+      const int b0 = (jw < X.JW) ? hb_first_block(jw, UC, R) : NB;
+      posted[tid] = b0;  // hand-overs for blocks below it are nobody's business
+      taken[tid] = b0;
+    }
+    if (tid == 0) {
+      fetched = hb_first_block(jw0, UC, R);
+      s_abort = 0;
+      s_awake = (j == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    const unsigned who = (unsigned)(j | (d << 16));
+    bool aborted = false;
+    // (neighbours reach a block's end within a fraction of a microsecond of each other: a short wait is
+    // spun out here -- the out-of-line wait is a call, and a call waits for every store under way)
+    auto wait_ge = [&](const int *cnt, int need, unsigned code) {
+      if (aborted) return;
+      for (int k = 0; k < HB_SPIN; k++) {
+        if (lds_peek(cnt) >= need) return;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, 1)) aborted = true;
+    };
+    const size_t tab_rec = (size_t)d * X.n_rec;
+
+    if (wave < P) {
+      // ================= spine waves =================
+      const int w = wave;
+      const int jw = jw0 + w;
+      if (jw < X.JW) {
+        while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_setprio(3);
+        const int b0 = hb_first_block(jw, UC, R);
+        const double a = A.a[d];
+        const int m0 = 2 + (jw * U - HL + lane) * C;  // first column of the lane (may be <= 0 in the halo of strip 0)
+        double v[C], coef[C], ma[C];
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          v[i] = 0.0;
+          ma[i] = (double)(m0 + i) * a;
+        }
+        int ep = 1 + PC_BIAS;
+        if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
+        const bool has_next = (w + 1 < P) && (jw + 1 < X.JW);
+        const int *left_cnt = (w == 0) ? &fetched : &posted[w > 0 ? w - 1 : 0];
+        const double *left_v = (w == 0) ? &fv[0][0] : &xv[w > 0 ? w - 1 : 0][0][0];
+        const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
+        const int left_mask = (w == 0) ? HB_FSLOTS - 1 : HB_SLOTS - 1;
+        unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
+        if (dbg) dbg[0] = wall_clock64();
+        // own records: strip index jw + 1, blocks from b0; the halo of strip 0: strip index 0, blocks from 0
+        // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
+        // together with every write-through store of the records still under way)
+        const bool own = lane >= HL;
+        const size_t rec_base = own ? tab_rec + X.rec_off[jw + 1] - (size_t)b0 : tab_rec + X.rec_off[0];
+        const int slot = own ? lane - HL : lane + U - HL;
+        unsigned long long *rec_v = X.ck_v + (rec_base * U + slot) * C;
+        unsigned *rec_e = X.ck_e + rec_base * U + slot;
+        unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
+        double s = 1.0;
+        for (int b = b0; b < NB; b++) {
+          if (b > b0) hb_renorm<C>(v, ep);
+          // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
+          if (has_next) {
+            wait_ge(&taken[w + 1], b - HB_SLOTS + 1, 0x400u);
+            if (lane >= U) {
+              double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
+#pragma unroll
+              for (int i = 0; i < C; i++) dst[i] = v[i];
+              xe[w][b & (HB_SLOTS - 1)][lane - U] = ep;
+            }
+            lds_post(&posted[w], b + 1);
+          }
+          // ---- the record of the block: the own lanes as they stand before it ----
+          {
+            // (halo lanes of strip 0 are exact: they go to strip index 0 at the place a left neighbour's
+            // rightmost lanes would have)
+            if ((own || jw == 0) && !(HB_DIAG & 1)) {
+              unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
+#pragma unroll
+              for (int i = 0; i < C; i++) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(v[i]);
+                if ((bits << 1) == 0) bits = CH_NEGZERO;
+                __hip_atomic_store(dst + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if constexpr ((HB_DIAG & 2) != 0) {
+#pragma unroll
+                for (int i = 0; i < C; i++) {
+                  unsigned long long bits = (unsigned long long)__double_as_longlong(v[i]);
+                  if ((bits << 1) == 0) bits = CH_NEGZERO;
+                  __hip_atomic_store(dst + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+            if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
+          if (jw > 0) {
+            wait_ge(left_cnt, b + 1, 0x100u);
+            asm volatile("" ::: "memory");
+            if (lane < HL) {
+              const double *src = left_v + (size_t)(b & left_mask) * (HB_MAXHL * C) + lane * C;
+#pragma unroll
+              for (int i = 0; i < C; i++) v[i] = src[i];
+              ep = left_e[(b & left_mask) * HB_MAXHL + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slot is in registers: it may be written again)
+            lds_post(&taken[w], b + 1);
+          }
+          if (dbg) dbg[1 + b] = wall_clock64();
+          // ---- R rows alone ----
+          {
+            const int dl = wave_shr1(ep, ep) - ep;
+            s = ldexp(1.0, min(max(dl, -1100), 220));
+            const double n1 = (double)(1 + b * R);  // n - 1 of the block's first row
+#pragma unroll
+            for (int i = 0; i < C; i++) coef[i] = n1 - ma[i];
+          }
+          for (int r = 0; r < R; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) hb_row<C>(v, coef, s);
+          }
+        }
+        if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dbg) dbg[NB + 1] = wall_clock64();
+        if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else if (wave == P && j > 0) {
+      // ================= fetcher: the left workgroup's last strip's records -> LDS, for spine wave 0 =================
+      // groups of 16 (or 32) lanes poll consecutive blocks: a poll takes longer than a block
+      const int gl = (HL <= 16) ? 16 : 32;
+      const int grp = lane / gl, sub = lane % gl, ngrp = 64 / gl;
+      const bool act = sub < HL;
+      const int bL0 = hb_first_block(jw0 - 1, UC, R);
+      const size_t rec_left = tab_rec + X.rec_off[jw0] - (size_t)bL0;  // (strip jw0 - 1 has strip index jw0)
+      const int slot = sub + U - HL;
+      int bb = hb_first_block(jw0, UC, R);  // blocks below it are delivered
+      {
+        // the left strip writes records from its own first block on: wait, dozing, for the first one needed here
+        const unsigned *probe = X.ck_e + (rec_left + bb) * U + (U - 1);
+        unsigned long long t_begin = 0;
+        unsigned spins = 0;
+        while (__hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(16);
+          if ((++spins & 255u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || lds_peek(&s_abort) ||
+              (unsigned long long)wall_clock64() - t_begin >= X.timeout)
+            break;  // (the main loop below gives up properly)
+        }
+        lds_post(&s_awake, 1);
+      }
+      unsigned long long t_begin = 0;
+      bool timing = false;
+      unsigned idle = 0;
+      while (bb < NB) {
+        const int mb = bb + grp;
+        const bool want = act && mb < NB;
+        unsigned long long bv[C];
+        unsigned be = 1;
+#pragma unroll
+        for (int i = 0; i < C; i++) bv[i] = 1;
+        if (want) {
+          const unsigned long long *src = X.ck_v + ((rec_left + mb) * U + slot) * C;
+#pragma unroll
+          for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          be = __hip_atomic_load(X.ck_e + (rec_left + mb) * U + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int tk = lds_peek(&taken[0]);
+        bool have = be != 0;
+#pragma unroll
+        for (int i = 0; i < C; i++) have = have && bv[i] != 0;
+        const unsigned long long miss = ~__ballot(have);
+        // leading groups that are complete, in range, and whose ring slot spine wave 0 has read
+        int k = miss ? (int)(__builtin_ctzll(miss) / gl) : ngrp;
+        k = min(k, NB - bb);
+        k = min(k, tk + HB_FSLOTS - bb);
+        if (k > 0) {
+          if (want && grp < k) {
+            double *dst = &fv[mb & (HB_FSLOTS - 1)][sub * C];
+#pragma unroll
+            for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)bv[i]);
+            fe[mb & (HB_FSLOTS - 1)][sub] = (int)(be - HB_EOFF32);
+          }
+          bb += k;
+          lds_post(&fetched, bb);
+          timing = false;
+          idle = 0;
+          continue;
+        }
+        for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
+        if ((++idle & 31) != 0 && X.timeout != 0) continue;
+        if (!timing) {
+          timing = true;
+          t_begin = wall_clock64();
+        }
+        const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+          if (lane == 0) {
+            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (err == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          lds_post(&fetched, 0x7fffffff);  // release the spine: it runs on with stale halos
+          break;
+        }
+      }
+    }
+    // Whoever is through with its part of the spine works on tiles -- but only once every workgroup of the
+    // grid has started (each takes a ticket when it does): while spine workgroups are still waiting for a
+    // free compute unit, this one must give its place up, or its waves would sit on tiles of strips whose
+    // spine cannot start.  Waves without a part (no strip, no fetching) sleep until the spine is through:
+    // a worker on the spine's compute unit takes issue slots from it.
+    if (X.spare_work && (wave > P || (wave == P && j == 0) || (wave < P && jw0 + wave >= X.JW))) {
+      // (tunable: the spare waves work on tiles from the start, once every workgroup of the grid is running)
+      unsigned spins = 0;
+      while (__hip_atomic_load(X.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < 200000u)
+        __builtin_amdgcn_s_sleep(64);
+    } else if (wave > P || (wave == P && j == 0) || (wave < P && jw0 + wave >= X.JW)) {
+      const int last = min(P, X.JW - jw0) - 1;
+      unsigned spins = 0;
+      while (__hip_atomic_load(X.progress + ((size_t)d * X.JW + jw0 + last) * HB_PROG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0x7fffffffu &&
+             !lds_peek(&s_abort)) {
+        __builtin_amdgcn_s_sleep(127);
+        if ((++spins & 1023u) == 0 && __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      }
+    }
+    if (__hip_atomic_load(X.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) return;
+  }
+
+  // =========================================================================================
+  // tile workers (every wave for itself)
+  {
+    int one_hi = 0x3ff00000;
+    asm volatile("" : "+v"(one_hi));
+    const unsigned total = X.n_tiles * (unsigned)X.D;
+    if (X.diag & 1) {
+      // diagnostic: the workers start when every spine wave is through (what the tiles cost with the chip to themselves)
+      unsigned spins = 0;
+      while (__hip_atomic_load(X.hdr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(X.JW * X.D) && ++spins < 400000u)
+        __builtin_amdgcn_s_sleep(100);
+    }
+    for (;;) {
+      unsigned k = 0;
+      if (lane == 0) k = atomicAdd(X.hdr + 3, 1u);
+      k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+      if (k >= total) break;
+      const int d = (int)(k % (unsigned)X.D);
+      const unsigned oi = k / (unsigned)X.D;
+      const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane((int)(order_in_lds ? s_order[oi] : X.order[oi]));
+      const int jw = (int)(ord & 0xffffu), b = (int)(ord >> 16);
+      const unsigned who = (unsigned)jw | ((unsigned)d << 16);
+      unsigned long long *wdbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)oi * 4 : nullptr;
+      if (wdbg) wdbg[0] = wall_clock64();
+      // ---- the tile's inputs: the strip's record of the block (own lanes) and the left strip's (halo lanes).
+      // Everything is asked for at once, without looking at the spine's progress first: what has been written
+      // is non-zero.  Only when something is missing is the progress word read, to sleep about as long as the
+      // missing blocks take. ----
+      const size_t tab_rec = (size_t)d * X.n_rec;
+      const bool own = lane >= HL;
+      const int bO = hb_first_block(jw, UC, R), bL = (jw > 0) ? hb_first_block(jw - 1, UC, R) : 0;
+      const size_t rec = own ? tab_rec + X.rec_off[jw + 1] + (size_t)(b - bO) : tab_rec + X.rec_off[jw] + (size_t)(b - bL);
+      const int slot = own ? lane - HL : lane + U - HL;
+      const unsigned long long *ckv = X.ck_v + (rec * U + slot) * C;
+      const unsigned *cke = X.ck_e + rec * U + slot;
+      const unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
+      double v[C], coef[C];
+      int ep = 0;
+      bool ok = true;
+      {
+        unsigned spins = 0, tries = 0;
+        unsigned long long t_begin = 0;
+        for (;;) {
+          unsigned long long bv[C];
+#pragma unroll
+          for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(ckv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned be = __hip_atomic_load(cke, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool have = be != 0;
+#pragma unroll
+          for (int i = 0; i < C; i++) have = have && bv[i] != 0;
+          if (__all(have)) {
+#pragma unroll
+            for (int i = 0; i < C; i++) v[i] = __longlong_as_double((long long)bv[i]);
+            ep = (int)(be - HB_EOFF32);
+            break;
+          }
+          // Not there yet.  Thousands of waves may be waiting like this while a table's first rows are walked,
+          // and every look at a record is 64 lanes' worth of requests to the memory side that the spine's own
+          // stores and hand-overs queue behind (one table of 10^4: 0.71 ms with every wave re-reading its
+          // records, 0.40 with a third of the waves): wait on the strip's progress word alone -- one request
+          // per look -- sleeping about as long as the blocks still missing take, then read the records again.
+          for (;;) {
+            const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done >= (unsigned)(b + 1)) break;
+            const int missing = min((int)((unsigned)(b + 1) - done), 32);
+            for (int i = 0; i < missing; i++)
+              for (int q = 0; q < X.nap_block; q++) __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 3u) != 0 && X.timeout != 0) continue;
+            if (t_begin == 0) t_begin = wall_clock64();
+            const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+              if (err == 0 && lane == 0) {
+                __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              ok = false;
+              break;
+            }
+          }
+          if (!ok) break;
+          // (the progress word may overtake the record's words by a little, and the left strip's record is
+          // not covered by it: look again shortly; the same clock bounds this)
+          __builtin_amdgcn_s_sleep(8);
+          if ((++tries & 63u) != 0 && X.timeout != 0) continue;
+          if (t_begin == 0) t_begin = wall_clock64();
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = false;
+            break;
+          }
+        }
+      }
+      if (!ok) break;
+      if (wdbg) wdbg[1] = wall_clock64();
+      const double a = A.a[d];
+      const int m0 = 2 + (jw * U - HL + lane) * C;
+      const double n1 = (double)(1 + b * R);
+#pragma unroll
+      for (int i = 0; i < C; i++) coef[i] = n1 - (double)(m0 + i) * a;
+      const int dl = wave_shr1(ep, ep) - ep;
+      const double s = ldexp(1.0, min(max(dl, -1100), 220));
+      double *table = A.tables + (uint64_t)d * A.tstride;
+      const unsigned e0 = (unsigned)(jw * UC);  // first own element of the strip
+      // (the lane offset counts from the strip's first halo lane: the base may lie before the row)
+      const unsigned voff = (unsigned)(lane * C) * 8u;
+      unsigned n = 2u + (unsigned)(b * R);  // the row the next step produces
+      uint64_t roff = stb_row_offset(n, M);
+      constexpr int RS = 8 / C;  // rows converted together: eight cells in flight
+      for (int r = 0; r < R; r += RS) {
+        double x[8], val[8];
+#pragma unroll
+        for (int u = 0; u < RS; u++) {
+          hb_row<C>(v, coef, s);
+#pragma unroll
+          for (int i = 0; i < C; i++) x[u * C + i] = v[i];
+        }
+        // (rows none of whose cells lies in the strip's own columns, and rows outside the table, are only walked)
+        const unsigned nl = n + RS - 1;
+        if (nl >= 3 && n <= N && e0 < stb_row_len(min(nl, N), M)) {
+          hb_logs8(x, ep, lt, one_hi, val);
+#pragma unroll
+          for (int u = 0; u < RS; u++) {
+            const unsigned nu = n + u;
+            if (nu >= 3 && nu <= N && e0 < stb_row_len(nu, M)) {
+              const double *rp = table + roff + e0 - (size_t)(HL * C);
+              if constexpr ((HB_DIAG & 8) != 0) {
+                asm volatile("" ::"v"(val[u * C]), "v"(val[u * C + C - 1]));
+              } else if (own) {
+                if constexpr (C == 1) {
+                  store_sbase(rp, voff, val[u]);
+                } else if constexpr (C == 2) {
+                  hb_store16(rp, voff, val[u * 2], val[u * 2 + 1]);
+                } else {
+                  hb_store16(rp, voff, val[u * 4], val[u * 4 + 1]);
+                  hb_store16(rp + 2, voff, val[u * 4 + 2], val[u * 4 + 3]);
+                }
+              }
+            }
+            roff += stb_row_pitch(nu, M);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < RS; u++) roff += stb_row_pitch(n + u, M);
+        }
+        n += RS;
+      }
+      if (wdbg) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wdbg[2] = wall_clock64();
+        wdbg[3] = (unsigned long long)hw | ((unsigned long long)(xcc & 15u) << 32);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+struct hb_geom {
+  int C, P, B, JW, NB, R, HL, U;
+  unsigned n_tiles, n_rec;
+  size_t off_prog, off_cke, off_ckv, zero_bytes, bytes;
+  bool ok;
+};
+
+static hb_geom hb_geometry(unsigned N, unsigned M, int D) {
+  hb_geom g;
+  memset(&g, 0, sizeof(g));
+  g.ok = false;
+  if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return g;
+  const uint64_t total_cells = (uint64_t)D * stb_table_cells(N, M);
+  g.C = stb_env_int("STB_HB_C", total_cells < 150000000ull ? 2 : 4);
+  if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
+  g.P = stb_env_int("STB_HB_P", HB_NW - 1);
+  if (g.P < 1 || g.P > HB_NW - 1) g.P = HB_NW - 1;
+  // a block is a renormalisation period (or less): rows in eights, halo lanes R / C <= 32
+  int Pc = stb_period_rows(N);
+  const int Penv = stb_env_int("STB_FILL_P", 0);
+  if (Penv > 0 && Penv < Pc) Pc = Penv;
+  int R = stb_env_int("STB_HB_ROWS", 48);
+  if (R > Pc) R = Pc;
+  if (R > HB_MAXHL * g.C) R = HB_MAXHL * g.C;
+  R = R / 8 * 8;
+  if (R < 8) return g;
+  g.R = R;
+  g.HL = R / g.C;
+  g.U = 64 - g.HL;
+  const int UC = g.U * g.C;
+  const unsigned cmax = (M < N - 1) ? M : N - 1;  // columns 2..cmax hold stored cells: elements 0 .. cmax - 2
+  g.JW = (int)((cmax - 1 + UC - 1) / UC);
+  if (g.JW < 1) g.JW = 1;
+  g.B = (g.JW + g.P - 1) / g.P;
+  g.NB = (int)((N - 1 + R - 1) / R);  // the state before block b is row 1 + b R
+  if (g.JW >= 65535 || g.NB >= 65536) return g;
+  uint64_t nt = 0;
+  for (int j = 0; j < g.JW; j++) {
+    const int b0 = hb_first_block(j, UC, R);
+    if (b0 >= g.NB) return g;  // (cannot happen: column 2 + j U C <= N - 1)
+    nt += (uint64_t)(g.NB - b0);
+  }
+  if (nt >= (1ull << 31)) return g;
+  g.n_tiles = (unsigned)nt;
+  g.n_rec = g.n_tiles + (unsigned)g.NB;
+  size_t o = 256;
+  g.off_prog = o;
+  o += stb_align_up((size_t)D * g.JW * HB_PROG_STRIDE * sizeof(unsigned), 256);
+  g.off_cke = o;
+  o += stb_align_up((size_t)D * g.n_rec * g.U * sizeof(unsigned), 256);
+  g.off_ckv = o;
+  o += stb_align_up((size_t)D * g.n_rec * g.U * g.C * 8, 256);
+  g.zero_bytes = o;
+  g.bytes = o;
+  g.ok = true;
+  return g;
+}
+
+bool stb_hb_eligible(unsigned N, unsigned M, int D) { return hb_geometry(N, M, D).ok; }
+
+int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out) {
+  const hb_geom g = hb_geometry(N, M, D);
+  if (W_out) *W_out = g.U * g.C;
+  if (rows_out) *rows_out = g.R;
+  return g.ok ? 0 : 1;
+}
+
+size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
+  const hb_geom g0 = hb_geometry(N, M, D);
+  if (!g0.ok) return 0;
+  // (the strip shape and the block length are tunables: room for the most records any of them needs --
+  // blocks of 8 rows, strips of 32 lanes -- is too much to ask for; size for the shapes the defaults and
+  // the tests use, and let stb_launch_hb refuse what does not fit)
+  size_t need = g0.bytes;
+  static const int shapes[3] = {1, 2, 4};
+  static const int rows[4] = {16, 24, 32, 48};
+  int Pc = stb_period_rows(N);
+  for (int c : shapes)
+    for (int r0 : rows) {
+      int R = std::min(std::min(r0, Pc), HB_MAXHL * c) / 8 * 8;
+      if (R < 8) continue;
+      const int HL = R / c, U = 64 - HL, UC = U * c;
+      const unsigned cmax = (M < N - 1) ? M : N - 1;
+      const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R;
+      size_t nrec = NB;
+      for (size_t j = 0; j < JW; j++) {
+        const size_t b0 = (size_t)hb_first_block((int)j, UC, R);
+        nrec += (b0 < NB) ? NB - b0 : 0;
+      }
+      const size_t b = 1024 + (size_t)D * JW * 4 * HB_PROG_STRIDE + (size_t)D * nrec * U * (4 + 8 * c) + 1024;
+      if (b > need) need = b;
+    }
+  return need + 256;
+}
+
+// the order in which the tiles of a table become ready, as j | b << 16 -- the spine writes the record of
+// block b of strip j at about b R r + (j / P) L + (j % P) lag -- and the first record of every strip
+struct hb_order_entry {
+  int dev;
+  unsigned N, M;
+  int C, P, R, NB, JW;
+  int r_ns, L_ns, lag_ns;
+  unsigned *d_buf;  // [JW + 2] rec_off, then [n_tiles] order
+};
+static std::mutex g_hb_mu;
+static std::vector<hb_order_entry> g_hb_orders;
+
+static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigned **rec_off, const unsigned **order) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  const int r_ns = stb_env_int("STB_HB_ORDER_R", 30), L_ns = stb_env_int("STB_HB_ORDER_L", 3000),
+            lag_ns = stb_env_int("STB_HB_ORDER_LAG", 300);
+  std::lock_guard<std::mutex> lock(g_hb_mu);
+  for (const hb_order_entry &e : g_hb_orders)
+    if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.R == g.R && e.NB == g.NB && e.JW == g.JW &&
+        e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
+      *rec_off = e.d_buf;
+      *order = e.d_buf + g.JW + 2;
+      return 0;
+    }
+  struct item {
+    long key;
+    unsigned code;
+  };
+  const int UC = g.U * g.C;
+  std::vector<unsigned> buf((size_t)g.JW + 2 + g.n_tiles);
+  std::vector<item> v;
+  v.reserve(g.n_tiles);
+  unsigned off = 0;
+  buf[0] = off;  // strip index 0: the halo of strip 0, blocks 0 .. NB - 1
+  off += (unsigned)g.NB;
+  for (int j = 0; j < g.JW; j++) {
+    const int b0 = hb_first_block(j, UC, g.R);
+    buf[j + 1] = off;
+    off += (unsigned)(g.NB - b0);
+    for (int b = b0; b < g.NB; b++) {
+      item it;
+      it.key = (long)b * g.R * r_ns + (long)(j / g.P) * L_ns + (long)(j % g.P) * lag_ns;
+      it.code = (unsigned)j | ((unsigned)b << 16);
+      v.push_back(it);
+    }
+  }
+  buf[g.JW + 1] = off;
+  if (off != g.n_rec || v.size() != g.n_tiles) return stb_fail("stb_fill_S: record count %u != %u", off, g.n_rec);
+  std::stable_sort(v.begin(), v.end(), [](const item &x, const item &y) { return x.key < y.key; });
+  for (size_t i = 0; i < v.size(); i++) buf[(size_t)g.JW + 2 + i] = v[i].code;
+  hb_order_entry e;
+  e.dev = dev;
+  e.N = N;
+  e.M = M;
+  e.C = g.C;
+  e.P = g.P;
+  e.R = g.R;
+  e.NB = g.NB;
+  e.JW = g.JW;
+  e.r_ns = r_ns;
+  e.L_ns = L_ns;
+  e.lag_ns = lag_ns;
+  e.d_buf = nullptr;
+  HIPCHK(hipMalloc((void **)&e.d_buf, buf.size() * sizeof(unsigned) + 16));
+  HIPCHK(hipMemcpy(e.d_buf, buf.data(), buf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  if (g_hb_orders.size() >= 16) {  // (shapes come and go in tests: keep the table small)
+    (void)hipFree(g_hb_orders.front().d_buf);
+    g_hb_orders.erase(g_hb_orders.begin());
+  }
+  g_hb_orders.push_back(e);
+  *rec_off = e.d_buf;
+  *order = e.d_buf + g.JW + 2;
+  return 0;
+}
+
+int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
+  const unsigned N = A.N, M = A.M;
+  const hb_geom g = hb_geometry(N, M, D);
+  if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
+  if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
+  if (dot) return stb_fail("stb_fill_S: the halo-block form has no summing kernel");
+  hb_args X;
+  memset(&X, 0, sizeof(X));
+  X.hdr = (unsigned *)ws;
+  X.progress = (unsigned *)(ws + g.off_prog);
+  X.ck_e = (unsigned *)(ws + g.off_cke);
+  X.ck_v = (unsigned long long *)(ws + g.off_ckv);
+  X.n_rec = g.n_rec;
+  X.D = D;
+  X.B = g.B;
+  X.JW = g.JW;
+  X.NB = g.NB;
+  X.P = g.P;
+  X.R = g.R;
+  X.HL = g.HL;
+  X.U = g.U;
+  X.n_tiles = g.n_tiles;
+  X.n_spine = (unsigned)g.B * (unsigned)D;
+  X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
+  X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
+  if (X.poll_nap < 1) X.poll_nap = 1;
+  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", 6);
+  X.diag = stb_env_int("STB_HB_DIAG", 0);
+  X.spare_work = stb_env_int("STB_HB_SPARE", 0);
+  if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
+  const char *tl_file = getenv("STB_HB_TIMELINE");
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4;
+  if (tl_file && *tl_file) {
+    HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
+    HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
+  }
+  HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  *hdr_out = X.hdr;
+  stb_launch_s1(A, D, st);
+  // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
+  int dev = 0, cus = 256;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int per_cu = stb_env_int("STB_HB_WG_PER_CU", 1);
+  unsigned grid = (unsigned)(cus * per_cu);
+  const unsigned min_workers = (unsigned)stb_env_int("STB_HB_MIN_WORKERS", 64);
+  if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
+  if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
+  const size_t shm = (g.n_tiles <= HB_ORDER_LDS) ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
+  switch (g.C) {
+    case 1: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+    case 2: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+    default: STB_LAUNCH_SHM((k_fill_hb<4, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+  }
+  HIPCHK(hipGetLastError());
+  if (X.dbg) {
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(dbg_words);
+    HIPCHK(hipMemcpy(h.data(), X.dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(X.dbg);
+    FILE *f = fopen(tl_file, "wb");
+    if (f) {
+      const int hd[8] = {g.JW, g.NB, (int)g.n_tiles, g.C, g.P, g.R, g.U, D};
+      fwrite(hd, sizeof(int), 8, f);
+      std::vector<unsigned> ord(g.n_tiles);
+      HIPCHK(hipMemcpy(ord.data(), X.order, (size_t)g.n_tiles * sizeof(unsigned), hipMemcpyDeviceToHost));
+      fwrite(ord.data(), sizeof(unsigned), g.n_tiles, f);
+      fwrite(h.data(), 8, dbg_words, f);
+      fclose(f);
+    }
+  }
+  return 0;
+}

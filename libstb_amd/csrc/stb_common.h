@@ -146,6 +146,12 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
 unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D);  // partial sums per table of the summing form
 unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D);  // spine workgroups it launches for D tables
 
+// halo-block form (fill_hb.hip): a spine that walks blocks of rows alone + tile workers, one launch
+bool stb_hb_eligible(unsigned N, unsigned M, int D);
+size_t stb_hb_workspace(unsigned N, unsigned M, int D);
+int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // own columns of a strip, rows of a block
+int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
+
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
 #define STB_ROWS_LOGDOM 1

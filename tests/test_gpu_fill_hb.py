@@ -1,0 +1,129 @@
+"""GPU parity of the halo-block fill form (k_fill_hb: a spine that walks blocks of rows behind a halo,
+alone, + tile workers; libstb_amd/csrc/fill_hb.hip) through the C ABI, against the oracle's table
+(reference recurrence lib/stable.c:380-388).  Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import numpy as np
+import pytest
+
+import orc
+from libstb_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _check_tables(T, a, N, M):
+    for d in range(T.D):
+        S1, tab = orc.fill_S(float(a[d]), N, M)
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got)), (N, M, d)
+        assert orc.close(got, tab, TOL), (N, M, d, orc.max_err(got, tab))
+        assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
+
+
+@pytest.mark.parametrize("C,P,R", [(1, 7, 32), (1, 3, 16), (2, 7, 48), (2, 1, 32), (2, 4, 16), (4, 7, 48), (4, 2, 24), (4, 5, 8)])
+def test_hb_geometries_agree(monkeypatch, C, P, R):
+    """every strip shape (columns per lane, spine waves per workgroup, rows per block) computes the same
+    tables and no wave gives up waiting (several strips, several workgroups per table, several tables)"""
+    monkeypatch.setenv("STB_HB_C", str(C))
+    monkeypatch.setenv("STB_HB_P", str(P))
+    monkeypatch.setenv("STB_HB_ROWS", str(R))
+    L = capi.lib()
+    a = np.array([0.05, 0.5, 0.93])
+    T = capi.DeviceTables(900, 700, D=3)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    _check_tables(T, a, 900, 700)
+
+
+def test_hb_random_shapes_vs_oracle():
+    rng = np.random.default_rng(20261005)
+    L = capi.lib()
+    before = L.stb_fill_fallbacks()
+    for _ in range(14):
+        N = int(rng.integers(3, 2600))
+        M = int(rng.integers(2, N + 1))
+        D = int(rng.integers(1, 5))
+        a = np.round(rng.uniform(0.0, 0.99, size=D), 6)
+        T = capi.DeviceTables(N, M, D=D)
+        T.tables.fill_(float("nan"))
+        T.fill(a, capi.FILL_HB)
+        T.status()
+        _check_tables(T, a, N, M)
+    assert L.stb_fill_fallbacks() == before
+
+
+def test_hb_short_periods(monkeypatch):
+    """a renormalisation period shorter than the block asked for shortens the block"""
+    monkeypatch.setenv("STB_FILL_P", "20")
+    a = np.array([0.2, 0.8])
+    T = capi.DeviceTables(1300, 1100, D=2)
+    T.tables.fill_(float("nan"))
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    _check_tables(T, a, 1300, 1100)
+
+
+def test_hb_more_spine_workgroups_than_compute_units(monkeypatch):
+    """one-wave spine workgroups of 32 columns, 40 tables of 3000 columns: thousands of spine workgroups
+    for a grid that holds a few hundred at once -- a strip only ever waits for a strip with a smaller ticket"""
+    monkeypatch.setenv("STB_HB_C", "1")
+    monkeypatch.setenv("STB_HB_P", "1")
+    D, N = 40, 3000
+    L = capi.lib()
+    a = synth.discount_grid(64)[:D]
+    T = capi.DeviceTables(N, N, D=D)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before       # (finished, not rescued by the other form after a time-out)
+    T2 = capi.DeviceTables(N, N, D=D)
+    T2.fill(a, capi.FILL_PC)
+    for d in (0, 7, D - 1):
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got))
+        assert orc.max_err(got, T2.packed_host(d)) <= TOL
+
+
+def test_hb_gives_up_instead_of_hanging(monkeypatch):
+    """every wait of the halo-block form is bounded: with the bound at zero whoever has to wait records an
+    error and everybody runs to the end; stb_fill_status then repeats the fill with the producer/consumer
+    form -- or reports the failure when that is switched off"""
+    L = capi.lib()
+    S1, tab = orc.fill_S(0.5, 3000, 3000)
+    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    monkeypatch.setenv("STB_CHAIN_NO_FALLBACK", "1")
+    T = capi.DeviceTables(3000, 3000, D=1)
+    T.fill([0.5], capi.FILL_HB)
+    with pytest.raises(capi.StbError):
+        T.status()
+    monkeypatch.delenv("STB_CHAIN_NO_FALLBACK")
+    before = L.stb_fill_fallbacks()
+    T.tables.fill_(float("nan"))
+    T.fill([0.5], capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before + 1
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
+    monkeypatch.delenv("STB_CHAIN_TIMEOUT_MS")
+    T.tables.fill_(float("nan"))
+    T.fill([0.5], capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before + 1
+    assert orc.max_err(T.packed_host(0), tab) <= TOL
+
+
+def test_hb_10000_full_table_vs_oracle():
+    """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's"""
+    N, a = 10000, 0.5
+    T = capi.DeviceTables(N, N, D=1)
+    T.tables.fill_(float("nan"))
+    T.fill([a], capi.FILL_HB)
+    T.status()
+    S1, tab = orc.fill_S(a, N, N)
+    got = T.packed_host(0)
+    err = np.abs(got - tab) / np.maximum(1.0, np.abs(tab))
+    assert np.all(np.isfinite(got))
+    assert float(err.max()) <= TOL, float(err.max())
