@@ -45,7 +45,7 @@ from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 TRAFFIC_DB = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
-FORM_NAMES = {2: "pc", 3: "chain", 4: "ck"}
+FORM_NAMES = {2: "pc", 3: "chain", 4: "ck", 6: "hb"}
 
 
 def cpu_baseline(N: int, M: int, a: float):
@@ -452,7 +452,8 @@ def main():
     if rank == 0:
         FORMS = {2: ("pc", "k_fill_pc", "k_fill_pc (producer wave + consumer waves per column block, launched per 128 rows)"),
                  3: ("chain", "k_fill_chain", "k_fill_chain (one launch per fill: producer, consumer and fetcher waves per column block)"),
-                 4: ("ck", "k_fill_ck", "k_fill_ck (one launch per fill: recurrence-only spine waves + tile workers)")}
+                 4: ("ck", "k_fill_ck", "k_fill_ck (one launch per fill: recurrence-only spine waves + tile workers)"),
+                 6: ("hb", "k_fill_hb", "k_fill_hb (one launch per fill: spine waves that walk blocks of rows alone behind a halo + tile workers)")}
         fname, kprefix, knote = FORMS.get(form if args.variant == capi.FILL_SCALED else -1, ("other", "k_fill", f"fill variant {args.variant}"))
         launches = max(kn.value, 1)
         avg_launch_ms = kms.value / launches

@@ -85,7 +85,8 @@ int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_ta
                uint64_t table_stride, double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes,
                int variant, void *stream);
 /* what stb_fill_S will use for these sizes: columns per lane, rows per launch, kernel launches;
- * returns the form: 2 producer/consumer, 3 chain, 4 checkpointed (spine + tile workers), 5 another */
+ * returns the form: 2 producer/consumer, 3 chain, 4 checkpointed (spine + tile workers), 5 another,
+ * 6 halo blocks (spine that walks blocks of rows alone + tile workers) */
 int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
 /* Completion status of the last chain-form fill issued by THIS thread (waits for it): 0, or non-zero
  * with stb_last_error() set when a column block gave up waiting for its neighbour (the fill's

@@ -151,12 +151,22 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
          cells <= (uint64_t)stb_env_int("STB_CK_MAX_MCELLS", 1000) * 1000000ull;
 }
 
-// the halo-block form: STB_HB=1 wherever it is eligible (default: off until measured)
+// The halo-block form (a spine that walks blocks of rows alone behind a halo + tile workers) wherever a table has
+// a few hundred rows and the batch stays below ~1.25 x 10^9 cells (24 tables of 10^4 columns), where the table
+// traffic of the producer/consumer form's many launches catches up.  (MI355X, tools/ab_ck.py, ms: N = M = 10^4:
+// 1 table 0.36 against 0.68 chain / 0.66-0.69 checkpointed, 2 tables 0.46 against 0.69, 4 tables 0.61 against
+// 0.73, 8 tables 0.88-0.92 against 0.89-0.96, 16 tables 1.61-1.65 against 1.64, 24 tables 2.33 against 2.41 pc,
+// 32 tables 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
+// 0.283, 8 tables 0.25 against 0.34, 32 tables 0.59 against 0.58, 64 tables 1.16 against 1.04 pc; N = M = 2000:
+// 1 / 3 / 8 tables 0.11-0.14 / 0.10 / 0.145 against 0.15 chain; N = M = 1000: 0.06-0.08 against 0.08;
+// N = M = 20000: 1 table 0.93 against 1.35, 4 tables 1.81 = checkpointed.)
+// STB_HB=0 / 1 switches it off / on wherever it is eligible.
 static bool hb_wins(unsigned N, unsigned M, int D) {
   const int force = stb_env_int("STB_HB", -1);
   if (force == 0 || g_dot_req_active() || !stb_hb_eligible(N, M, D)) return false;
   if (force > 0) return true;
-  return false;
+  const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
+  return N >= (unsigned)stb_env_int("STB_HB_MIN_N", 512) && cells <= (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull;
 }
 
 enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK, FORM_HB };

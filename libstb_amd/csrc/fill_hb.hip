@@ -28,8 +28,8 @@
 // the last halo lane of strip 0, whose halo needs no neighbour (column 0 is identically zero): strip 0
 // computes it along.  The state before block b is row 1 + b R; row 1 is S^1_1 = 1.
 //
-// A record word is its own flag: 0 means "not written yet" (an exact zero travels as -0.0, exponents
-// carry an offset); records are written with write-through stores and read with L1-bypassing loads.
+// A record word is its own flag: 0 means "not written yet" (significands, which are never negative, travel
+// with the sign bit set, exponents carry an offset); records are written with write-through stores and read with L1-bypassing loads.
 // Every wait is bounded; on expiry the waiter records an error in the header and everybody runs to the
 // end (stb_fill_status repeats the fill with k_fill_pc).
 
@@ -39,11 +39,14 @@
 
 #include "fill_chain.h"
 
-#define HB_NW 8          // waves per workgroup: up to 7 spine waves and a fetcher
+#define HB_NW 8          // waves per workgroup: up to HB_PMAX spine waves and a fetcher
+#define HB_PMAX 7
 #define HB_SLOTS 4       // ring of hand-overs between two spine waves of a workgroup (blocks)
 #define HB_FSLOTS 8      // ring of hand-overs from the fetcher to spine wave 0
 #define HB_MAXHL 32      // halo lanes at most
 #define HB_EOFF32 (1u << 30)
+#define HB_WRITTEN 0x8000000000000000ull  // a record's significands (never negative) travel with the sign bit set
+#define HB_DOT_NQ 12       // groups of 4 rows in a block at most (summing form)
 #define HB_ORDER_LDS 8192  // tiles of a table whose order list is copied to LDS (32 KB)
 #define HB_PROG_STRIDE 32  // words between two strips' progress words: a line each (a strip's waiting workers poll
                            // the word its spine wave writes; 125 strips' words in four lines made those lines the
@@ -70,6 +73,12 @@ struct hb_args {
   int nap_block;               // s_sleep argument of a worker per block its inputs are away
   int diag;                    // STB_HB_DIAG: 1 the workers wait for the whole spine
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
+  // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
+  // per item = (record index of the tile) * HB_DOT_NQ + (group of 4 rows of the block), and where the sums go
+  const unsigned *item_ptr;        // [n_rec * HB_DOT_NQ + 1] first entry of every item
+  const unsigned short *ent_pos;   // row-in-group << 8 | element of the wave (halo included) of each occurring cell
+  const unsigned *ent_cnt;         // its occurrence count
+  double *dotp;                    // [D][n_tiles] sum of count * log S per tile
   unsigned long long *dbg;     // STB_HB_TIMELINE: wall-clock stamps, table 0: [JW][NB + 2] spine (start, block starts, end),
                                // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
 };
@@ -87,7 +96,7 @@ __device__ __forceinline__ void hb_store16(const void *sbase, unsigned byte_off,
 }
 
 // ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
-__device__ __forceinline__ void hb_logs8(const double (&x)[8], int myep, const double2 *lt, int one_hi, double (&val)[8]) {
+__device__ __forceinline__ void hb_logs8(const double (&x)[8], const int (&ep8)[8], const double2 *lt, int one_hi, double (&val)[8]) {
   double z[8], kf[8], r[8], pl[8];
   double2 tt[8];
 #pragma unroll
@@ -96,7 +105,7 @@ __device__ __forceinline__ void hb_logs8(const double (&x)[8], int myep, const d
   for (int u = 0; u < 8; u++) {
     const int hi = __double2hiint(x[u]);
     z[u] = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x[u]));
-    kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + myep);
+    kf[u] = (double)((int)((hi >> 20) & 0x7ff) - 1023 + ep8[u]);
   }
 #pragma unroll
   for (int u = 0; u < 8; u++) r[u] = fma(z[u], tt[u].x, -1.0);
@@ -112,18 +121,16 @@ __device__ __forceinline__ void hb_logs8(const double (&x)[8], int myep, const d
   for (int u = 0; u < 8; u++) val[u] = fma(kf[u], 0.693147180559945309417, fma(r[u], pl[u], tt[u].y));
 }
 
-// renormalise a lane: the largest of its C significands back to 2^-PC_BIAS * [0.5,1)
+// renormalise a lane: the largest of its C significands (none is negative) back to 2^-PC_BIAS * [0.5,1)
 template <int C>
 __device__ __forceinline__ void hb_renorm(double (&v)[C], int &ep) {
-  int kmax = -4000;
+  double vmax = v[0];
 #pragma unroll
-  for (int i = 0; i < C; i++)
-    if (v[i] != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(v[i]));
-  if (kmax > -4000) {
+  for (int i = 1; i < C; i++) vmax = fmax(vmax, v[i]);
+  const int sh = (vmax != 0.0) ? __builtin_amdgcn_frexp_exp(vmax) + PC_BIAS : 0;
 #pragma unroll
-    for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -kmax - PC_BIAS);
-    ep += kmax + PC_BIAS;
-  }
+  for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -sh);
+  ep += sh;
 }
 
 // eight rows of the recurrence: lane l takes the last column of lane l - 1 (lane 0: nothing), scaled
@@ -144,21 +151,26 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 template <int C, int DOT>
 __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
-  static_assert(DOT == 0, "the summing form is not written yet");
+  constexpr int NG = (C == 4 && DOT == 0) ? 2 : 1, CG = C / NG;  // a worker lane's groups of adjacent elements (see the workers)
   __shared__ double2 lt[128];
-  __shared__ __attribute__((aligned(16))) double xv[HB_NW - 1][HB_SLOTS][HB_MAXHL * C];
-  __shared__ int xe[HB_NW - 1][HB_SLOTS][HB_MAXHL];
+  // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
+  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
+  __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
   __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
   __shared__ int fe[HB_FSLOTS][HB_MAXHL];
   __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
   __shared__ unsigned s_ticket;
-  extern __shared__ unsigned s_order[];
+  // dynamic segment.  Storing form: the tile order, when it fits (a ticket then costs no dependent global load).
+  // Summing form: per wave four rows of the wave's 64 C significands.
+  extern __shared__ __attribute__((aligned(16))) double hb_dyn[];
+  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn);
+  __shared__ int w_se[DOT ? HB_NW : 1][64];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
-  const bool order_in_lds = X.n_tiles <= HB_ORDER_LDS;
+  const bool order_in_lds = DOT == 0 && X.n_tiles <= HB_ORDER_LDS;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
   __syncthreads();
@@ -247,37 +259,25 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             }
             lds_post(&posted[w], b + 1);
           }
-          // ---- the record of the block: the own lanes as they stand before it ----
-          {
-            // (halo lanes of strip 0 are exact: they go to strip index 0 at the place a left neighbour's
-            // rightmost lanes would have)
-            if ((own || jw == 0) && !(HB_DIAG & 1)) {
-              unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
+          // ---- the record of the block: the own lanes as they stand before it (the halo lanes of strip 0 are
+          // exact: they go to strip index 0 at the place a left neighbour's rightmost lanes would have).
+          // (A publisher wave that takes the row from LDS and stores it in the spine's stead was tried: the spine
+          // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
+          if ((own || jw == 0) && !(HB_DIAG & 1)) {
+            unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
 #pragma unroll
-              for (int i = 0; i < C; i++) {
-                unsigned long long bits = (unsigned long long)__double_as_longlong(v[i]);
-                if ((bits << 1) == 0) bits = CH_NEGZERO;
-                __hip_atomic_store(dst + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if constexpr ((HB_DIAG & 2) != 0) {
-#pragma unroll
-                for (int i = 0; i < C; i++) {
-                  unsigned long long bits = (unsigned long long)__double_as_longlong(v[i]);
-                  if ((bits << 1) == 0) bits = CH_NEGZERO;
-                  __hip_atomic_store(dst + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < C; i++)
+              __hip_atomic_store(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
           if (jw > 0) {
             wait_ge(left_cnt, b + 1, 0x100u);
             asm volatile("" ::: "memory");
             if (lane < HL) {
-              const double *src = left_v + (size_t)(b & left_mask) * (HB_MAXHL * C) + lane * C;
+              const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
 #pragma unroll
               for (int i = 0; i < C; i++) v[i] = src[i];
               ep = left_e[(b & left_mask) * HB_MAXHL + lane];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           if (want && grp < k) {
             double *dst = &fv[mb & (HB_FSLOTS - 1)][sub * C];
 #pragma unroll
-            for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)bv[i]);
+            for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)(bv[i] & ~HB_WRITTEN));
             fe[mb & (HB_FSLOTS - 1)][sub] = (int)(be - HB_EOFF32);
           }
           bb += k;
@@ -437,39 +437,79 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       // Everything is asked for at once, without looking at the spine's progress first: what has been written
       // is non-zero.  Only when something is missing is the progress word read, to sleep about as long as the
       // missing blocks take. ----
+      // A worker lane holds NG groups of CG adjacent elements.  With 4 elements per spine lane the two groups
+      // lie a kilobyte apart -- elements 2 l, 2 l + 1 and 128 + 2 l, 129 + 2 l of the wave's 256 -- so that each
+      // of a row's two store instructions covers ONE contiguous kilobyte (8 whole lines) instead of 64 pieces
+      // of 16 bytes 32 apart: half the requests to the memory side, which is what a compute unit's store rate
+      // is made of (tools/ubench/wcap.hip: 129 against 65 GB/s per compute unit).  A group takes its
+      // exponent from the spine lane its elements belong to.
       const size_t tab_rec = (size_t)d * X.n_rec;
-      const bool own = lane >= HL;
       const int bO = hb_first_block(jw, UC, R), bL = (jw > 0) ? hb_first_block(jw - 1, UC, R) : 0;
-      const size_t rec = own ? tab_rec + X.rec_off[jw + 1] + (size_t)(b - bO) : tab_rec + X.rec_off[jw] + (size_t)(b - bL);
-      const int slot = own ? lane - HL : lane + U - HL;
-      const unsigned long long *ckv = X.ck_v + (rec * U + slot) * C;
-      const unsigned *cke = X.ck_e + rec * U + slot;
+      const size_t recO = tab_rec + X.rec_off[jw + 1] + (size_t)(b - bO), recL = tab_rec + X.rec_off[jw] + (size_t)(b - bL);
+      const unsigned long long *ckv[NG];
+      const unsigned *cke[NG];
+      bool own[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int L = (NG == 2) ? g * 32 + (lane >> 1) : lane;  // the spine lane of the group
+        const int i0 = (NG == 2) ? 2 * (lane & 1) : 0;          // ... and the group's first element in it
+        own[g] = L >= HL;
+        const size_t rec = own[g] ? recO : recL;
+        const int slot = own[g] ? L - HL : L + U - HL;
+        ckv[g] = X.ck_v + (rec * U + slot) * C + i0;
+        cke[g] = X.ck_e + rec * U + slot;
+      }
       const unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
-      double v[C], coef[C];
-      int ep = 0;
+      // summing form: first entry of each of the tile's groups of four rows (lane q: group q; lane NQ: the end)
+      unsigned ip = 0;
+      int qe = 0;  // groups below it have occurring cells
+      if constexpr (DOT != 0) {
+        const int NQ = R / 4;
+        const unsigned tix = (unsigned)(recO - tab_rec);
+        if (lane <= NQ) ip = X.item_ptr[(size_t)tix * HB_DOT_NQ + lane];
+        const unsigned ipn = (unsigned)__shfl_down((int)ip, 1);
+        const unsigned long long hm = __ballot(lane < NQ && ipn != ip);
+        qe = hm ? 64 - (int)__builtin_clzll(hm) : 0;
+        if (qe == 0) {  // none of the tile's cells occurs: nothing to walk, nothing to wait for
+          if (lane == 0) X.dotp[(size_t)d * X.n_tiles + (tix - (unsigned)NB)] = 0.0;
+          continue;
+        }
+      }
+      double v[NG][CG], coef[NG][CG];
+      int ep[NG];
       bool ok = true;
       {
         unsigned spins = 0, tries = 0;
         unsigned long long t_begin = 0;
         for (;;) {
-          unsigned long long bv[C];
+          unsigned long long bv[NG][CG];
+          unsigned be[NG];
 #pragma unroll
-          for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(ckv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned be = __hip_atomic_load(cke, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bool have = be != 0;
+          for (int g = 0; g < NG; g++) {
 #pragma unroll
-          for (int i = 0; i < C; i++) have = have && bv[i] != 0;
+            for (int i = 0; i < CG; i++) bv[g][i] = __hip_atomic_load(ckv[g] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            be[g] = __hip_atomic_load(cke[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          bool have = true;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            have = have && be[g] != 0;
+#pragma unroll
+            for (int i = 0; i < CG; i++) have = have && bv[g][i] != 0;
+          }
           if (__all(have)) {
 #pragma unroll
-            for (int i = 0; i < C; i++) v[i] = __longlong_as_double((long long)bv[i]);
-            ep = (int)(be - HB_EOFF32);
+            for (int g = 0; g < NG; g++) {
+#pragma unroll
+              for (int i = 0; i < CG; i++) v[g][i] = __longlong_as_double((long long)(bv[g][i] & ~HB_WRITTEN));
+              ep[g] = (int)(be[g] - HB_EOFF32);
+            }
             break;
           }
           // Not there yet.  Thousands of waves may be waiting like this while a table's first rows are walked,
-          // and every look at a record is 64 lanes' worth of requests to the memory side that the spine's own
-          // stores and hand-overs queue behind (one table of 10^4: 0.71 ms with every wave re-reading its
-          // records, 0.40 with a third of the waves): wait on the strip's progress word alone -- one request
-          // per look -- sleeping about as long as the blocks still missing take, then read the records again.
+          // and every look at a record is 64 lanes' worth of requests to the memory side: wait on the strip's
+          // progress word alone -- one request per look, a line of its own -- sleeping about as long as the
+          // blocks still missing take, then read the records again.
           for (;;) {
             const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done >= (unsigned)(b + 1)) break;
@@ -508,31 +548,136 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       if (!ok) break;
       if (wdbg) wdbg[1] = wall_clock64();
       const double a = A.a[d];
-      const int m0 = 2 + (jw * U - HL + lane) * C;
+      const int mE0 = 2 + (jw * U - HL) * C;  // the column of the wave's first element (halo included)
       const double n1 = (double)(1 + b * R);
 #pragma unroll
-      for (int i = 0; i < C; i++) coef[i] = n1 - (double)(m0 + i) * a;
-      const int dl = wave_shr1(ep, ep) - ep;
-      const double s = ldexp(1.0, min(max(dl, -1100), 220));
+      for (int g = 0; g < NG; g++) {
+        const int m0 = mE0 + ((NG == 2) ? g * 128 + 2 * lane : lane * C);
+#pragma unroll
+        for (int i = 0; i < CG; i++) coef[g][i] = n1 - (double)(m0 + i) * a;
+      }
+      // what a group's first element takes from the element to its left, which lives in lane l - 1 -- or,
+      // for the second group of lane 0, in the first group of lane 63 -- under that lane's exponent
+      double s[NG], z1 = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int dl = wave_shr1(ep[g], ep[g]) - ep[g];
+        s[g] = (lane == 0) ? 0.0 : ldexp(1.0, min(max(dl, -1100), 220));
+      }
+      if constexpr (NG == 2) {
+        const int e63 = __builtin_amdgcn_readlane(ep[0], 63);
+        if (lane == 0) z1 = ldexp(1.0, min(max(e63 - ep[1], -1100), 220));
+      }
+      if constexpr (DOT != 0) {
+        // ---- the tile as a sum: no logs but those of the cells that occur, nothing stored.  Four rows at a
+        // time go to LDS (this wave's own area), then every lane looks one occurring cell up; the first 64
+        // cells of every group's list were asked for when the tile was taken. ----
+        constexpr int WS = 64 * C;
+        double *stage = hb_dyn + (size_t)wave * (4 * WS);
+        int *se = &w_se[DOT ? wave : 0][0];
+        unsigned short pp[HB_DOT_NQ];
+        unsigned cc[HB_DOT_NQ];
+#pragma unroll
+        for (int q = 0; q < HB_DOT_NQ; q++) {
+          pp[q] = 0;
+          cc[q] = 0;
+          if (q < qe) {
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)ip, q), b1 = (unsigned)__builtin_amdgcn_readlane((int)ip, q + 1);
+            if (b0 + lane < b1) {
+              pp[q] = X.ent_pos[b0 + lane];
+              cc[q] = X.ent_cnt[b0 + lane];
+            }
+          }
+        }
+        se[lane] = ep[0];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < HB_DOT_NQ; q++) {
+          if (q < qe) {
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)ip, q), b1 = (unsigned)__builtin_amdgcn_readlane((int)ip, q + 1);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const double t0 = wave_shr1_zero(v[0][C - 1]) * s[0];
+#pragma unroll
+              for (int i = C - 1; i >= 1; i--) v[0][i] = fma(coef[0][i], v[0][i], v[0][i - 1]);
+              v[0][0] = fma(coef[0][0], v[0][0], t0);
+#pragma unroll
+              for (int i = 0; i < C; i++) coef[0][i] += 1.0;
+              if (b0 != b1) {  // (a group none of whose cells occurs is only walked)
+                if constexpr (C == 4) {
+                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4) = hb_double2{v[0][0], v[0][1]};
+                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4 + 2) = hb_double2{v[0][2], v[0][3]};
+                } else if constexpr (C == 2) {
+                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 2) = hb_double2{v[0][0], v[0][1]};
+                } else {
+                  stage[u * WS + lane] = v[0][0];
+                }
+              }
+            }
+            if (b0 != b1) {
+              unsigned kk = b0 + lane, pos = pp[q], cnt = cc[q];
+              for (;;) {
+                if (kk < b1) {
+                  const int cw = (int)(pos & 255u);
+                  const double val = bfp_log(stage[(pos >> 8) * WS + cw], se[cw / C], lt);
+                  acc += (double)cnt * val;
+                }
+                if (kk - lane + 64 >= b1) break;  // (wave-uniform)
+                kk += 64;
+                pos = cnt = 0;
+                if (kk < b1) {
+                  pos = X.ent_pos[kk];
+                  cnt = X.ent_cnt[kk];
+                }
+              }
+            }
+          }
+        }
+        // fixed-shape tree over the wave: the same bits on every run, whoever computed the tile
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) X.dotp[(size_t)d * X.n_tiles + ((unsigned)(recO - tab_rec) - (unsigned)NB)] = acc;
+      } else {
       double *table = A.tables + (uint64_t)d * A.tstride;
       const unsigned e0 = (unsigned)(jw * UC);  // first own element of the strip
-      // (the lane offset counts from the strip's first halo lane: the base may lie before the row)
-      const unsigned voff = (unsigned)(lane * C) * 8u;
+      // (the lane offset counts from the wave's first halo element: the base may lie before the row)
+      const unsigned voff = (unsigned)(lane * CG) * 8u;
       unsigned n = 2u + (unsigned)(b * R);  // the row the next step produces
       uint64_t roff = stb_row_offset(n, M);
       constexpr int RS = 8 / C;  // rows converted together: eight cells in flight
+      int ep8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) ep8[u] = ep[(NG == 2) ? ((u >> 1) & 1) : 0];
       for (int r = 0; r < R; r += RS) {
         double x[8], val[8];
 #pragma unroll
         for (int u = 0; u < RS; u++) {
-          hb_row<C>(v, coef, s);
+          if constexpr (NG == 1) {
+            const double t0 = wave_shr1_zero(v[0][CG - 1]) * s[0];
 #pragma unroll
-          for (int i = 0; i < C; i++) x[u * C + i] = v[i];
+            for (int i = CG - 1; i >= 1; i--) v[0][i] = fma(coef[0][i], v[0][i], v[0][i - 1]);
+            v[0][0] = fma(coef[0][0], v[0][0], t0);
+          } else {
+            const double ra = wave_ror1(v[0][1]), rb = wave_shr1_zero(v[1][1]);
+            const double ta = ra * s[0];
+            const double tb = fma(ra, z1, rb * s[1]);
+            v[0][1] = fma(coef[0][1], v[0][1], v[0][0]);
+            v[0][0] = fma(coef[0][0], v[0][0], ta);
+            v[1][1] = fma(coef[1][1], v[1][1], v[1][0]);
+            v[1][0] = fma(coef[1][0], v[1][0], tb);
+          }
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < CG; i++) {
+              coef[g][i] += 1.0;
+              x[u * C + g * CG + i] = v[g][i];
+            }
         }
         // (rows none of whose cells lies in the strip's own columns, and rows outside the table, are only walked)
         const unsigned nl = n + RS - 1;
         if (nl >= 3 && n <= N && e0 < stb_row_len(min(nl, N), M)) {
-          hb_logs8(x, ep, lt, one_hi, val);
+          hb_logs8(x, ep8, lt, one_hi, val);
 #pragma unroll
           for (int u = 0; u < RS; u++) {
             const unsigned nu = n + u;
@@ -540,15 +685,13 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
               const double *rp = table + roff + e0 - (size_t)(HL * C);
               if constexpr ((HB_DIAG & 8) != 0) {
                 asm volatile("" ::"v"(val[u * C]), "v"(val[u * C + C - 1]));
-              } else if (own) {
-                if constexpr (C == 1) {
-                  store_sbase(rp, voff, val[u]);
-                } else if constexpr (C == 2) {
-                  hb_store16(rp, voff, val[u * 2], val[u * 2 + 1]);
-                } else {
-                  hb_store16(rp, voff, val[u * 4], val[u * 4 + 1]);
-                  hb_store16(rp + 2, voff, val[u * 4 + 2], val[u * 4 + 3]);
-                }
+              } else if constexpr (C == 1) {
+                if (own[0]) store_sbase(rp, voff, val[u]);
+              } else if constexpr (C == 2) {
+                if (own[0]) hb_store16(rp, voff, val[u * 2], val[u * 2 + 1]);
+              } else {
+                if (own[0]) hb_store16(rp, voff, val[u * 4], val[u * 4 + 1]);
+                if (own[1]) hb_store16(rp + 128, voff, val[u * 4 + 2], val[u * 4 + 3]);
               }
             }
             roff += stb_row_pitch(nu, M);
@@ -558,6 +701,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           for (int u = 0; u < RS; u++) roff += stb_row_pitch(n + u, M);
         }
         n += RS;
+      }
       }
       if (wdbg) {
         unsigned hw, xcc;
@@ -580,16 +724,25 @@ struct hb_geom {
   bool ok;
 };
 
-static hb_geom hb_geometry(unsigned N, unsigned M, int D) {
+static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) {
   hb_geom g;
   memset(&g, 0, sizeof(g));
   g.ok = false;
   if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return g;
-  const uint64_t total_cells = (uint64_t)D * stb_table_cells(N, M);
-  g.C = stb_env_int("STB_HB_C", total_cells < 150000000ull ? 2 : 4);
+  // 2 columns per lane walk faster (26 against 32.5 ns a row) but need 2.6 times the spine waves of 4 (80
+  // against 208 own columns a strip): 2 while the spine waves of all tables fit on ~80 compute units at one per
+  // SIMD.  (MI355X, tools/ab_ck.py: N = M = 10^4, 1 table 0.36 against 0.46-0.50 ms, 2 tables 0.46 against 0.49,
+  // 4 tables 0.78 against 0.61; N = M = 4000, 3 tables 0.198 against 0.206, 8 tables 0.31 against 0.25.)
+  {
+    const unsigned cmax0 = (M < N - 1) ? M : N - 1;
+    const uint64_t waves2 = (uint64_t)D * ((cmax0 - 1 + 79) / 80);
+    g.C = stb_env_int("STB_HB_C", waves2 <= 320 ? 2 : 4);
+  }
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
-  g.P = stb_env_int("STB_HB_P", HB_NW - 1);
-  if (g.P < 1 || g.P > HB_NW - 1) g.P = HB_NW - 1;
+  // (a summing fill's cell lists are laid out for one strip shape, whatever the number of discounts)
+  if (summing) g.C = 4;
+  g.P = stb_env_int("STB_HB_P", 4);  // (one spine wave per SIMD: two on one slow each other by a third)
+  if (g.P < 1 || g.P > HB_PMAX) g.P = 4;
   // a block is a renormalisation period (or less): rows in eights, halo lanes R / C <= 32
   int Pc = stb_period_rows(N);
   const int Penv = stb_env_int("STB_FILL_P", 0);
@@ -744,12 +897,34 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   return 0;
 }
 
+// what the builder of a summing fill's cell lists has to know: the shape of the tiles and where a strip's
+// records start (device array of JW + 2 words; a tile's record index is its item base)
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
+  const hb_geom g = hb_geometry(N, M, D, true);
+  if (!g.ok || g.R / 4 > HB_DOT_NQ) return 1;
+  const unsigned *rec_off = nullptr, *order = nullptr;
+  if (hb_order_list(g, N, M, &rec_off, &order)) return 1;
+  out->R = g.R;
+  out->UC = g.U * g.C;
+  out->HC = g.HL * g.C;
+  out->NB = g.NB;
+  out->JW = g.JW;
+  out->NQ = HB_DOT_NQ;
+  out->n_tiles = g.n_tiles;
+  out->n_rec = g.n_rec;
+  out->n_spine = (unsigned)g.B * (unsigned)D;
+  out->rec_off = rec_off;
+  return 0;
+}
+
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
   const unsigned N = A.N, M = A.M;
-  const hb_geom g = hb_geometry(N, M, D);
+  const hb_geom g = hb_geometry(N, M, D, dot != nullptr);
   if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
-  if (dot) return stb_fail("stb_fill_S: the halo-block form has no summing kernel");
+  if (dot && (!dot->item_ptr || dot->col0 != 3))
+    return stb_fail("stb_fill_S: the halo-block form sums over cell lists built for its tiles");
+  if (dot && g.R / 4 > HB_DOT_NQ) return stb_fail("stb_fill_S: blocks of %d rows are too long for the summing form", g.R);
   hb_args X;
   memset(&X, 0, sizeof(X));
   X.hdr = (unsigned *)ws;
@@ -773,6 +948,13 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", 6);
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
+  if (dot) {
+    X.item_ptr = dot->item_ptr;
+    X.ent_pos = dot->ent_pos;
+    X.ent_cnt = dot->ent_cnt;
+    X.dotp = dot->dotp;
+    const_cast<dot_request *>(dot)->parts_per_table = (int)g.n_tiles;
+  }
   if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4;
@@ -787,16 +969,32 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   int dev = 0, cus = 256;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // ... as many workers as the spine can feed: it hands out D tables' rows at its own pace, ~N / 80 workgroups'
+  // worth per table; more only wait (one table of 10^4: 0.36 ms with 64 worker workgroups, 0.37-0.385 with 224;
+  // N = 2000: 0.108 against 0.138; N = 1000: 0.061 against 0.079), and waiting is not free (see the workers)
   const int per_cu = stb_env_int("STB_HB_WG_PER_CU", 1);
   unsigned grid = (unsigned)(cus * per_cu);
-  const unsigned min_workers = (unsigned)stb_env_int("STB_HB_MIN_WORKERS", 64);
+  const unsigned min_workers = (unsigned)stb_env_int("STB_HB_MIN_WORKERS", 48);
+  {
+    const uint64_t fed = (uint64_t)D * N / 80;
+    const uint64_t want = (uint64_t)X.n_spine + (fed > min_workers ? fed : min_workers);
+    if (want < grid) grid = (unsigned)want;
+  }
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
-  const size_t shm = (g.n_tiles <= HB_ORDER_LDS) ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
-  switch (g.C) {
-    case 1: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-    case 2: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-    default: STB_LAUNCH_SHM((k_fill_hb<4, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+  if (dot) {
+    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
+    switch (g.C) {
+      case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
+    }
+  } else {
+    const size_t shm = (g.n_tiles <= HB_ORDER_LDS) ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
+    switch (g.C) {
+      case 1: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 2: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      default: STB_LAUNCH_SHM((k_fill_hb<4, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+    }
   }
   HIPCHK(hipGetLastError());
   if (X.dbg) {

@@ -35,13 +35,14 @@ struct stb_groups {
   double *d_dotp;
   size_t dotp_elems;
   int fused, fused_ready;
-  // sparse form of the fused evaluation: CSR of the occurring cells per (trip, slice) item, in two layouts,
-  // each built when first needed: [0] slices from column 1 (k_fill_chain), [1] from column 2 (k_fill_ck)
-  unsigned *d_item_ptr[2];
-  unsigned short *d_ent_pos[2];
-  unsigned *d_ent_cnt[2];
+  // sparse form of the fused evaluation: CSR of the occurring cells per item, in three layouts, each built when
+  // first needed: [0] (trip, 64-column slice from column 1) for k_fill_chain, [1] the same from column 2 for
+  // k_fill_ck, [2] (tile, group of 4 rows) for k_fill_hb
+  unsigned *d_item_ptr[3];
+  unsigned short *d_ent_pos[3];
+  unsigned *d_ent_cnt[3];
   unsigned nsg;
-  int lists_ready[2];
+  int lists_ready[3];
   int sparse;
   // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
   double *h_out;  // pinned, [2][Dmax]: what the stream copies the sums to
@@ -115,7 +116,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   const int prev_dev = stb_device_enter(g->dev);
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
-                  g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1]};
+                  g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
+                  g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -255,6 +257,27 @@ __global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, un
   payload[g] = (uint32_t)g;
 }
 
+// the same for the tiles of k_fill_hb: key = (item << 10) | (row in group << 8) | element of the wave (halo included),
+// item = (record index of tile (strip, block)) * NQ + group of 4 rows; row n belongs to block (n - 2) / R
+__global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, hb_dot_info H,
+                               uint64_t *key, uint32_t *payload) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  uint64_t k;
+  if (nn <= 1) k = STB_KEY_SKIP;
+  else if (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
+  else {
+    const unsigned e = tt - 2, j = e / (unsigned)H.UC, cw = (unsigned)H.HC + (e - j * (unsigned)H.UC);
+    const unsigned b = (nn - 2) / (unsigned)H.R, r = (nn - 2) - b * (unsigned)H.R;
+    const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
+    const unsigned rec = H.rec_off[j + 1] + (b - b0);  // (b >= b0: the cell lies on or below the diagonal)
+    k = ((((uint64_t)rec * (unsigned)H.NQ) + (r >> 2)) << 10) | ((uint64_t)(r & 3u) << 8) | cw;
+  }
+  key[g] = k;
+  payload[g] = (uint32_t)g;
+}
+
 // counts[0] = keys below STB_KEY_OTHER (table cells), counts[1] = keys equal to it
 __global__ void k_key_bounds(const uint64_t *key, uint64_t G, uint64_t *counts) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -284,11 +307,11 @@ __global__ void k_gather_pairs(const uint32_t *n, const uint16_t *t, const uint3
   }
 }
 
-__global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigned short *pos, unsigned *item) {
+__global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigned short *pos, unsigned *item, int posbits) {
   const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < *runs) {
-    pos[r] = (unsigned short)(ukey[r] & 511u);
-    item[r] = (unsigned)(ukey[r] >> 9);
+    pos[r] = (unsigned short)(ukey[r] & ((1u << posbits) - 1u));
+    item[r] = (unsigned)(ukey[r] >> posbits);
   }
 }
 
@@ -315,7 +338,10 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
   if (G == 0 || G >= 0xffffffffull) return 0;
   const unsigned nsg = (M + 63) / 64 + 4;
   const unsigned trips = (N - 2 + 7) / 8;
-  const uint64_t nitems64 = (uint64_t)trips * nsg;
+  hb_dot_info H;
+  memset(&H, 0, sizeof(H));
+  if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
+  const uint64_t nitems64 = (which == 2) ? (uint64_t)H.n_rec * (unsigned)H.NQ : (uint64_t)trips * nsg;
   if (nitems64 >= (1ull << 31)) return 0;
   const unsigned nitems = (unsigned)nitems64;
   uint64_t *k0 = nullptr, *k1 = nullptr, *uk = nullptr, *d_counts = nullptr;
@@ -333,7 +359,10 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       stb_fail("stb_groups_aterms: out of device memory");
       break;
     }
-    hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, which ? 2u : 1u, k0, p0);
+    if (which == 2)
+      hipLaunchKernelGGL(k_item_keys_hb, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, k0, p0);
+    else
+      hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, which ? 2u : 1u, k0, p0);
     size_t b1 = 0, b2 = 0;
     if (rocprim::radix_sort_pairs(nullptr, b1, k0, k1, p0, p1, (size_t)G, 0, 64, g->st) != hipSuccess) break;
     if (rocprim::run_length_encode(nullptr, b2, k1, (unsigned)G, uk, cnt, runs, g->st) != hipSuccess) break;
@@ -385,7 +414,8 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       break;
     }
     if (h_runs) {
-      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item);
+      hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item,
+                         which == 2 ? 10 : 9);
       if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
@@ -395,6 +425,9 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
       const size_t ckp = (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax);
       if (ckp > g->dotp_elems) g->dotp_elems = ckp;
+      hb_dot_info H2;
+      if (stb_hb_dot_info(N, M, g->Dmax, &H2) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
+        g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
       if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
         stb_fail("stb_groups_aterms: out of device memory");
         break;
@@ -484,7 +517,7 @@ static int groups_fused_setup(stb_groups_t *g) {
 // (the fused chain fill gave up waiting: the caller repeats the evaluation through stored tables).
 static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v) {
   // (v = STB_FILL_CK with fuse: the summing checkpointed form and its cell lists)
-  const int which = (fuse && v == STB_FILL_CK) ? 1 : 0;
+  const int which = (fuse && v == STB_FILL_HB) ? 2 : ((fuse && v == STB_FILL_CK) ? 1 : 0);
   g->pending = 0;
   g->pend_fb0 = stb_fill_fallbacks();
   HIPCHK(hipEventRecord(g->ev[0], g->st));
@@ -497,14 +530,14 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
       req.ent_pos = g->d_ent_pos[which];
       req.ent_cnt = g->d_ent_cnt[which];
       req.nsg = g->nsg;
-      req.col0 = which ? 2 : 1;
+      req.col0 = which + 1;
     } else {
       req.cnt = g->d_cnt;
     }
     req.dotp = g->d_dotp;
     stb_set_dot_request(&req);
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
-                              g->ws_fill, which ? STB_FILL_CK : STB_FILL_CHAIN, g->st);
+                              g->ws_fill, which == 2 ? STB_FILL_HB : (which ? STB_FILL_CK : STB_FILL_CHAIN), g->st);
     stb_set_dot_request(nullptr);
     if (rc) return 1;
     stb_fill_last(&g->pend_fill);
@@ -574,7 +607,8 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   if (g->pending) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int v = stb_default_variant();
   // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
-  const bool fuse = allow_fuse && g->fused && D >= 2 && (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK);
+  const bool fuse = allow_fuse && g->fused && D >= 2 &&
+                    (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK || v == STB_FILL_HB);
   // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
   // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine
   // workgroups all fit on the chip.  It is not the default: MI355X, 10^6 pairs, N = M = 10^4, its 0.66 ms
@@ -585,11 +619,20 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   if (fuse && (stb_env_int("STB_ATERMS_CK", 0) || v == STB_FILL_CK) && v != STB_FILL_CHAIN && stb_ck_eligible(g->N, g->M, D) &&
       stb_ck_dot_spine(g->N, g->M, D) <= (unsigned)stb_env_int("STB_ATERMS_CK_MAX_SPINE", 208))
     which = 1;
+  // ... and in the halo-block form (a spine that walks blocks of rows alone + tile workers that sum their
+  // tiles' listed cells): the default for a grid while its spine workgroups (13 per table of 10^4 columns) leave
+  // the tile workers room; STB_ATERMS_HB=0 switches it off.  (MI355X, tools/time_grid.py, 10^6 pairs, N = M =
+  // 10^4, wall ms: 2 discounts 0.53 against 0.82 chain, 4: 0.56 against 0.87, 8: 0.77 against 0.97, 16: 1.37
+  // against 1.07, 64: 5.1 against 2.4.)
+  if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
+    hb_dot_info H;
+    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_SPINE", 160)) which = 2;
+  }
   if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which)) return 1;
   if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
   if (fuse && !g->sparse) which = 0;  // (dense pair sets: the count slab, chain form only)
   *fuse_out = fuse;
-  *v_out = (fuse && which) ? STB_FILL_CK : (fuse ? STB_FILL_CHAIN : v);
+  *v_out = (fuse && which == 2) ? STB_FILL_HB : ((fuse && which) ? STB_FILL_CK : (fuse ? STB_FILL_CHAIN : v));
   return 0;
 }
 

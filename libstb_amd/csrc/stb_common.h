@@ -128,7 +128,7 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   const unsigned short *ent_pos = nullptr; //         row-in-trip << 6 | column-in-slice
   const unsigned *ent_cnt = nullptr;       //         occurrence count
   unsigned nsg = 0;                        //         slices per trip in item_ptr
-  int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck)
+  int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck); 3: k_fill_hb's tiles
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
 };
@@ -151,6 +151,12 @@ bool stb_hb_eligible(unsigned N, unsigned M, int D);
 size_t stb_hb_workspace(unsigned N, unsigned M, int D);
 int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // own columns of a strip, rows of a block
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
+struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: item = record index * NQ + group of 4 rows)
+  int R, UC, HC, NB, JW, NQ;   // rows of a block, own columns of a strip, halo columns, blocks, strips, groups per item base
+  unsigned n_tiles, n_rec, n_spine;
+  const unsigned *rec_off;     // device: first record of strip index s = j + 1 (s = 0: the halo of strip 0)
+};
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out);
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
@@ -176,6 +182,12 @@ __device__ __forceinline__ int wave_shr1(int v, int fill) {
 __device__ __forceinline__ double wave_shr1_zero(double v) {
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// rotated instead: lane 0 receives lane 63's value (DPP wave_ror:1)
+__device__ __forceinline__ double wave_ror1(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_shr1(double v, double fill) {

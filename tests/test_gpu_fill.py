@@ -148,7 +148,7 @@ def test_10000_batched_config3_eight_per_gpu(golden_dir, rank):
     T = capi.DeviceTables(10000, 10000, D=8)
     T.tables.fill_(float("nan"))
     before = L.stb_fill_fallbacks()
-    assert L.stb_fill_tuning(10000, 10000, 8, None, None, None) == 4      # checkpointed form (spine + tile workers)
+    assert L.stb_fill_tuning(10000, 10000, 8, None, None, None) == 6      # halo-block form (spine + tile workers)
     T.fill(mine)
     T.status()
     assert L.stb_fill_fallbacks() == before

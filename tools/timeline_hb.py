@@ -16,15 +16,34 @@ out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/timeline_hb.txt"
 M = int(sys.argv[4]) if len(sys.argv) > 4 else N
 raw = out + ".raw"
 a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
-T = capi.DeviceTables(N, M, D=D)
-for _ in range(3):
+if os.environ.get("TL_GRID"):
+    # the summing form: one fused grid aterms over 10^6 pairs (n < N)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import orc
+    L = capi.lib()
+    g = synth.groups(1000, 1000, N, "wide")
+    M = max(int(g.t.max()) + 1, 10)
+    N = max(int(g.n.max()) + 1, M)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
+    assert h, capi.last_error()
+    x = np.ascontiguousarray(a)
+    o = np.zeros(D)
+    for _ in range(3):
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(o)))
+    os.environ["STB_HB_TIMELINE"] = raw
+    capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(o)))
+    del os.environ["STB_HB_TIMELINE"]
+    L.stb_groups_free(h)
+else:
+    T = capi.DeviceTables(N, M, D=D)
+    for _ in range(3):
+        T.fill(a, capi.FILL_HB)
+    torch.cuda.synchronize()
+    os.environ["STB_HB_TIMELINE"] = raw
     T.fill(a, capi.FILL_HB)
-torch.cuda.synchronize()
-os.environ["STB_HB_TIMELINE"] = raw
-T.fill(a, capi.FILL_HB)
-torch.cuda.synchronize()
-del os.environ["STB_HB_TIMELINE"]
-T.status()
+    torch.cuda.synchronize()
+    del os.environ["STB_HB_TIMELINE"]
+    T.status()
 
 buf = open(raw, "rb").read()
 JW, NB, NT, C, P, R, U, Dd = np.frombuffer(buf, dtype=np.int32, count=8)
