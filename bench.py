@@ -498,7 +498,7 @@ def main():
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_per_step": kms.value / args.steps,
-                "note": "one table per GPU is bound by the N serial row steps of the recurrence plus one hand-off per column block, not by HBM; see DESIGN.md",
+                "note": "one table per GPU is bound by the N serial row steps of the recurrence (10^4 rows x 25 ns in k_fill_hb) plus the hand-overs between the spine's workgroups, not by HBM; see DESIGN.md",
             },
         }
         extra = {}

@@ -5,10 +5,12 @@
 
 The interpreter itself follows `--` (no env / shell hop: the profiler's library has initialised the
 GPU by then).  WHAT:
-    fill1 fill8 fill64   stb_fill_S of 1 / 8 / 64 tables, N = M = 10000 (k_fill_ck / k_fill_ck / k_fill_pc)
-    fill1chain fill8chain  the same 1 / 8 tables forced into the chain form (what round 2 ran)
+    fill1 fill8 fill64   stb_fill_S of 1 / 8 / 64 tables, N = M = 10000 (k_fill_hb / k_fill_hb / k_fill_pc)
+    fill1ck fill8ck      the same 1 / 8 tables in the checkpointed form (k_fill_ck)
+    fill1chain fill8chain  ... and in the chain form (what round 2 ran)
     vfill                stb_fill_V, N = M = 10000                      (k_fillv_chain)
-    grid64 grid8         the fused 64- / 8-discount aterms over 10^6 pairs, n < 10000 (k_fill_chain DOT)
+    grid64 grid8         the fused 64- / 8-discount aterms over 10^6 pairs, n < 10000 (k_fill_chain DOT / k_fill_hb DOT)
+    grid8chain           the 8-discount grid in the chain form
     sweep64              the same grid through stored tables             (k_fill_pc, k_sweep_partial)
     eval1                one-discount aterms, 10^6 pairs, n < 4000       (k_fill_chain, k_sweep_partial, k_terms_partial)
     bterms               stb_bterms, 10^6 restaurants x 20 abscissae     (k_terms_partial)
@@ -39,10 +41,13 @@ def groups_handle(g, Dmax):
     return h
 
 
-if what in ("fill1", "fill8", "fill64", "fill1chain", "fill8chain"):
-    D = int(what[4:].replace("chain", ""))
+if what in ("fill1", "fill8", "fill64", "fill1chain", "fill8chain", "fill1ck", "fill8ck"):
+    D = int(what[4:].replace("chain", "").replace("ck", ""))
     if what.endswith("chain"):
         os.environ["STB_CK"] = "0"
+        os.environ["STB_HB"] = "0"
+    if what.endswith("ck"):
+        os.environ["STB_HB"] = "0"
     a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
     T = capi.DeviceTables(N, N, D=D)
     for _ in range(reps):
@@ -54,10 +59,12 @@ elif what == "vfill":
     for _ in range(reps):
         T.fill(np.array([0.5]))
     torch.cuda.synchronize()
-elif what in ("grid64", "grid8", "sweep64"):
+elif what in ("grid64", "grid8", "grid8chain", "sweep64"):
     if what == "sweep64":
         os.environ["STB_ATERMS_FUSED"] = "0"
-    Dg = 8 if what == "grid8" else 64
+    if what == "grid8chain":
+        os.environ["STB_ATERMS_HB"] = "0"
+    Dg = 8 if what.startswith("grid8") else 64
     g = synth.groups(1000, 1000, N, "wide")
     h = groups_handle(g, Dg)
     x = np.ascontiguousarray(synth.discount_grid(64)[:Dg])

@@ -20,9 +20,9 @@ tail -1 $OUT/bench_n1_main.stdout > $OUT/r03_bench_n1_main_under_rocprof.json
 stats bench_d8 $ROOT/bench.py --steps 10 --discounts-per-gpu 8 --no-cpu-baseline --no-extra --no-batch64
 tail -1 $OUT/bench_d8.stdout > $OUT/r03_bench_d8_under_rocprof.json
 # one workload per quoted duration
-for w in fill1 fill1chain fill8 fill8chain fill64 grid64 grid8 sweep64 vfill eval1 bterms; do stats $w $ROOT/tools/prof_target.py $w 5; done
+for w in fill1 fill1ck fill1chain fill8 fill8ck fill8chain fill64 grid64 grid8 grid8chain sweep64 vfill eval1 bterms; do stats $w $ROOT/tools/prof_target.py $w 5; done
 # PMC: WRITE_SIZE and FETCH_SIZE in separate passes (TCC slots), no tracing domains beside them
-for w in fill1 fill8 fill64 vfill grid64 sweep64 eval1; do
+for w in fill1 fill8 fill64 vfill grid64 grid8 sweep64 eval1; do
   for c in WRITE_SIZE FETCH_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${w}_$c -o p -- python3 $ROOT/tools/prof_target.py $w 3 > /dev/null 2> $OUT/pmc_${w}_$c.stderr || echo "pmc $w $c failed"
   done
@@ -31,11 +31,11 @@ done
 find $OUT -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*domain_stats.csv" | grep -v pmc_ | xargs -r rm -f
 find $OUT -name "*.db" | xargs -r rm -f
 cd $ROOT
-lab() { case $1 in fill1) echo N10000_M10000_D1_ck;; fill8) echo N10000_M10000_D8_ck;; fill64) echo N10000_M10000_D64_pc;; vfill) echo vfill_N10000_D1;; grid64) echo grid_N10000_D64;; sweep64) echo sweep_N10000_D64;; eval1) echo eval_N4000_D1;; esac; }
+lab() { case $1 in fill1) echo N10000_M10000_D1_hb;; fill8) echo N10000_M10000_D8_hb;; grid8) echo grid_N10000_D8;; fill64) echo N10000_M10000_D64_pc;; vfill) echo vfill_N10000_D1;; grid64) echo grid_N10000_D64;; sweep64) echo sweep_N10000_D64;; eval1) echo eval_N4000_D1;; esac; }
 rm -f $OUT/r03_hbm_traffic.json
-for w in fill1 fill8 fill64 vfill grid64 sweep64 eval1; do
+for w in fill1 fill8 fill64 vfill grid64 grid8 sweep64 eval1; do
   python3 tools/pmc_traffic.py $(lab $w) $OUT/pmc_${w}_WRITE_SIZE $OUT/pmc_${w}_FETCH_SIZE 3 $OUT/r03_hbm_traffic.json > /dev/null || echo "traffic $w failed"
 done
 # SQ counters of the 8-table fill and of the fused grid
-for w in fill8 grid64 fill1; do bash tools/pmc_sq.sh $w > /dev/null 2>&1; cp gpurun_out/pmc_sq/$w.txt $OUT/r03_sq_counters_$w.txt 2>/dev/null; done
+for w in fill8 grid64 fill1 grid8; do bash tools/pmc_sq.sh $w > /dev/null 2>&1; cp gpurun_out/pmc_sq/$w.txt $OUT/r03_sq_counters_$w.txt 2>/dev/null; done
 ls $OUT/r03_* | head -40; du -sh $OUT

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Soak test of the checkpointed form: thousands of fills must give bit-identical tables, never give up (no
-fallback to the producer/consumer form), alone and next to a background load of copies and fp64 matmuls.
-usage: python tools/soak_ck.py [seconds]      (repo root, GPU box)"""
+"""Soak test of a one-launch fill form (hb: halo blocks, the default; ck: checkpointed): thousands of fills must give
+bit-identical tables, never give up (no fallback to the producer/consumer form), alone and next to a background
+load of copies and fp64 matmuls.
+usage: python tools/soak_fill.py [seconds] [hb|ck]      (repo root, GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from libstb_amd import capi, synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+form_name = sys.argv[2] if len(sys.argv) > 2 else "hb"
+FORM = {"hb": capi.FILL_HB, "ck": capi.FILL_CK}[form_name]
 L = capi.lib()
-cases = [(777, 500, 5), (6000, 900, 2), (10000, 10000, 1), (3000, 3000, 3), (4000, 4000, 8), (10000, 10000, 8), (2000, 2000, 40), (10000, 10000, 16)]
+cases = [(777, 500, 5), (6000, 900, 2), (10000, 10000, 1), (3000, 3000, 3), (4000, 4000, 8), (10000, 10000, 8), (2000, 2000, 40), (10000, 10000, 16),
+         (1000, 1000, 1), (20000, 20000, 1)]
 fb0 = L.stb_fill_fallbacks()
 total = 0
 side = torch.cuda.Stream()
@@ -19,7 +23,7 @@ for load in (False, True):
         a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
         T = capi.DeviceTables(N, M, D=D)
         T.tables.zero_()
-        T.fill(a, capi.FILL_CK); torch.cuda.synchronize(); T.status()
+        T.fill(a, FORM); torch.cuda.synchronize(); T.status()
         ref = T.tables.clone(); refS1 = T.S1.clone()
         n = 0
         t_case = time.time() + budget / (2 * len(cases))
@@ -30,7 +34,7 @@ for load in (False, True):
                         big[: 128 << 20].copy_(big[128 << 20:])
                         mm2 = mm @ mm
                 T.tables.zero_()
-                T.fill(a, capi.FILL_CK)
+                T.fill(a, FORM)
                 if not torch.equal(T.tables, ref) or not torch.equal(T.S1, refS1):
                     bad = (T.tables != ref).nonzero()
                     print(f"MISMATCH N={N} M={M} D={D} load={load} after {n} fills: {bad.shape[0]} elements differ, first {bad[0].tolist()}", flush=True)
@@ -43,4 +47,4 @@ for load in (False, True):
         total += n
         print(f"N={N} M={M} D={D} load={load}: {n} fills identical, none gave up", flush=True)
         del T
-print(f"soak ok: {total} checkpointed fills", flush=True)
+print(f"soak ok: {total} {form_name} fills", flush=True)
