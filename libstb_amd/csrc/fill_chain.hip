@@ -168,8 +168,13 @@ __device__ __forceinline__ void chain_body(const fill_args &A, const chain_args 
   const unsigned who = (unsigned)(j | (d << 16));
   bool aborted = false;
   auto wait_ge = [&](const int *cnt, int need, unsigned code, int nap) {
-    if (aborted || lds_peek(cnt) >= need) return;
+    // (what the counter guards is read -- or written -- after it: the compiler may not move LDS accesses across)
+    if (aborted || lds_peek(cnt) >= need) {
+      asm volatile("" ::: "memory");
+      return;
+    }
     if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, nap)) aborted = true;
+    asm volatile("" ::: "memory");
   };
   auto period_of = [&](int t) { return (TP == 1) ? t : (int)__umulhi((unsigned)t, X.tp_magic); };
   // A strip has nothing to do until the diagonal reaches it, and a workgroup that spins meanwhile slows
@@ -815,9 +820,13 @@ __global__ __launch_bounds__(64 * (P + 2)) void k_fillv_chain(fill_args A, chain
   double *table = A.tables + (uint64_t)d * A.tstride;
   bool aborted = false;
   auto wait_ge = [&](const int *cnt, int need, unsigned code) {
-    if (aborted || lds_peek(cnt) >= need) return;
+    if (aborted || lds_peek(cnt) >= need) {
+      asm volatile("" ::: "memory");
+      return;
+    }
     if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, (unsigned)(j | (d << 16)), wave < P ? 1 : 2))
       aborted = true;
+    asm volatile("" ::: "memory");
   };
 
   if (wave < P) {

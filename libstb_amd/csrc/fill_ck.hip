@@ -223,8 +223,12 @@ __global__ __launch_bounds__(64 * CK_NW, 4) void k_fill_ck(fill_args A, ck_args 
     const unsigned who = (unsigned)(j | (d << 16));
     bool aborted = false;
     auto wait_ge = [&](const int *cnt, int need, unsigned code, int nap) {
-      if (aborted || lds_peek(cnt) >= need) return;
+      if (aborted || lds_peek(cnt) >= need) {
+        asm volatile("" ::: "memory");  // (what the counter guards is read or written after it)
+        return;
+      }
       if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, nap)) aborted = true;
+      asm volatile("" ::: "memory");
     };
     auto doze = [&]() {
       while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(16);

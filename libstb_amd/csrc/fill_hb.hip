@@ -39,7 +39,9 @@
 
 #include "fill_chain.h"
 
+#ifndef HB_NW
 #define HB_NW 8          // waves per workgroup: up to HB_PMAX spine waves and a fetcher
+#endif
 #define HB_PMAX 7
 #define HB_SLOTS 4       // ring of hand-overs between two spine waves of a workgroup (blocks)
 #define HB_FSLOTS 8      // ring of hand-overs from the fetcher to spine wave 0
@@ -204,10 +206,14 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
     auto wait_ge = [&](const int *cnt, int need, unsigned code) {
       if (aborted) return;
       for (int k = 0; k < HB_SPIN; k++) {
-        if (lds_peek(cnt) >= need) return;
+        if (lds_peek(cnt) >= need) {
+          asm volatile("" ::: "memory");  // (what the counter guards is read or written after it)
+          return;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
       if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, 1)) aborted = true;
+      asm volatile("" ::: "memory");
     };
     const size_t tab_rec = (size_t)d * X.n_rec;
 
@@ -785,6 +791,11 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
 }
 
 bool stb_hb_eligible(unsigned N, unsigned M, int D) { return hb_geometry(N, M, D).ok; }
+// spine workgroups a fill of D tables launches (it pays while they all fit on the chip)
+unsigned stb_hb_spine(unsigned N, unsigned M, int D) {
+  const hb_geom g = hb_geometry(N, M, D);
+  return g.ok ? (unsigned)g.B * (unsigned)D : 0xffffffffu;
+}
 
 int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out) {
   const hb_geom g = hb_geometry(N, M, D);

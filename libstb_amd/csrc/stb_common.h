@@ -149,6 +149,7 @@ unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D);  // spine workgroups i
 // halo-block form (fill_hb.hip): a spine that walks blocks of rows alone + tile workers, one launch
 bool stb_hb_eligible(unsigned N, unsigned M, int D);
 size_t stb_hb_workspace(unsigned N, unsigned M, int D);
+unsigned stb_hb_spine(unsigned N, unsigned M, int D);  // spine workgroups of a fill of D tables
 int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // own columns of a strip, rows of a block
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
 struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: item = record index * NQ + group of 4 rows)

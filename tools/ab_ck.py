@@ -15,7 +15,7 @@ D = int(sys.argv[2])
 specs = sys.argv[3].split(",")
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 M = int(sys.argv[5]) if len(sys.argv) > 5 else N
-a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
+a = (np.resize(synth.discount_grid(64), D) if D > 64 else synth.discount_grid(64)[:D]) if D > 1 else np.array([0.5])
 FORMS = {"hb": capi.FILL_HB, "ck": capi.FILL_CK, "chain": capi.FILL_CHAIN, "pc": capi.FILL_PC, "auto": capi.FILL_SCALED}
 T = capi.DeviceTables(N, M, D=D)
 L = capi.lib()

@@ -1,12 +1,11 @@
 set -e
-for N in 1000 2000 4000; do
-for D in 1 3 8; do
-timeout -k 10 200 python tools/ab_ck.py $N $D "hb,hb@STB_HB_C=4,hb@STB_HB_GRID=64,chain,auto" 2
-done; done
-timeout -k 10 200 python tools/ab_ck.py 4000 32 "hb,hb@STB_HB_C=2,ck,chain,auto" 2
-timeout -k 10 200 python tools/ab_ck.py 4000 64 "hb,ck,pc,auto" 2
-timeout -k 10 200 python tools/ab_ck.py 10000 24 "hb,ck,pc" 2
-timeout -k 10 200 python tools/ab_ck.py 10000 32 "hb,ck,pc" 2
-timeout -k 10 200 python tools/ab_ck.py 20000 1 "hb,hb@STB_HB_C=4,ck,chain,auto" 2
-timeout -k 10 200 python tools/ab_ck.py 20000 4 "hb,ck,pc,auto" 2
-timeout -k 10 200 python tools/ab_ck.py 10000 3 "hb,hb@STB_HB_C=4,ck" 2 2000
+timeout -k 10 200 python tools/ab_ck.py 1000 16 "hb,chain" 2
+timeout -k 10 200 python tools/ab_ck.py 1000 32 "hb,chain" 2
+timeout -k 10 200 python tools/ab_ck.py 1000 256 "hb,chain,pc" 2
+timeout -k 10 200 python tools/ab_ck.py 600 1000 "hb,chain,pc" 2
+timeout -k 10 200 python tools/ab_ck.py 2000 40 "hb,chain,pc" 2
+timeout -k 10 200 python tools/ab_ck.py 2000 128 "hb,chain,pc" 2
+timeout -k 10 200 python tools/ab_ck.py 3000 100 "hb,chain,pc" 2 200
+timeout -k 10 200 python tools/ab_ck.py 50000 4 "hb,chain,pc" 2 100
+timeout -k 10 200 python tools/ab_ck.py 700 8 "hb,chain" 2
+timeout -k 10 200 python tools/ab_ck.py 512 1 "hb,chain" 2
