@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_reduce_final(const dd_t *partial, int n
 
 #define STB_SWEEP_DT 8
 #define STB_SWEEP_CHUNK 4096
+// pairs per workgroup: a few thousand pairs (what a fused evaluation leaves to the gather) go 256 to a
+// workgroup, one look-up per thread, instead of three workgroups walking 16 look-ups each one after the other
+__host__ __device__ static inline unsigned stb_sweep_chunk(uint64_t G) { return (G <= 65536) ? 256u : (unsigned)STB_SWEEP_CHUNK; }
 
 __global__ __launch_bounds__(256) void k_sweep_partial(const double *tables, uint64_t tstride,
                                                        const double *S1, uint64_t s1stride, int D,
@@ -95,8 +98,9 @@ __global__ __launch_bounds__(256) void k_sweep_partial(const double *tables, uin
                                                        int nb) {
   __shared__ dd_t lds[4];
   const int d0 = blockIdx.y * STB_SWEEP_DT;
-  const uint64_t g0 = (uint64_t)blockIdx.x * STB_SWEEP_CHUNK;
-  const uint64_t g1 = (g0 + STB_SWEEP_CHUNK < G) ? g0 + STB_SWEEP_CHUNK : G;
+  const uint64_t chunk = (uint64_t)stb_sweep_chunk(G);
+  const uint64_t g0 = (uint64_t)blockIdx.x * chunk;
+  const uint64_t g1 = (g0 + chunk < G) ? g0 + chunk : G;
   dd_t acc[STB_SWEEP_DT];
 #pragma unroll
   for (int q = 0; q < STB_SWEEP_DT; q++) acc[q] = dd_t{0.0, 0.0};
@@ -133,11 +137,11 @@ __global__ __launch_bounds__(256) void k_sweep_partial(const double *tables, uin
   }
 }
 
-static int sweep_blocks(uint64_t G) { return (int)((G + STB_SWEEP_CHUNK - 1) / STB_SWEEP_CHUNK); }
+static int sweep_blocks(uint64_t G) { return (int)((G + stb_sweep_chunk(G) - 1) / stb_sweep_chunk(G)); }
 
 extern "C" size_t stb_sweep_workspace_bytes(uint64_t G, int D) {
   int nb = sweep_blocks(G);
-  if (nb < 1) nb = 1;
+  if (nb < 256) nb = 256;  // (a subset of up to 65536 of the G pairs may be swept in the same workspace: 256 to a workgroup)
   return (size_t)D * nb * sizeof(dd_t) + 256;
 }
 
