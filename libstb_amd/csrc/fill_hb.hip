@@ -54,6 +54,13 @@
                            // the word its spine wave writes; 125 strips' words in four lines made those lines the
                            // busiest of the chip and the spine's stores to them slow: its store queue filled up)
 #define HB_SPIN 48         // looks at a neighbour's counter, ~0.1 us apart, before the out-of-line wait
+// timeline stamps of the spine: the 100 MHz wall clock, or (diagnostic build -DHB_TL_CYCLES) the shader clock,
+// which tells a slower clock from waiting
+#ifdef HB_TL_CYCLES
+#define HB_STAMP() ((unsigned long long)clock64())
+#else
+#define HB_STAMP() ((unsigned long long)wall_clock64())
+#endif
 #ifndef HB_DIAG
 #define HB_DIAG 0          // diagnostic builds: 1 the spine stores no records, 2 it stores every record twice, 8 the workers store nothing (results wrong)
 #endif
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
         const int left_mask = (w == 0) ? HB_FSLOTS - 1 : HB_SLOTS - 1;
         unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
-        if (dbg) dbg[0] = wall_clock64();
+        if (dbg) dbg[0] = HB_STAMP();
         // own records: strip index jw + 1, blocks from b0; the halo of strip 0: strip index 0, blocks from 0
         // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
         // together with every write-through store of the records still under way)
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slot is in registers: it may be written again)
             lds_post(&taken[w], b + 1);
           }
-          if (dbg) dbg[1 + b] = wall_clock64();
+          if (dbg) dbg[1 + b] = HB_STAMP();
           // ---- R rows alone ----
           {
             const int dl = wave_shr1(ep, ep) - ep;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           }
         }
         if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (dbg) dbg[NB + 1] = wall_clock64();
+        if (dbg) dbg[NB + 1] = HB_STAMP();
         if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
         __builtin_amdgcn_s_setprio(0);
       }
