@@ -43,7 +43,7 @@
 #define HB_NW 8          // waves per workgroup: up to HB_PMAX spine waves and a fetcher
 #endif
 #define HB_PMAX 7
-#define HB_SLOTS 4       // ring of hand-overs between two spine waves of a workgroup (blocks)
+#define HB_SLOTS 8       // ring of hand-overs between two spine waves of a workgroup (blocks); looked after every 4th block
 #define HB_FSLOTS 8      // ring of hand-overs from the fetcher to spine wave 0
 #define HB_MAXHL 32      // halo lanes at most
 #define HB_EOFF32 (1u << 30)
@@ -102,6 +102,13 @@ __device__ __forceinline__ void hb_store16(const void *sbase, unsigned byte_off,
                : "=&s"(base_copy)
                : "v"(byte_off), "v"(v2), "s"(sbase)
                : "memory");
+}
+
+// two record words with one write-through store (what __hip_atomic_store at agent scope compiles to, 16 bytes wide)
+__device__ __forceinline__ void hb_store_wt16(unsigned long long *p, unsigned long long a, unsigned long long b) {
+  typedef unsigned long long hb_u64x2 __attribute__((ext_vector_type(2)));
+  const hb_u64x2 v2 = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v2) : "memory");
 }
 
 // ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
@@ -234,11 +241,13 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         const int b0 = hb_first_block(jw, UC, R);
         const double a = A.a[d];
         const int m0 = 2 + (jw * U - HL + lane) * C;  // first column of the lane (may be <= 0 in the halo of strip 0)
-        double v[C], coef[C], ma[C];
+        // (the coefficient n - 1 - m a of the next row is carried along, + 1 a row: the workers start every tile
+        // from the closed form instead, which differs from this in the last bits at most)
+        double v[C], coef[C];
 #pragma unroll
         for (int i = 0; i < C; i++) {
           v[i] = 0.0;
-          ma[i] = (double)(m0 + i) * a;
+          coef[i] = (double)(1 + b0 * R) - (double)(m0 + i) * a;
         }
         int ep = 1 + PC_BIAS;
         if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
@@ -263,7 +272,9 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           if (b > b0) hb_renorm<C>(v, ep);
           // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
           if (has_next) {
-            wait_ge(&taken[w + 1], b - HB_SLOTS + 1, 0x400u);
+            // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
+            // but the last 4, which covers this block and the next three)
+            if ((b & 3) == 0 || b == b0) wait_ge(&taken[w + 1], b - 4, 0x400u);
             if (lane >= U) {
               double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
 #pragma unroll
@@ -278,22 +289,46 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
           if ((own || jw == 0) && !(HB_DIAG & 1)) {
             unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
-#pragma unroll
-            for (int i = 0; i < C; i++)
-              __hip_atomic_store(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN, __ATOMIC_RELAXED,
+            if constexpr (C == 1) {
+              __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+              for (int i = 0; i < C; i += 2)
+                hb_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN,
+                              (unsigned long long)__double_as_longlong(v[i + 1]) | HB_WRITTEN);
+            }
             __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
           if (jw > 0) {
-            wait_ge(left_cnt, b + 1, 0x100u);
+            // (the counter and the data are asked for together -- LDS serves a wave's requests in order, so data
+            // read after a counter that says "there" is there -- and only if the counter says "not yet" is it
+            // waited for and the data read again: one LDS round trip instead of two)
+            double hv[C];
+            int he = 0;
+            const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
+            const int *srce = left_e + (b & left_mask) * HB_MAXHL + lane;
+            const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
             asm volatile("" ::: "memory");
             if (lane < HL) {
-              const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
 #pragma unroll
-              for (int i = 0; i < C; i++) v[i] = src[i];
-              ep = left_e[(b & left_mask) * HB_MAXHL + lane];
+              for (int i = 0; i < C; i++) hv[i] = src[i];
+              he = *srce;
+            }
+            if (seen < b + 1) {
+              wait_ge(left_cnt, b + 1, 0x100u);
+              if (lane < HL) {
+#pragma unroll
+                for (int i = 0; i < C; i++) hv[i] = src[i];
+                he = *srce;
+              }
+            }
+            if (lane < HL) {
+#pragma unroll
+              for (int i = 0; i < C; i++) v[i] = hv[i];
+              ep = he;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slot is in registers: it may be written again)
             lds_post(&taken[w], b + 1);
@@ -303,9 +338,6 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           {
             const int dl = wave_shr1(ep, ep) - ep;
             s = ldexp(1.0, min(max(dl, -1100), 220));
-            const double n1 = (double)(1 + b * R);  // n - 1 of the block's first row
-#pragma unroll
-            for (int i = 0; i < C; i++) coef[i] = n1 - ma[i];
           }
           for (int r = 0; r < R; r += 8) {
 #pragma unroll
