@@ -144,7 +144,7 @@ def test_float_table_after_a_fill_that_gave_up(monkeypatch):
 @pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_CK])
 def test_10000_full_table_vs_oracle(variant):
     """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's
-    (reference recurrence lib/stable.c:380-388), in the form stb_fill_S picks and in the checkpointed one"""
+    (reference recurrence lib/stable.c:380-388), in the form stb_fill_S picks (halo blocks) and in the checkpointed one"""
     N, a = 10000, 0.5
     T = capi.DeviceTables(N, N, D=1)
     T.tables.fill_(float("nan"))
@@ -161,8 +161,8 @@ def test_10000_full_table_vs_oracle(variant):
 
 @pytest.mark.parametrize("D", [8, 64])
 def test_10000_batch_every_table_vs_oracle(D):
-    """configs[2]: EVERY table of the 8-per-GPU share (checkpointed form) and of the whole 64-discount
-    batch on one GPU (producer/consumer form) against the oracle: the last row, an interior row and
+    """configs[2]: EVERY table of the 8-per-GPU share (halo-block form, the default there) and of the whole
+    64-discount batch on one GPU (producer/consumer form) against the oracle: the last row, an interior row and
     the row where the table turns rectangular-free (n = N/3), per-row maximum relative error"""
     N = 10000
     grid = synth.discount_grid(64)
