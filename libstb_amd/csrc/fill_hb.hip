@@ -108,7 +108,9 @@ __device__ __forceinline__ void hb_store16(const void *sbase, unsigned byte_off,
 __device__ __forceinline__ void hb_store_wt16(unsigned long long *p, unsigned long long a, unsigned long long b) {
   typedef unsigned long long hb_u64x2 __attribute__((ext_vector_type(2)));
   const hb_u64x2 v2 = {a, b};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v2) : "memory");
+  // (s_nop: a store of more than 8 bytes reads its data a cycle or two after it issues, and the compiler does
+  // not look into an asm statement for the VALU write of those registers that may follow)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v2) : "memory");
 }
 
 // ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
@@ -236,8 +238,6 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       const int w = wave;
       const int jw = jw0 + w;
       if (jw < X.JW) {
-        while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(16);
-        __builtin_amdgcn_s_setprio(3);
         const int b0 = hb_first_block(jw, UC, R);
         const double a = A.a[d];
         const int m0 = 2 + (jw * U - HL + lane) * C;  // first column of the lane (may be <= 0 in the halo of strip 0)
@@ -257,7 +257,6 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
         const int left_mask = (w == 0) ? HB_FSLOTS - 1 : HB_SLOTS - 1;
         unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
-        if (dbg) dbg[0] = HB_STAMP();
         // own records: strip index jw + 1, blocks from b0; the halo of strip 0: strip index 0, blocks from 0
         // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
         // together with every write-through store of the records still under way)
@@ -268,6 +267,12 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         unsigned *rec_e = X.ck_e + rec_base * U + slot;
         unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
         double s = 1.0;
+        // Everything is set up (the loads above included) before the wave dozes until the fetcher has the first
+        // halo: a strip can never make up for a late start -- its neighbours walk at the same pace -- so what a
+        // workgroup loses at its start is added to the end of the fill, once per workgroup of the table.
+        while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_setprio(3);
+        if (dbg) dbg[0] = HB_STAMP();
         for (int b = b0; b < NB; b++) {
           if (b > b0) hb_renorm<C>(v, ep);
           // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
@@ -359,21 +364,9 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       const size_t rec_left = tab_rec + X.rec_off[jw0] - (size_t)bL0;  // (strip jw0 - 1 has strip index jw0)
       const int slot = sub + U - HL;
       int bb = hb_first_block(jw0, UC, R);  // blocks below it are delivered
-      {
-        // the left strip writes records from its own first block on: wait, dozing, for the first one needed here
-        const unsigned *probe = X.ck_e + (rec_left + bb) * U + (U - 1);
-        unsigned long long t_begin = 0;
-        unsigned spins = 0;
-        while (__hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          __builtin_amdgcn_s_sleep(16);
-          if ((++spins & 255u) != 0 && X.timeout != 0) continue;
-          if (t_begin == 0) t_begin = wall_clock64();
-          if (__hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || lds_peek(&s_abort) ||
-              (unsigned long long)wall_clock64() - t_begin >= X.timeout)
-            break;  // (the main loop below gives up properly)
-        }
-        lds_post(&s_awake, 1);
-      }
+      // (the left strip writes records from its own first block on; the first one that arrives wakes the spine
+      // waves, and is delivered with the same look that found it)
+      bool woke = false;
       unsigned long long t_begin = 0;
       bool timing = false;
       unsigned idle = 0;
@@ -408,11 +401,16 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           }
           bb += k;
           lds_post(&fetched, bb);
+          if (!woke) {
+            woke = true;
+            lds_post(&s_awake, 1);
+          }
           timing = false;
           idle = 0;
           continue;
         }
         for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
+        if (!woke) __builtin_amdgcn_s_sleep(4);  // (the left strip may be a long way from this one's first block)
         if ((++idle & 31) != 0 && X.timeout != 0) continue;
         if (!timing) {
           timing = true;
@@ -428,6 +426,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             }
           }
           lds_post(&fetched, 0x7fffffff);  // release the spine: it runs on with stale halos
+          lds_post(&s_awake, 1);
           break;
         }
       }
@@ -995,7 +994,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
   X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
   if (X.poll_nap < 1) X.poll_nap = 1;
-  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", 6);
+  // a waiting worker sleeps this many x 512 cycles per block its tile is away: a little less than the spine takes
+  // for a block (48 rows x 22 ns with 2 columns per lane, x 32 ns with 4), so that it looks again shortly before
+  // the tile is due -- longer and it oversleeps (one table: 0.34 ms with 6 against 0.32 with 3-4), shorter and
+  // the looks of thousands of waiting waves slow the spine (fused grid of 2 discounts: 0.59 ms with 3 against 0.38)
+  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C == 4 ? 6 : 4);
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
   if (dot) {
@@ -1026,7 +1029,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   unsigned grid = (unsigned)(cus * per_cu);
   const unsigned min_workers = (unsigned)stb_env_int("STB_HB_MIN_WORKERS", 48);
   {
-    const uint64_t fed = (uint64_t)D * N / 80;
+    const uint64_t fed = (uint64_t)D * N / (dot ? 250 : 80);  // (a summing tile costs a third of a storing one)
     const uint64_t want = (uint64_t)X.n_spine + (fed > min_workers ? fed : min_workers);
     if (want < grid) grid = (unsigned)want;
   }
