@@ -20,7 +20,7 @@ def _check_tables(T, a, N, M):
         assert orc.close(T.S1[d].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("C,P,R", [(1, 6, 32), (1, 3, 16), (2, 6, 48), (2, 1, 32), (2, 4, 16), (4, 6, 48), (4, 2, 24), (4, 5, 8)])
+@pytest.mark.parametrize("C,P,R", [(1, 6, 32), (1, 3, 16), (2, 7, 48), (2, 1, 32), (2, 4, 16), (4, 7, 48), (4, 2, 24), (4, 5, 8)])
 def test_hb_geometries_agree(monkeypatch, C, P, R):
     """every strip shape (columns per lane, spine waves per workgroup, rows per block) computes the same
     tables and no wave gives up waiting (several strips, several workgroups per table, several tables)"""
