@@ -143,7 +143,10 @@ static bool chain_wins(unsigned N, unsigned M, int D) {
 // 8 tables 0.33 = chain, 16 tables 0.36 against 0.47, 64 tables 1.04 = pc.)
 // STB_CK=0 / 1 switches it off / on wherever it is eligible.
 static bool ck_wins(unsigned N, unsigned M, int D) {
-  const int force = stb_env_int("STB_CK", -1);
+  // (since the halo-block form took over the batches this one was made for, it is chosen on request only: STB_CK=1,
+  // or the variant STB_FILL_CK; what the halo-block form leaves -- very many mid-sized tables -- is the
+  // producer/consumer form's: 64 tables of 4000 columns 1.04 against 1.17 ms, 128 of 2000 0.56 against 0.68)
+  const int force = stb_env_int("STB_CK", 0);
   if (force == 0 || g_dot_req_active() || !stb_ck_eligible(N, M, D)) return false;
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
@@ -153,13 +156,14 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
 
 // The halo-block form (a spine that walks blocks of rows alone behind a halo + tile workers) is the fast one
 // wherever the ROW CHAIN, not the chip's throughput, decides: tall tables, few of them.  Chosen for tables of
-// >= 512 rows while the batch's spine workgroups all fit on the chip at once (256: 16 tables of 10^4 columns,
-// 40 of 2000) and the batch stays below 1.25 x 10^9 cells; tables of fewer than 1500 rows only up to 8 at a time
+// >= 512 rows while the batch's spine workgroups leave the tile workers room (180 at most: 24 tables of 10^4
+// columns, 48 of 4000) and the batch stays below 1.25 x 10^9 cells; tables of fewer than 1500 rows only up to 8 at a time
 // (many short tables fill the chip in the chain form as they are).  (MI355X, tools/ab_ck.py, ms: N = M = 10^4:
 // 1 table 0.36 against 0.68 chain / 0.66-0.69 checkpointed, 2 tables 0.46 against 0.69, 4 tables 0.61 against
-// 0.73, 8 tables 0.88-0.92 against 0.89-0.96, 16 tables 1.61-1.65 against 1.64, 24 tables 2.33 against 2.41 pc,
-// 32 tables 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
-// 0.283, 8 tables 0.25 against 0.34, 32 tables 0.59 against 0.58, 64 tables 1.16 against 1.04 pc; N = M = 2000:
+// 0.73, 8 tables 0.825-0.89 against 0.94-0.97, 16 tables 1.39-1.43 against 1.51-1.69, 20 tables 1.89 against 2.07,
+// 24 tables 2.13 against 2.40 pc, 32 tables (four strips a workgroup) 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
+// 0.283, 8 tables 0.25 against 0.34, 32 tables 0.54 against 0.56, 48 tables 0.825 against 0.89 pc, 64 tables 1.09 against
+// 1.03 pc; N = M = 2000:
 // 1 / 3 / 8 / 40 tables 0.11 / 0.10 / 0.145 / 0.246 against 0.15 / 0.15 / 0.154 / 0.265 chain, 128 tables 0.74
 // against 0.56 pc; N = M = 1000: 1 / 8 tables 0.06 / 0.088 against 0.08 / 0.085, 16 / 32 / 64 tables 0.107 / 0.125 /
 // 0.16 against 0.09 / 0.094 / 0.12; N = 3000, M = 200, 100 tables 0.31 against 0.25; N = 50000, M = 100, 4
@@ -171,8 +175,8 @@ static bool hb_wins(unsigned N, unsigned M, int D) {
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
-  if (N < 1500 && D > 8) return false;
-  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 256);
+  if ((N < 1500 && D > 8) || D > 64) return false;  // (many short, or very many narrow tables: the chain form)
+  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 180);
 }
 
 enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK, FORM_HB };

@@ -839,7 +839,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
 }
 
 bool stb_hb_eligible(unsigned N, unsigned M, int D) { return hb_geometry(N, M, D).ok; }
-// spine workgroups a fill of D tables launches (it pays while they all fit on the chip)
+// spine workgroups a fill of D tables launches (4 strips each, or 7 once there would be more than 100)
 unsigned stb_hb_spine(unsigned N, unsigned M, int D) {
   const hb_geom g = hb_geometry(N, M, D);
   return g.ok ? (unsigned)g.B * (unsigned)D : 0xffffffffu;
