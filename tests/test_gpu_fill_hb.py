@@ -55,6 +55,21 @@ def test_hb_random_shapes_vs_oracle():
     assert L.stb_fill_fallbacks() == before
 
 
+@pytest.mark.parametrize("N,M,D", [(30000, 60, 2), (16500, 500, 1), (70000, 130, 1)])
+def test_hb_tall_narrow_tables(N, M, D):
+    """tables much taller than wide -- one or two strips, thousands of blocks -- and row counts beyond 2^14 and 2^16,
+    where the renormalisation period (hence the block) is shorter than 48 rows"""
+    a = np.array([0.37, 0.81])[:D]
+    T = capi.DeviceTables(N, M, D=D)
+    T.tables.fill_(float("nan"))
+    L = capi.lib()
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    _check_tables(T, a, N, M)
+
+
 def test_hb_short_periods(monkeypatch):
     """a renormalisation period shorter than the block asked for shortens the block"""
     monkeypatch.setenv("STB_FILL_P", "20")
