@@ -69,7 +69,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
  * variant              STB_FILL_SCALED (default), STB_FILL_LOGDOMAIN or STB_FILL_SCALED_STEP
  */
-#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks CHAIN or PC */
+#define STB_FILL_SCALED 0      /* linear-domain recurrence, block-floating cells, table log; picks HB, CHAIN or PC by size */
 #define STB_FILL_LOGDOMAIN 1   /* logadd(log(.)+., .) per cell, operation order of lib/stable.c:380-388 */
 #define STB_FILL_SCALED_STEP 2 /* (ablation build) linear-domain, renormalised every row, libm-grade log */
 #define STB_FILL_SPLIT 3       /* (ablation build) recurrence kernel + in-place log conversion on auxiliary streams */
@@ -88,16 +88,16 @@ int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_ta
  * returns the form: 2 producer/consumer, 3 chain, 4 checkpointed (spine + tile workers), 5 another,
  * 6 halo blocks (spine that walks blocks of rows alone + tile workers) */
 int stb_fill_tuning(unsigned N, unsigned M, int D, int *C_out, int *R_out, int *launches);
-/* Completion status of the last chain-form fill issued by THIS thread (waits for it): 0, or non-zero
- * with stb_last_error() set when a column block gave up waiting for its neighbour (the fill's
- * polls are bounded; STB_CHAIN_TIMEOUT_MS, default 2000).  The other forms cannot fail on the device. */
+/* Completion status of the last one-launch fill (halo-block, chain, checkpointed) issued by THIS thread (waits
+ * for it): 0, or non-zero with stb_last_error() set when a workgroup gave up waiting for its neighbour (the
+ * fill's polls are bounded; STB_CHAIN_TIMEOUT_MS, default 2000).  The other forms cannot fail on the device. */
 int stb_fill_status(void);
-/* A chain-form stb_fill_S whose wait expired is repeated by stb_fill_status with the
+/* A one-launch stb_fill_S whose wait expired is repeated by stb_fill_status with the
  * producer/consumer form (no waits between workgroups) before it returns 0; this counts how often
  * that happened on this thread.  STB_CHAIN_NO_FALLBACK=1 turns the repeat off (status then fails). */
 unsigned stb_fill_fallbacks(void);
 /* 1 when the library carries the superseded fill forms (STB_FILL_SCALED_STEP / _SPLIT / _FUSED /
- * _CHAINX; `make ABLATION=1`); the default build refuses those variants with a message */
+ * _CHAINX; tools/ablation); the default build refuses those variants with a message */
 int stb_has_ablation(void);
 /* release the device buffers the library keeps for reuse between stb_groups_create / samplea calls
  * (capped at STB_POOL_MB, default 4096) */

@@ -157,7 +157,7 @@ ABLATION_VARIANTS = (FILL_SCALED_STEP, FILL_SPLIT, FILL_FUSED, FILL_CHAINX)
 
 
 def has_variant(variant: int) -> bool:
-    """the superseded fill forms are only in `make ABLATION=1` builds of the library"""
+    """the superseded fill forms are only in the library `make -C tools/ablation` builds"""
     return variant not in ABLATION_VARIANTS or bool(lib().stb_has_ablation())
 
 

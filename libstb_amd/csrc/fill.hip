@@ -3,12 +3,16 @@
 // workspace, keeps the status of the last chain-form fill and the optional per-launch timing.
 //
 // Forms (kernels in their own translation units):
-//   chain   k_fill_chain / k_fillv_chain   one launch per fill (default for small fills, and the fused aterms)
-//   ck      k_fill_ck                      one launch: recurrence-only spine + tile workers (default from
-//                                          ~10^8 to ~10^9 cells: 2-20 tables of 10^4 columns)
-//   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of chain and ck)
+//   hb      k_fill_hb                      one launch: a spine that walks blocks of rows alone behind a halo + tile
+//                                          workers (default wherever the row chain decides: tables of >= 512 rows
+//                                          while the spine fits, e.g. 1-24 tables of 10^4 columns; the fused aterms
+//                                          of 2-12 discounts)
+//   chain   k_fill_chain / k_fillv_chain   one launch per fill (small tables, many short ones, the V table, the fused
+//                                          aterms of more than 12 discounts)
+//   ck      k_fill_ck                      one launch: recurrence-only spine + tile workers (on request)
+//   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of the one-launch forms)
 //   rows    k_fill_rows                    the reference's own operation order (STB_FILL_LOGDOMAIN)
-//   + the superseded forms of ablation.hip in `make ABLATION=1` builds
+//   + the superseded forms of tools/ablation/ablation.hip in the library `make -C tools/ablation` builds
 
 #include "stb_common.h"
 
@@ -402,7 +406,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     default: {
       if (!stb_ablation_fill)
         return stb_fail("%s: fill variant %d is one of the superseded forms, which this build does not carry "
-                        "(make -C libstb_amd/csrc ABLATION=1)", who, variant);
+                        "(make -C tools/ablation builds a library that does)", who, variant);
       unsigned *hdr = nullptr;
       if (stb_ablation_fill(A, D, variant, ws, ws_left, &hdr, st)) return 1;
       g_last.hdr = hdr;

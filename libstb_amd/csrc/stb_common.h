@@ -10,7 +10,7 @@
 //   fill_rows.hip    k_fill_rows: the reference's own operation order (log domain / V ratios)
 //   sweep_terms.hip  k_lookup, k_to_float, k_sweep_partial, k_terms_partial, reductions
 //   groups.hip       stb_groups_*: device-resident (n,t) pairs and the aterms evaluation
-//   ablation.hip     superseded fill forms, only in `make ABLATION=1` builds
+//   tools/ablation/ablation.hip   superseded fill forms, in a library of their own (make -C tools/ablation)
 #ifndef STB_COMMON_H
 #define STB_COMMON_H
 
