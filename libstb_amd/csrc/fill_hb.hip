@@ -49,6 +49,7 @@
 #define HB_EOFF32 (1u << 30)
 #define HB_WRITTEN 0x8000000000000000ull  // a record's significands (never negative) travel with the sign bit set
 #define HB_DOT_NQ 12       // groups of 4 rows in a block at most (summing form)
+#define HB_RECOFF_LDS 512   // strips + 2 whose record offsets are copied to LDS
 #define HB_ORDER_LDS 8192  // tiles of a table whose order list is copied to LDS (32 KB)
 #define HB_PROG_STRIDE 32  // words between two strips' progress words: a line each (a strip's waiting workers poll
                            // the word its spine wave writes; 125 strips' words in four lines made those lines the
@@ -81,6 +82,7 @@ struct hb_args {
   int poll_nap;                // s_sleep argument between two polls of a fetcher
   int nap_block;               // s_sleep argument of a worker per block its inputs are away
   int diag;                    // STB_HB_DIAG: 1 the workers wait for the whole spine
+  int order_lds;               // 1: the tile order fits the dynamic LDS segment
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
   // per item = (record index of the tile) * HB_DOT_NQ + (group of 4 rows of the block), and where the sums go
@@ -172,26 +174,32 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   constexpr int NG = (C == 4 && DOT == 0) ? 2 : 1, CG = C / NG;  // a worker lane's groups of adjacent elements (see the workers)
   __shared__ double2 lt[128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
-  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
-  __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
+  // (the summing form runs four strips a workgroup: room for its staging rows and the tile order)
+  __shared__ __attribute__((aligned(16))) double xv[DOT ? 4 : HB_PMAX][HB_SLOTS][HB_MAXHL * C];
+  __shared__ int xe[DOT ? 4 : HB_PMAX][HB_SLOTS][HB_MAXHL];
   __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
   __shared__ int fe[HB_FSLOTS][HB_MAXHL];
   __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
   __shared__ unsigned s_ticket;
-  // dynamic segment.  Storing form: the tile order, when it fits (a ticket then costs no dependent global load).
-  // Summing form: per wave four rows of the wave's 64 C significands.
+  // dynamic segment.  Summing form: per wave four rows of the wave's 64 C significands; then, in both forms,
+  // the tile order when it fits (a ticket then costs no dependent global load).
   extern __shared__ __attribute__((aligned(16))) double hb_dyn[];
-  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn);
+  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT ? (size_t)HB_NW * 4 * 64 * C : 0));
   __shared__ int w_se[DOT ? HB_NW : 1][64];
+  __shared__ unsigned s_recoff[HB_RECOFF_LDS];  // first record of every strip (a tile's record costs no global load)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
-  const bool order_in_lds = DOT == 0 && X.n_tiles <= HB_ORDER_LDS;
+  const bool order_in_lds = X.order_lds != 0;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
+  const bool recoff_in_lds = X.JW + 2 <= HB_RECOFF_LDS;
+  if (recoff_in_lds)
+    for (int i = tid; i < X.JW + 2; i += blockDim.x) s_recoff[i] = X.rec_off[i];
   __syncthreads();
+  auto rec_off = [&](int sidx) -> unsigned { return recoff_in_lds ? s_recoff[sidx] : X.rec_off[sidx]; };
   const unsigned ticket = s_ticket;
   const unsigned N = A.N, M = A.M;
   const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
         // together with every write-through store of the records still under way)
         const bool own = lane >= HL;
-        const size_t rec_base = own ? tab_rec + X.rec_off[jw + 1] - (size_t)b0 : tab_rec + X.rec_off[0];
+        const size_t rec_base = own ? tab_rec + rec_off(jw + 1) - (size_t)b0 : tab_rec + rec_off(0);
         const int slot = own ? lane - HL : lane + U - HL;
         unsigned long long *rec_v = X.ck_v + (rec_base * U + slot) * C;
         unsigned *rec_e = X.ck_e + rec_base * U + slot;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       const int grp = lane / gl, sub = lane % gl, ngrp = 64 / gl;
       const bool act = sub < HL;
       const int bL0 = hb_first_block(jw0 - 1, UC, R);
-      const size_t rec_left = tab_rec + X.rec_off[jw0] - (size_t)bL0;  // (strip jw0 - 1 has strip index jw0)
+      const size_t rec_left = tab_rec + rec_off(jw0) - (size_t)bL0;  // (strip jw0 - 1 has strip index jw0)
       const int slot = sub + U - HL;
       int bb = hb_first_block(jw0, UC, R);  // blocks below it are delivered
       // (the left strip writes records from its own first block on; the first one that arrives wakes the spine
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       // exponent from the spine lane its elements belong to.
       const size_t tab_rec = (size_t)d * X.n_rec;
       const int bO = hb_first_block(jw, UC, R), bL = (jw > 0) ? hb_first_block(jw - 1, UC, R) : 0;
-      const size_t recO = tab_rec + X.rec_off[jw + 1] + (size_t)(b - bO), recL = tab_rec + X.rec_off[jw] + (size_t)(b - bL);
+      const size_t recO = tab_rec + rec_off(jw + 1) + (size_t)(b - bO), recL = tab_rec + rec_off(jw) + (size_t)(b - bL);
       const unsigned long long *ckv[NG];
       const unsigned *cke[NG];
       bool own[NG];
@@ -507,6 +515,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       // summing form: first entry of each of the tile's groups of four rows (lane q: group q; lane NQ: the end)
       unsigned ip = 0;
       int qe = 0;  // groups below it have occurring cells
+      unsigned short pp[DOT ? HB_DOT_NQ : 1];
+      unsigned cc[DOT ? HB_DOT_NQ : 1];
       if constexpr (DOT != 0) {
         const int NQ = R / 4;
         const unsigned tix = (unsigned)(recO - tab_rec);
@@ -619,8 +629,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         constexpr int WS = 64 * C;
         double *stage = hb_dyn + (size_t)wave * (4 * WS);
         int *se = &w_se[DOT ? wave : 0][0];
-        unsigned short pp[HB_DOT_NQ];
-        unsigned cc[HB_DOT_NQ];
+        // the first 64 cells of every group's list are asked for now, all at once
 #pragma unroll
         for (int q = 0; q < HB_DOT_NQ; q++) {
           pp[q] = 0;
@@ -811,7 +820,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
   {
     const int b4 = (g.JW + 3) / 4;
     g.P = stb_env_int("STB_HB_P", (!summing && (int64_t)b4 * D > 100) ? 7 : 4);
-    if (g.P < 1 || g.P > HB_PMAX) g.P = 4;
+    if (g.P < 1 || g.P > HB_PMAX || (summing && g.P > 4)) g.P = 4;
   }
   g.B = (g.JW + g.P - 1) / g.P;
   g.NB = (int)((N - 1 + R - 1) / R);  // the state before block b is row 1 + b R
@@ -1045,14 +1054,17 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   }
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
+  // the tile order goes to LDS when it fits beside the rest (static ~50 KB summing, ~80 KB storing, of 160)
+  X.order_lds = (g.n_tiles <= HB_ORDER_LDS) ? 1 : 0;
   if (dot) {
-    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
+    if (g.P > 4) return stb_fail("stb_fill_S: the summing halo-block kernel runs at most 4 strips a workgroup (STB_HB_P)");
+    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double) + (X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0);
     switch (g.C) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
     }
   } else {
-    const size_t shm = (g.n_tiles <= HB_ORDER_LDS) ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
+    const size_t shm = X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
     switch (g.C) {
       case 1: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       case 2: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
