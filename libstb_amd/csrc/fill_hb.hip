@@ -49,6 +49,9 @@
 #define HB_EOFF32 (1u << 30)
 #define HB_WRITTEN 0x8000000000000000ull  // a record's significands (never negative) travel with the sign bit set
 #define HB_DOT_NQ 12       // groups of 4 rows in a block at most (summing form)
+#define HB_MAXCNT 64        // ticket counters at most
+#define HB_CNT0 64          // word of the header the ticket counters start at (one per 32 words)
+#define HB_HDR_BYTES (256 + HB_MAXCNT * 128)
 #define HB_RECOFF_LDS 512   // strips + 2 whose record offsets are copied to LDS
 #define HB_ORDER_LDS 8192  // tiles of a table whose order list is copied to LDS (32 KB)
 #define HB_PROG_STRIDE 32  // words between two strips' progress words: a line each (a strip's waiting workers poll
@@ -63,7 +66,7 @@
 #define HB_STAMP() ((unsigned long long)wall_clock64())
 #endif
 #ifndef HB_DIAG
-#define HB_DIAG 0          // diagnostic builds: 1 the spine stores no records, 2 it stores every record twice, 8 the workers store nothing (results wrong)
+#define HB_DIAG 0          // diagnostic builds: 1 the spine stores no records, 2 it stores every record twice, 8 the workers store nothing, 16 summing workers look nothing up, 32 ... and stage nothing (results wrong)
 #endif
 
 struct hb_args {
@@ -82,6 +85,7 @@ struct hb_args {
   int poll_nap;                // s_sleep argument between two polls of a fetcher
   int nap_block;               // s_sleep argument of a worker per block its inputs are away
   int diag;                    // STB_HB_DIAG: 1 the workers wait for the whole spine
+  int n_cnt;                   // ticket counters: a multiple of D
   int order_lds;               // 1: the tile order fits the dynamic LDS segment
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   extern __shared__ __attribute__((aligned(16))) double hb_dyn[];
   unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT ? (size_t)HB_NW * 4 * 64 * C : 0));
   __shared__ int w_se[DOT ? HB_NW : 1][64];
+  __shared__ int s_done[HB_MAXCNT];  // ticket counters this workgroup has found exhausted
   __shared__ unsigned s_recoff[HB_RECOFF_LDS];  // first record of every strip (a tile's record costs no global load)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   const bool order_in_lds = X.order_lds != 0;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
+  for (int i = tid; i < HB_MAXCNT; i += blockDim.x) s_done[i] = 0;
   const bool recoff_in_lds = X.JW + 2 <= HB_RECOFF_LDS;
   if (recoff_in_lds)
     for (int i = tid; i < X.JW + 2; i += blockDim.x) s_recoff[i] = X.rec_off[i];
@@ -466,20 +472,41 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   {
     int one_hi = 0x3ff00000;
     asm volatile("" : "+v"(one_hi));
-    const unsigned total = X.n_tiles * (unsigned)X.D;
     if (X.diag & 1) {
       // diagnostic: the workers start when every spine wave is through (what the tiles cost with the chip to themselves)
       unsigned spins = 0;
       while (__hip_atomic_load(X.hdr + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(X.JW * X.D) && ++spins < 400000u)
         __builtin_amdgcn_s_sleep(100);
     }
+    // Tickets.  ONE counter hands out 88 million tickets a second whoever asks (tools/ubench/ticket.hip): eight
+    // tables of 10^4 columns are 41 000 tiles, half a millisecond of tickets alone.  So there is a counter per
+    // table -- and per interleaved part of the order list when the tables are few -- each on a line of its own;
+    // a wave starts at the counter its number gives it and moves on when one is exhausted (and tells its
+    // workgroup, so that the other waves do not ask there again).
+    // (more than HB_MAXCNT tables share counters: table d asks counter d mod Dg)
+    const unsigned NC = (unsigned)X.n_cnt, Dg = min((unsigned)X.D, (unsigned)HB_MAXCNT), S = NC / Dg;
+    unsigned cur = ((unsigned)blockIdx.x * HB_NW + (unsigned)wave) % NC, misses = 0;
     for (;;) {
+      if (lds_peek(&s_done[cur])) {
+        if (++misses >= NC) break;
+        cur = (cur + 1 == NC) ? 0 : cur + 1;
+        continue;
+      }
+      const unsigned grp = cur % Dg, part = cur / Dg;          // tiles part, part + S, part + 2 S, .. of the order list
+      const unsigned Tg = ((unsigned)X.D - grp + Dg - 1) / Dg;  // tables grp, grp + Dg, ..
+      const unsigned mine = (X.n_tiles + S - 1 - part) / S * Tg;  // how many tickets this counter hands out
       unsigned k = 0;
-      if (lane == 0) k = atomicAdd(X.hdr + 3, 1u);
+      if (lane == 0) k = atomicAdd(X.hdr + HB_CNT0 + cur * HB_PROG_STRIDE, 1u);
       k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-      if (k >= total) break;
-      const int d = (int)(k % (unsigned)X.D);
-      const unsigned oi = k / (unsigned)X.D;
+      if (k >= mine) {
+        if (lane == 0) __hip_atomic_store(&s_done[cur], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++misses >= NC) break;
+        cur = (cur + 1 == NC) ? 0 : cur + 1;
+        continue;
+      }
+      misses = 0;
+      const int d = (int)(grp + Dg * (k % Tg));
+      const unsigned oi = (k / Tg) * S + part;
       const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane((int)(order_in_lds ? s_order[oi] : X.order[oi]));
       const int jw = (int)(ord & 0xffffu), b = (int)(ord >> 16);
       const unsigned who = (unsigned)jw | ((unsigned)d << 16);
@@ -656,7 +683,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
               v[0][0] = fma(coef[0][0], v[0][0], t0);
 #pragma unroll
               for (int i = 0; i < C; i++) coef[0][i] += 1.0;
-              if (b0 != b1) {  // (a group none of whose cells occurs is only walked)
+              if (b0 != b1 && !(HB_DIAG & 32)) {  // (a group none of whose cells occurs is only walked)
                 if constexpr (C == 4) {
                   *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4) = hb_double2{v[0][0], v[0][1]};
                   *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4 + 2) = hb_double2{v[0][2], v[0][3]};
@@ -667,7 +694,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
                 }
               }
             }
-            if (b0 != b1) {
+            if (b0 != b1 && !(HB_DIAG & 16)) {
               unsigned kk = b0 + lane, pos = pp[q], cnt = cc[q];
               for (;;) {
                 if (kk < b1) {
@@ -834,7 +861,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
   if (nt >= (1ull << 31)) return g;
   g.n_tiles = (unsigned)nt;
   g.n_rec = g.n_tiles + (unsigned)g.NB;
-  size_t o = 256;
+  size_t o = HB_HDR_BYTES;
   g.off_prog = o;
   o += stb_align_up((size_t)D * g.JW * HB_PROG_STRIDE * sizeof(unsigned), 256);
   g.off_cke = o;
@@ -883,7 +910,7 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
         const size_t b0 = (size_t)hb_first_block((int)j, UC, R);
         nrec += (b0 < NB) ? NB - b0 : 0;
       }
-      const size_t b = 1024 + (size_t)D * JW * 4 * HB_PROG_STRIDE + (size_t)D * nrec * U * (4 + 8 * c) + 1024;
+      const size_t b = 1024 + HB_HDR_BYTES + (size_t)D * JW * 4 * HB_PROG_STRIDE + (size_t)D * nrec * U * (4 + 8 * c) + 1024;
       if (b > need) need = b;
     }
   return need + 256;
@@ -1056,6 +1083,14 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
   // the tile order goes to LDS when it fits beside the rest (static ~50 KB summing, ~80 KB storing, of 160)
   X.order_lds = (g.n_tiles <= HB_ORDER_LDS) ? 1 : 0;
+  {
+    // at least 8 counters when the tables are few; every counter's part of the order list keeps hundreds of tiles
+    const int Dg = D < HB_MAXCNT ? D : HB_MAXCNT;
+    int Sn = stb_env_int("STB_HB_TICKET_PARTS", Dg >= 8 ? 1 : (8 + Dg - 1) / Dg);
+    while (Sn > 1 && ((unsigned)Sn * 64 > g.n_tiles || Sn * Dg > HB_MAXCNT)) Sn--;
+    if (Sn < 1) Sn = 1;
+    X.n_cnt = Sn * Dg;
+  }
   if (dot) {
     if (g.P > 4) return stb_fail("stb_fill_S: the summing halo-block kernel runs at most 4 strips a workgroup (STB_HB_P)");
     const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double) + (X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0);
