@@ -163,9 +163,9 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
 // >= 512 rows while the batch's spine workgroups leave the tile workers room (180 at most: 24 tables of 10^4
 // columns, 48 of 4000) and the batch stays below 1.25 x 10^9 cells; tables of fewer than 1500 rows only up to 8 at a time
 // (many short tables fill the chip in the chain form as they are).  (MI355X, tools/ab_ck.py, ms: N = M = 10^4:
-// 1 table 0.36 against 0.68 chain / 0.66-0.69 checkpointed, 2 tables 0.46 against 0.69, 4 tables 0.61 against
-// 0.73, 8 tables 0.825-0.89 against 0.94-0.97, 16 tables 1.39-1.43 against 1.51-1.69, 20 tables 1.89 against 2.07,
-// 24 tables 2.13 against 2.40 pc, 32 tables (four strips a workgroup) 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
+// 1 table 0.33 against 0.70 chain / 0.71 checkpointed, 2 tables 0.365 against 0.72, 4 tables 0.50 against
+// 0.76, 8 tables 0.73-0.75 against 0.90-0.93, 16 tables 1.34-1.50 against 1.51-1.65, 20 tables 1.89 against 2.07,
+// 24 tables 2.13 against 2.37 pc, 32 tables (four strips a workgroup) 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
 // 0.283, 8 tables 0.25 against 0.34, 32 tables 0.54 against 0.56, 48 tables 0.825 against 0.89 pc, 64 tables 1.09 against
 // 1.03 pc; N = M = 2000:
 // 1 / 3 / 8 / 40 tables 0.11 / 0.10 / 0.145 / 0.246 against 0.15 / 0.15 / 0.154 / 0.265 chain, 128 tables 0.74

@@ -48,6 +48,7 @@ if what in ("fill1", "fill8", "fill64", "fill1chain", "fill8chain", "fill1ck", "
         os.environ["STB_HB"] = "0"
     if what.endswith("ck"):
         os.environ["STB_HB"] = "0"
+        os.environ["STB_CK"] = "1"
     a = synth.discount_grid(64)[:D] if D > 1 else np.array([0.5])
     T = capi.DeviceTables(N, N, D=D)
     for _ in range(reps):
