@@ -70,6 +70,28 @@ def test_hb_tall_narrow_tables(N, M, D):
     _check_tables(T, a, N, M)
 
 
+@pytest.mark.parametrize("D,parts", [(70, 0), (3, 5), (9, 2)])
+def test_hb_ticket_counters(monkeypatch, D, parts):
+    """tiles are handed out by a counter per table and per part of the order list; more tables than counters
+    (tables share them), odd numbers of parts, and every table still complete and right"""
+    if parts:
+        monkeypatch.setenv("STB_HB_TICKET_PARTS", str(parts))
+    N, M = 700, 640
+    L = capi.lib()
+    a = np.resize(synth.discount_grid(64), D)
+    T = capi.DeviceTables(N, M, D=D)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    for d in sorted(set([0, 1, D // 2, D - 2, D - 1])):
+        S1, tab = orc.fill_S(float(a[d]), N, M)
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got)), d
+        assert orc.close(got, tab, TOL), (d, orc.max_err(got, tab))
+
+
 def test_hb_short_periods(monkeypatch):
     """a renormalisation period shorter than the block asked for shortens the block"""
     monkeypatch.setenv("STB_FILL_P", "20")
