@@ -1040,11 +1040,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
   X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
   if (X.poll_nap < 1) X.poll_nap = 1;
-  // a waiting worker sleeps this many x 512 cycles per block its tile is away: a little less than the spine takes
-  // for a block (48 rows x 22 ns with 2 columns per lane, x 32 ns with 4), so that it looks again shortly before
-  // the tile is due -- longer and it oversleeps (one table: 0.34 ms with 6 against 0.32 with 3-4), shorter and
-  // the looks of thousands of waiting waves slow the spine (fused grid of 2 discounts: 0.59 ms with 3 against 0.38)
-  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C == 4 ? 6 : 4);
+  // a waiting worker sleeps this many x 512 cycles per block its tile is away: about half of what the spine takes
+  // for a block (48 rows x 22 ns with 2 columns per lane, x 32-45 ns with 4), so that it looks again well before
+  // the tile is due -- longer and it oversleeps (one table: 0.33 ms with 6 against 0.31 with 3; a table of 4000
+  // rows 0.166 against 0.148), much shorter and the looks of thousands of waiting waves get in the spine's way
+  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", dot ? 6 : (g.C == 4 ? 4 : 3));
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
   if (dot) {
@@ -1068,14 +1068,15 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   int dev = 0, cus = 256;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  // ... as many workers as the spine can feed: it hands out D tables' rows at its own pace, ~N / 80 workgroups'
-  // worth per table; more only wait (one table of 10^4: 0.36 ms with 64 worker workgroups, 0.37-0.385 with 224;
-  // N = 2000: 0.108 against 0.138; N = 1000: 0.061 against 0.079), and waiting is not free (see the workers)
+  // A storing fill takes the whole chip: idle workers cost nothing any more (they wait on progress words that have
+  // a line each, and ask counters of their own for tiles).  A summing fill's tiles are cheap and its spine decides:
+  // ~D N / 250 worker workgroups keep up with it, and fewer waiting waves leave it the memory side (2 discounts:
+  // 0.36 ms with 126 workgroups against 0.38 with 256).
   const int per_cu = stb_env_int("STB_HB_WG_PER_CU", 1);
   unsigned grid = (unsigned)(cus * per_cu);
   const unsigned min_workers = (unsigned)stb_env_int("STB_HB_MIN_WORKERS", 48);
-  {
-    const uint64_t fed = (uint64_t)D * N / (dot ? 250 : 80);  // (a summing tile costs a third of a storing one)
+  if (dot) {
+    const uint64_t fed = (uint64_t)D * N / 250;
     const uint64_t want = (uint64_t)X.n_spine + (fed > min_workers ? fed : min_workers);
     if (want < grid) grid = (unsigned)want;
   }
