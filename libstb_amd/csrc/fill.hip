@@ -159,19 +159,17 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
 }
 
 // The halo-block form (a spine that walks blocks of rows alone behind a halo + tile workers) is the fast one
-// wherever the ROW CHAIN, not the chip's throughput, decides: tall tables, few of them.  Chosen for tables of
-// >= 512 rows while the batch's spine workgroups leave the tile workers room (180 at most: 24 tables of 10^4
-// columns, 48 of 4000) and the batch stays below 1.25 x 10^9 cells; tables of fewer than 1500 rows only up to 8 at a time
-// (many short tables fill the chip in the chain form as they are).  (MI355X, tools/ab_ck.py, ms: N = M = 10^4:
-// 1 table 0.33 against 0.70 chain / 0.71 checkpointed, 2 tables 0.365 against 0.72, 4 tables 0.50 against
-// 0.76, 8 tables 0.73-0.75 against 0.90-0.93, 16 tables 1.34-1.50 against 1.51-1.65, 20 tables 1.89 against 2.07,
-// 24 tables 2.13 against 2.37 pc, 32 tables (four strips a workgroup) 3.06 against 2.84 pc; N = M = 4000: 1 table 0.176 against 0.278 chain, 3 tables 0.198 against
-// 0.283, 8 tables 0.25 against 0.34, 32 tables 0.54 against 0.56, 48 tables 0.825 against 0.89 pc, 64 tables 1.09 against
-// 1.03 pc; N = M = 2000:
-// 1 / 3 / 8 / 40 tables 0.11 / 0.10 / 0.145 / 0.246 against 0.15 / 0.15 / 0.154 / 0.265 chain, 128 tables 0.74
-// against 0.56 pc; N = M = 1000: 1 / 8 tables 0.06 / 0.088 against 0.08 / 0.085, 16 / 32 / 64 tables 0.107 / 0.125 /
-// 0.16 against 0.09 / 0.094 / 0.12; N = 3000, M = 200, 100 tables 0.31 against 0.25; N = 50000, M = 100, 4
-// tables 1.18 against 2.32; N = M = 20000: 1 table 0.93 against 1.35, 4 tables 1.81 = checkpointed.)
+// wherever the ROW CHAIN, not the chip's throughput, decides.  Chosen for tables of >= 512 rows while the batch's
+// spine workgroups leave the tile workers room (200 at most: 24 tables of 10^4 columns, 64 of 4000) and the batch
+// stays below 1.25 x 10^9 cells.  (MI355X, tools/ab_ck.py, ms: N = M = 10^4: 1 table 0.32-0.33 against 0.70 chain /
+// 0.71 checkpointed, 2 tables 0.365 against 0.72, 4 tables 0.48-0.50 against 0.76, 8 tables 0.73-0.75 against
+// 0.90-0.93, 16 tables 1.34-1.50 against 1.51-1.65, 24 tables 2.13 against 2.37 pc, 32 tables 4.3 against 2.9 pc;
+// N = M = 4000: 1 table 0.15-0.16 against 0.28 chain, 3 tables 0.158 against 0.289, 8 tables 0.20 against 0.34,
+// 64 tables 0.99 against 1.02 pc; N = M = 2000: 1 / 3 tables 0.095 / 0.10 against 0.15, 64 tables 0.32 against
+// 0.37 chain, 128 tables 0.61 against 0.55 pc; N = M = 1000: 1 / 8 / 16 / 32 / 64 tables 0.06 / 0.067 / 0.075 /
+// 0.087 / 0.122 against 0.08 / 0.086 / 0.089 / 0.090 / 0.118; N = M = 512: 0.05 = chain; N = M = 300: 0.05
+// against 0.04; N = 3000, M = 200, 100 tables 0.23 against 0.25; N = 50000, M = 100, 4 tables 1.18 against 2.32;
+// N = M = 20000: 1 table 0.75 against 1.44.)
 // STB_HB=0 / 1 switches it off / on wherever it is eligible.
 static bool hb_wins(unsigned N, unsigned M, int D) {
   const int force = stb_env_int("STB_HB", -1);
@@ -179,8 +177,7 @@ static bool hb_wins(unsigned N, unsigned M, int D) {
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
-  if ((N < 1500 && D > 8) || D > 64) return false;  // (many short, or very many narrow tables: the chain form)
-  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 180);
+  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 200);
 }
 
 enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK, FORM_HB };
