@@ -178,9 +178,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   constexpr int NG = (C == 4 && DOT == 0) ? 2 : 1, CG = C / NG;  // a worker lane's groups of adjacent elements (see the workers)
   __shared__ double2 lt[128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
-  // (the summing form runs four strips a workgroup: room for its staging rows and the tile order)
-  __shared__ __attribute__((aligned(16))) double xv[DOT ? 4 : HB_PMAX][HB_SLOTS][HB_MAXHL * C];
-  __shared__ int xe[DOT ? 4 : HB_PMAX][HB_SLOTS][HB_MAXHL];
+  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
+  __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
   __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
   __shared__ int fe[HB_FSLOTS][HB_MAXHL];
   __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
@@ -846,8 +845,9 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
   // discounts, whose tiles store nothing, 0.83 against 0.65.
   {
     const int b4 = (g.JW + 3) / 4;
-    g.P = stb_env_int("STB_HB_P", (!summing && (int64_t)b4 * D > 100) ? 7 : 4);
-    if (g.P < 1 || g.P > HB_PMAX || (summing && g.P > 4)) g.P = 4;
+    // (a summing fill's tiles are cheap: its spine keeps a wave per SIMD while all its workgroups fit on the chip)
+    g.P = stb_env_int(summing ? "STB_HB_DOT_P" : "STB_HB_P", ((int64_t)b4 * D > (summing ? 230 : 100)) ? 7 : 4);
+    if (g.P < 1 || g.P > HB_PMAX) g.P = 4;
   }
   g.B = (g.JW + g.P - 1) / g.P;
   g.NB = (int)((N - 1 + R - 1) / R);  // the state before block b is row 1 + b R
@@ -1082,8 +1082,9 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   }
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
-  // the tile order goes to LDS when it fits beside the rest (static ~50 KB summing, ~80 KB storing, of 160)
-  X.order_lds = (g.n_tiles <= HB_ORDER_LDS) ? 1 : 0;
+  // the tile order goes to LDS when it fits beside the rest (a storing kernel's ~80 KB; a summing kernel's staging
+  // rows leave no room for it)
+  X.order_lds = (!dot && g.n_tiles <= HB_ORDER_LDS) ? 1 : 0;
   {
     // at least 8 counters when the tables are few; every counter's part of the order list keeps hundreds of tiles
     const int Dg = D < HB_MAXCNT ? D : HB_MAXCNT;
@@ -1092,9 +1093,9 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     if (Sn < 1) Sn = 1;
     X.n_cnt = Sn * Dg;
   }
+  if (X.n_cnt < 1 || X.n_cnt > HB_MAXCNT) return stb_fail("stb_fill_S: %d ticket counters", X.n_cnt);
   if (dot) {
-    if (g.P > 4) return stb_fail("stb_fill_S: the summing halo-block kernel runs at most 4 strips a workgroup (STB_HB_P)");
-    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double) + (X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0);
+    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
     switch (g.C) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);

@@ -616,14 +616,17 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
       stb_ck_dot_spine(g->N, g->M, D) <= (unsigned)stb_env_int("STB_ATERMS_CK_MAX_SPINE", 208))
     which = 1;
   // ... and in the halo-block form (a spine that walks blocks of rows alone + tile workers that sum their
-  // tiles' listed cells): the default for a grid while its spine workgroups (13 per table of 10^4 columns) all
-  // fit on the chip beside some tile workers; STB_ATERMS_HB=0 switches it off.  (MI355X, tools/time_grid.py, 10^6
-  // pairs, N = M = 10^4, kernel / wall ms: 2 discounts 0.36 / 0.45 against 0.76 / 0.83 chain, 4: 0.37 / 0.45
-  // against 0.79 / 0.87, 8: 0.44 / 0.53 against 0.89 / 0.97, 12: 0.57 / 0.66 against 0.98 / 1.04, 16: 0.78 / 0.87
-  // against 1.01 / 1.09, 24: 2.0 against 1.23, 64: 4.3 against 2.4.)
+  // tiles' listed cells): the default for a grid while the chip holds its spine -- 49 strips per table of 10^4
+  // columns, four to a workgroup up to 17 discounts, seven beyond: up to 24 discounts (1200 strips in all); STB_ATERMS_HB=0 switches
+  // it off.  (MI355X, tools/time_grid.py, 10^6 pairs, N = M = 10^4, kernel / wall ms: 2 discounts 0.36 / 0.45
+  // against 0.76 / 0.83 chain, 4: 0.36 / 0.45 against 0.78 / 0.86, 8: 0.44 / 0.53 against 0.89 / 0.97, 16: 0.76 /
+  // 0.86 against 0.98 / 1.07, 24: 1.07 / 1.15 against 1.25 / 1.34, 28: 1.22 against 1.32, 30: 1.55 against 1.37,
+  // 64: 2.7 against 2.4.)
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
     hb_dot_info H;
-    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_SPINE", 230)) which = 2;
+    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 &&
+        (unsigned)H.JW * (unsigned)D <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_WAVES", 1200))
+      which = 2;
   }
   if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which)) return 1;
   if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
