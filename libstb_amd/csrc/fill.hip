@@ -6,9 +6,9 @@
 //   hb      k_fill_hb                      one launch: a spine that walks blocks of rows alone behind a halo + tile
 //                                          workers (default wherever the row chain decides: tables of >= 512 rows
 //                                          while the spine fits, e.g. 1-24 tables of 10^4 columns; the fused aterms
-//                                          of 2-12 discounts)
+//                                          of 2-24 discounts)
 //   chain   k_fill_chain / k_fillv_chain   one launch per fill (small tables, many short ones, the V table, the fused
-//                                          aterms of more than 12 discounts)
+//                                          aterms of more than 24 discounts)
 //   ck      k_fill_ck                      one launch: recurrence-only spine + tile workers (on request)
 //   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of the one-launch forms)
 //   rows    k_fill_rows                    the reference's own operation order (STB_FILL_LOGDOMAIN)
