@@ -7,6 +7,7 @@
 #include "stb_common.h"
 
 #define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
+#define STB_NLISTS 5
 
 // ------------------------------------------------------------------------------------------------
 // device-resident group set
@@ -35,19 +36,23 @@ struct stb_groups {
   double *d_dotp;
   size_t dotp_elems;
   int fused, fused_ready;
-  // sparse form of the fused evaluation: CSR of the occurring cells per item, in three layouts, each built when
+  // sparse form of the fused evaluation: CSR of the occurring cells per item, in several layouts, each built when
   // first needed: [0] (trip, 64-column slice from column 1) for k_fill_chain, [1] the same from column 2 for
-  // k_fill_ck, [2] (tile, group of 4 rows) for k_fill_hb
-  unsigned *d_item_ptr[3];
-  unsigned short *d_ent_pos[3];
-  unsigned *d_ent_cnt[3];
+  // k_fill_ck, [2] (tile, group of 4 rows) for k_fill_hb's tile workers, [3] / [4] (strip, block, group of G rows)
+  // for k_fill_hb's self-summing spine with 2 / 4 columns per lane (column 1 -- the pairs with t = 1 -- included)
+  unsigned *d_item_ptr[STB_NLISTS];
+  unsigned short *d_ent_pos[STB_NLISTS];
+  unsigned *d_ent_cnt[STB_NLISTS];
   unsigned nsg;
-  int lists_ready[3];
+  int lists_ready[STB_NLISTS];
+  int list_R[STB_NLISTS], list_G[STB_NLISTS];  // [3], [4]: the block and group length the list was built for
+  uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
   // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
   double *h_out;  // pinned, [2][Dmax]: what the stream copies the sums to
   hipEvent_t ev_dep;
   int pending, pend_D, pend_fuse, pend_v;
+  int sel_which;  // the list layout aterms_prepare chose for a fused evaluation in the halo-block form
   unsigned pend_fb0;
   double *pend_out;
   double pend_x[STB_TERMS_DMAX];
@@ -117,7 +122,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
                   g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
-                  g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2]};
+                  g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
+                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -158,6 +164,32 @@ __global__ __launch_bounds__(256) void k_dot_reduce(const double *dotp, int part
   for (int i = threadIdx.x; i < parts; i += 256) dd_add(acc, dotp[(size_t)d * parts + i]);
   const dd_t tot = block_reduce_dd(acc, red);
   if (threadIdx.x == 0) out[d] += tot.hi + tot.lo;
+}
+
+// ... of the self-summing form: per strip an exact sum of binary exponents and a sum of mantissa logs.  `inf` pairs
+// have S_S = log 0 (lib/stable.c:948-949): the reference's sum is then -inf whatever the rest.
+__global__ __launch_bounds__(256) void k_dot2_reduce(const double *dotp, int parts, double *out, unsigned long long inf) {
+  __shared__ dd_t red[4];
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const int d = blockIdx.x;
+  dd_t acc{0.0, 0.0};
+  double k = 0.0;  // (integers below 2^53: exact in any order)
+  for (int i = threadIdx.x; i < parts; i += 256) {
+    k += dotp[((size_t)d * parts + i) * 2];
+    dd_add(acc, dotp[((size_t)d * parts + i) * 2 + 1]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) k += __shfl_down(k, off, 64);
+  __shared__ double ks[4];
+  if ((threadIdx.x & 63) == 0) ks[threadIdx.x >> 6] = k;
+  dd_t tot = block_reduce_dd(acc, red);
+  if (threadIdx.x == 0) {
+    k = (ks[0] + ks[1]) + (ks[2] + ks[3]);
+    // k ln2 in two pieces: k < 2^38 and LN2_HI has 32 trailing zero bits, so the first product rounds at 2^-53 relative
+    dd_add(tot, k * LN2_LO);
+    dd_add(tot, k * LN2_HI);
+    out[d] = inf ? -HUGE_VAL : tot.hi + tot.lo;
+  }
 }
 
 static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
@@ -274,6 +306,35 @@ __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G,
   payload[g] = (uint32_t)g;
 }
 
+// ... and for the strips of the self-summing k_fill_hb: key = (item << 12) | (row in group << 8) | element of the wave,
+// item = (record index of tile (strip, block)) * NQ + group of G rows.  Column 1 (t = 1) is a cell too -- the last
+// element of strip 0's halo, which that strip computes along -- and a pair with t = n contributes log 1 = 0: what is
+// left as "other" are the pairs whose S_S is log 0 (lib/stable.c:948-949).
+__global__ void k_item_keys_hb2(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, hb_dot_info H,
+                                uint64_t *key, uint32_t *payload) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const unsigned nn = n[g], tt = t[g];
+  uint64_t k;
+  if (nn <= 1 || nn == tt) k = STB_KEY_SKIP;
+  else if (tt == 0 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
+  else {
+    unsigned j = 0, cw = (unsigned)H.HC - 1u;  // t = 1
+    if (tt >= 2) {
+      const unsigned e = tt - 2;
+      j = e / (unsigned)H.UC;
+      cw = (unsigned)H.HC + (e - j * (unsigned)H.UC);
+    }
+    const unsigned b = (nn - 2) / (unsigned)H.R, r = (nn - 2) - b * (unsigned)H.R;
+    const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
+    const unsigned rec = H.rec_off[j + 1] + (b - b0);
+    const unsigned q = r / (unsigned)H.G;
+    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << 12) | ((uint64_t)(r - q * (unsigned)H.G) << 8) | cw;
+  }
+  key[g] = k;
+  payload[g] = (uint32_t)g;
+}
+
 // counts[0] = keys below STB_KEY_OTHER (table cells), counts[1] = keys equal to it
 __global__ void k_key_bounds(const uint64_t *key, uint64_t G, uint64_t *counts) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -326,18 +387,33 @@ __global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned 
 
 // Returns 0 and sets g->sparse = 1 when the sparse form was built, 0 with g->sparse = 0 when the
 // pairs are too dense for it to pay (the caller then builds the count slab), non-zero on error.
-static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
+static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
   const unsigned N = g->N, M = g->M;
   const uint64_t G = g->G;
+  hb_dot_info H;
+  memset(&H, 0, sizeof(H));
+  if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
+  if (which >= 3) {
+    // (the strip shape of the self-summing form depends on the number of discounts: a list per shape)
+    if (stb_hb_dot_info(N, M, D, &H, 2)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
+    which = (H.C == 2) ? 3 : 4;
+    if (g->lists_ready[which] && (g->list_R[which] != H.R || g->list_G[which] != H.G)) {
+      (void)hipStreamSynchronize(g->st);
+      stb_pool_free(g->d_item_ptr[which]);
+      stb_pool_free(g->d_ent_pos[which]);
+      stb_pool_free(g->d_ent_cnt[which]);
+      g->d_item_ptr[which] = nullptr;
+      g->d_ent_pos[which] = nullptr;
+      g->d_ent_cnt[which] = nullptr;
+      g->lists_ready[which] = 0;
+    }
+  }
   if (g->lists_ready[which]) return 0;
   if (!g->fused_ready) g->sparse = 0;
   if (G == 0 || G >= 0xffffffffull) return 0;
   const unsigned nsg = (M + 63) / 64 + 4;
   const unsigned trips = (N - 2 + 7) / 8;
-  hb_dot_info H;
-  memset(&H, 0, sizeof(H));
-  if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
-  const uint64_t nitems64 = (which == 2) ? (uint64_t)H.n_rec * (unsigned)H.NQ : (uint64_t)trips * nsg;
+  const uint64_t nitems64 = (which >= 2) ? (uint64_t)H.n_rec * (unsigned)H.NQ : (uint64_t)trips * nsg;
   if (nitems64 >= (1ull << 31)) return 0;
   const unsigned nitems = (unsigned)nitems64;
   uint64_t *k0 = nullptr, *k1 = nullptr, *uk = nullptr, *d_counts = nullptr;
@@ -355,7 +431,9 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       stb_fail("stb_groups_aterms: out of device memory");
       break;
     }
-    if (which == 2)
+    if (which >= 3)
+      hipLaunchKernelGGL(k_item_keys_hb2, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, k0, p0);
+    else if (which == 2)
       hipLaunchKernelGGL(k_item_keys_hb, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, k0, p0);
     else
       hipLaunchKernelGGL(k_item_keys, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, nsg, which ? 2u : 1u, k0, p0);
@@ -380,8 +458,11 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       rc = 0;
       break;
     }
-    // the pairs outside the table, in their sorted order (the same whichever layout is built first)
-    if (!g->d_n2) {
+    // the pairs outside the table, in their sorted order (the same whichever layout is built first; the
+    // self-summing form has none but those whose S_S is log 0, which it only counts)
+    if (which >= 3) {
+      g->n_inf = n_other;
+    } else if (!g->d_n2) {
       g->G2 = n_other;
       if (stb_pool_malloc((void **)&g->d_n2, 4 * (n_other ? n_other : 1)) != hipSuccess ||
           stb_pool_malloc((void **)&g->d_t2, 2 * (n_other ? n_other : 1)) != hipSuccess) {
@@ -411,7 +492,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
     }
     if (h_runs) {
       hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item,
-                         which == 2 ? 10 : 9);
+                         which >= 3 ? 12 : (which == 2 ? 10 : 9));
       if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
@@ -424,6 +505,9 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
       hb_dot_info H2;
       if (stb_hb_dot_info(N, M, g->Dmax, &H2) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
         g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
+      // (the self-summing form: two sums per strip, strips of 80 columns at the narrowest)
+      const size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
+      if (hb2 > g->dotp_elems) g->dotp_elems = hb2;
       if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
         stb_fail("stb_groups_aterms: out of device memory");
         break;
@@ -433,6 +517,8 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which) {
     g->nsg = nsg;
     g->sparse = 1;
     g->lists_ready[which] = 1;
+    g->list_R[which] = H.R;
+    g->list_G[which] = H.G;
     g->fused_ready = 1;
     rc = 0;
   } while (0);
@@ -512,8 +598,9 @@ static int groups_fused_setup(stb_groups_t *g) {
 // memory; then wait, check the fill and hand the values over.  aterms_finish returns 0, 1 (error) or 2
 // (the fused chain fill gave up waiting: the caller repeats the evaluation through stored tables).
 static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v) {
-  // (v = STB_FILL_CK with fuse: the summing checkpointed form and its cell lists)
-  const int which = (fuse && v == STB_FILL_HB) ? 2 : ((fuse && v == STB_FILL_CK) ? 1 : 0);
+  // (v = STB_FILL_CK with fuse: the summing checkpointed form and its cell lists; STB_FILL_HB: the halo-block form,
+  // its tile workers summing or -- g->sel_which 3 / 4 -- its spine)
+  const int which = (fuse && v == STB_FILL_HB) ? (g->sel_which >= 3 ? g->sel_which : 2) : ((fuse && v == STB_FILL_CK) ? 1 : 0);
   g->pending = 0;
   g->pend_fb0 = stb_fill_fallbacks();
   HIPCHK(hipEventRecord(g->ev[0], g->st));
@@ -526,23 +613,34 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
       req.ent_pos = g->d_ent_pos[which];
       req.ent_cnt = g->d_ent_cnt[which];
       req.nsg = g->nsg;
-      req.col0 = which + 1;
+      req.col0 = which >= 3 ? 4 : which + 1;
+      if (which >= 3) {
+        req.geom_C = which == 3 ? 2 : 4;
+        req.geom_R = g->list_R[which];
+        req.geom_G = g->list_G[which];
+      }
     } else {
       req.cnt = g->d_cnt;
     }
     req.dotp = g->d_dotp;
     stb_set_dot_request(&req);
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
-                              g->ws_fill, which == 2 ? STB_FILL_HB : (which ? STB_FILL_CK : STB_FILL_CHAIN), g->st);
+                              g->ws_fill, which >= 2 ? STB_FILL_HB : (which ? STB_FILL_CK : STB_FILL_CHAIN), g->st);
     stb_set_dot_request(nullptr);
     if (rc) return 1;
     stb_fill_last(&g->pend_fill);
-    if ((size_t)D * req.parts_per_table > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+    if ((size_t)D * req.parts_per_table * (which >= 3 ? 2 : 1) > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
     HIPCHK(hipEventRecord(g->ev[1], g->st));
-    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
-                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
-      return 1;
-    hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
+    if (which >= 3) {
+      // (every pair that contributes is in the lists, column 1 included)
+      hipLaunchKernelGGL(k_dot2_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out,
+                         (unsigned long long)g->n_inf);
+    } else {
+      if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
+                      g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+        return 1;
+      hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
+    }
   } else {
     if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
                    g->ws_fill, v, g->st))
@@ -622,17 +720,26 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   // against 0.76 / 0.83 chain, 4: 0.36 / 0.45 against 0.78 / 0.86, 8: 0.44 / 0.53 against 0.89 / 0.97, 16: 0.76 /
   // 0.86 against 0.98 / 1.07, 24: 1.07 / 1.15 against 1.25 / 1.34, 28: 1.22 against 1.32, 30: 1.55 against 1.37,
   // 64: 2.7 against 2.4.)
+  // ... and with the spine itself summing its strips' listed cells, no tile workers at all (STB_ATERMS_HB2=0
+  // switches it off): every discount count, see fill_hb.hip.
+  if (fuse && which == 0 && (v == STB_FILL_HB || v == STB_FILL_SCALED) && stb_env_int("STB_ATERMS_HB2", 1)) {
+    hb_dot_info H;
+    if (stb_hb_dot_info(g->N, g->M, D, &H, 2) == 0) which = (H.C == 2) ? 3 : 4;
+  }
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
     hb_dot_info H;
     if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 &&
         (unsigned)H.JW * (unsigned)D <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_WAVES", 1200))
       which = 2;
   }
-  if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which)) return 1;
+  if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which, D)) return 1;
   if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;
   if (fuse && !g->sparse) which = 0;  // (dense pair sets: the count slab, chain form only)
-  *fuse_out = fuse;
-  *v_out = (fuse && which == 2) ? STB_FILL_HB : ((fuse && which) ? STB_FILL_CK : (fuse ? STB_FILL_CHAIN : v));
+  bool fuse2 = fuse;
+  if (fuse && g->sparse && !g->lists_ready[which]) fuse2 = false;  // (no list in this layout: stored tables + gather)
+  g->sel_which = which;
+  *fuse_out = fuse2;
+  *v_out = !fuse2 ? v : (which >= 2 ? STB_FILL_HB : (which ? STB_FILL_CK : STB_FILL_CHAIN));
   return 0;
 }
 

@@ -128,7 +128,9 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   const unsigned short *ent_pos = nullptr; //         row-in-trip << 6 | column-in-slice
   const unsigned *ent_cnt = nullptr;       //         occurrence count
   unsigned nsg = 0;                        //         slices per trip in item_ptr
-  int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck); 3: k_fill_hb's tiles
+  int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck); 3: k_fill_hb's tiles;
+                                           //         4: k_fill_hb's strips (the spine sums), lists built for geom_*
+  int geom_C = 0, geom_R = 0, geom_G = 0;  //         col0 = 4: columns per lane, rows per block, rows per group of the lists
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
 };
@@ -154,10 +156,11 @@ int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  //
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
 struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: item = record index * NQ + group of 4 rows)
   int R, UC, HC, NB, JW, NQ;   // rows of a block, own columns of a strip, halo columns, blocks, strips, groups per item base
+  int G, C;                    // rows of a group, columns per lane
   unsigned n_tiles, n_rec, n_spine;
   const unsigned *rec_off;     // device: first record of strip index s = j + 1 (s = 0: the halo of strip 0)
 };
-int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out);
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int mode = 1);  // mode 1: tile workers sum, 2: the spine does
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);

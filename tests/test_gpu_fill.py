@@ -137,7 +137,7 @@ def _check_against_grid_fixture(T, dl, d, z, probes):
 @pytest.mark.parametrize("rank", [0, 3, 7])
 def test_10000_batched_config3_eight_per_gpu(golden_dir, rank):
     """configs[2] as one GPU of eight sees it: its 8 consecutive members of the 64-discount grid at
-    N=M=10000 in one batched fill (the form stb_fill_S picks by itself: the chain), status checked,
+    N=M=10000 in one batched fill (the form stb_fill_S picks by itself: the halo blocks), status checked,
     no fallback taken, against the reference's tables for the grid members 0, 7, 31, 63."""
     L = capi.lib()
     z = np.load(os.path.join(golden_dir, "stable_grid10k.npz"))
@@ -212,7 +212,7 @@ def test_v_table_big_vs_oracle():
     assert np.array_equal(T.packed_host(0), want)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK, capi.FILL_HB, capi.FILL_SCALED])
 @pytest.mark.parametrize("a", [0.0, 0.01, 0.07, 0.5, 0.98])
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the

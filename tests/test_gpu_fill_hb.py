@@ -164,3 +164,20 @@ def test_hb_10000_full_table_vs_oracle():
     err = np.abs(got - tab) / np.maximum(1.0, np.abs(tab))
     assert np.all(np.isfinite(got))
     assert float(err.max()) <= TOL, float(err.max())
+
+
+@pytest.mark.parametrize("C", [2, 4])
+def test_hb_discount_zero_and_the_samplers_bounds(monkeypatch, C):
+    """a = 0 (unsigned Stirling numbers of the first kind: the reference takes it, lib/stable.c:1058-1065,
+    lib/sampleb.c:101-118) and the ends of samplea's bracket, A_MIN = 0.01 and A_MAX = 0.98
+    (lib/psample.h:89-94), through the halo-block form at N = M = 4000, every cell against the oracle"""
+    monkeypatch.setenv("STB_HB_C", str(C))
+    L = capi.lib()
+    a = np.array([0.0, 0.01, 0.98])
+    T = capi.DeviceTables(4000, 4000, D=3)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    assert L.stb_fill_fallbacks() == before
+    _check_tables(T, a, 4000, 4000)

@@ -297,6 +297,7 @@ def test_fused_aterms_in_the_checkpointed_form(monkeypatch, golden_dir):
     n[6:40], t[6:40] = 400, 123
     x = np.array([0.11, 0.5, 0.83])
     outs = []
+    monkeypatch.setenv("STB_ATERMS_HB2", "0")
     for ck in ("1", "0"):
         monkeypatch.setenv("STB_ATERMS_CK", ck)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
@@ -333,6 +334,7 @@ def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
         try:
             x = np.ascontiguousarray(xs[:D])
             hb1, hb2, ch = np.zeros(D), np.zeros(D), np.zeros(D)
+            monkeypatch.setenv("STB_ATERMS_HB2", "0")   # (the default since round 4 is the self-summing spine: next test)
             monkeypatch.setenv("STB_ATERMS_HB", "1")
             fb = L.stb_fill_fallbacks()
             capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(hb1)))
@@ -363,6 +365,7 @@ def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
     n[44], t[44] = 211, 210    # next to the diagonal in strip 1's first block
     x = np.array([0.11, 0.5, 0.83])
     outs = []
+    monkeypatch.setenv("STB_ATERMS_HB2", "0")
     for hb in ("1", "0"):
         monkeypatch.setenv("STB_ATERMS_HB", hb)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
@@ -397,3 +400,103 @@ def test_fused_aterms_dense_pairs_take_the_count_slab(monkeypatch):
             L.stb_groups_free(h)
     assert np.all(np.isfinite(outs[0]))
     assert orc.close(outs[0], outs[1], 1e-12), (outs[0], outs[1])
+
+
+def _edge_pairs(C):
+    """pairs on every kind of edge of the self-summing form's strips (C columns per lane: 80 or 208 own columns)"""
+    UC = (64 - 48 // C) * C
+    g = synth.groups(80, 60, 900, "wide")
+    n, t = g.n.copy(), g.t.copy()
+    n[0], t[0] = 1, 1          # n = 1: skipped (lib/samplea.c:78)
+    n[1], t[1] = 77, 77        # t = n: log 1
+    n[2], t[2] = 500, 1        # t = 1: column 1, which strip 0's halo computes along
+    n[3], t[3] = 3, 2          # the table's first cell
+    n[4], t[4] = 900, 2
+    n[5], t[5] = 900, 899      # last row, next to the diagonal
+    n[6:40], t[6:40] = 400, 123    # many pairs on one cell
+    n[40], t[40] = 49, 2       # last row of block 0
+    n[41], t[41] = 50, 2       # first row of block 1
+    n[42], t[42] = 300, UC + 1     # last own column of strip 0
+    n[43], t[43] = 300, UC + 2     # first own column of strip 1
+    n[44], t[44] = UC + 3, UC + 2  # next to the diagonal in strip 1's first block
+    n[45], t[45] = 2, 1        # S^2_1 = 1 - a: a negative log
+    n[46], t[46] = 13, 1
+    n[47:60], t[47:60] = 900, 1    # column 1 in the last row, several times
+    return g, n, t
+
+
+@pytest.mark.parametrize("C,P,G", [(2, 4, 12), (2, 7, 6), (2, 2, 4), (4, 4, 8), (4, 7, 4), (4, 3, 12)])
+def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G):
+    """the default for a grid since round 4: k_fill_hb<C, 2>, whose spine waves stage G rows at a time in LDS and
+    sum their own strip's listed cells (column 1 included; no tile workers, no S1 vector, no gather pass) --
+    against stored tables + gather at 1e-12, bit for bit run to run, at the ends of samplea's bracket
+    (A_MIN = 0.01, A_MAX = 0.98, lib/psample.h:89-94), in every strip shape"""
+    L = capi.lib()
+    for k, v in (("C", C), ("P", P), ("G", G)):
+        monkeypatch.setenv("STB_HB2_" + k, str(v))
+    g, n, t = _edge_pairs(C)
+    x = np.array([0.01, 0.11, 0.5, 0.83, 0.98])
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("STB_ATERMS_FUSED", fused)
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 5)
+        assert h, capi.last_error()
+        try:
+            fb = L.stb_fill_fallbacks()
+            out, again = np.zeros(5), np.zeros(5)
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), 5, capi.dp(out)))
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), 5, capi.dp(again)))
+            assert L.stb_fill_fallbacks() == fb
+            assert np.array_equal(out, again)
+            outs.append(out)
+        finally:
+            L.stb_groups_free(h)
+    assert np.all(np.isfinite(outs[0])) and orc.close(outs[0], outs[1], 1e-12), outs
+    # ... and against the oracle's aterms, pair by pair in the reference's order
+    O = orc.oracle()
+    for d in (0, 2, 4):
+        S1, tab = orc.fill_S(float(x[d]), 900, 900)
+        want = O.orc_aterms_sum(float(x[d]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar),
+                                orc.dp(tab), orc.dp(S1), 900, 900)
+        assert orc.close(outs[0][d], want, TOL), (d, outs[0][d], want)
+
+
+def test_fused_aterms_the_spine_sums_log_zero_pairs():
+    """a pair outside the table's support has S_S = log 0 (lib/stable.c:948-949): the sum is -inf, as the
+    reference's is, in the form that never gathers"""
+    L = capi.lib()
+    g = synth.groups(20, 30, 300, "wide")
+    n, t = g.n.copy(), g.t.copy()
+    n[7], t[7] = 5, 9
+    x = np.array([0.3, 0.6])
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 300, 300, 2)
+    assert h, capi.last_error()
+    try:
+        out = np.zeros(2)
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), 2, capi.dp(out)))
+        assert np.all(np.isneginf(out)), out
+    finally:
+        L.stb_groups_free(h)
+
+
+def test_fused_aterms_the_spine_sums_vs_reference(golden_dir):
+    """... against the reference's own aterms values (golden), small and mid-sized sets"""
+    L = capi.lib()
+    for name in ("small_wide", "small_real", "mid_wide"):
+        spec = load(golden_dir, "aterms.json")[name]
+        g = groups_of(spec)
+        N, M = bounds(spec)
+        x = np.array([fh(v) for v in spec["x"]])
+        want = np.array([fh(v) for v in spec["aterms"]])
+        D = len(x)
+        if D < 2:
+            continue
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
+        assert h, capi.last_error()
+        try:
+            out = np.zeros(D)
+            assert L.stb_fill_tuning(N, M, D, None, None, None) in (3, 6)
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(out)))
+            assert orc.close(out, want, TOL), (name, orc.max_err(out, want))
+        finally:
+            L.stb_groups_free(h)
