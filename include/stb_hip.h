@@ -139,6 +139,13 @@ int stb_restaurant_terms(const double *x_host, int D, const uint32_t *d_T, const
 int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
                const uint32_t *d_T, uint64_t I, double *d_out, void *d_ws, size_t ws_bytes,
                void *stream);
+/* the same for a host sampler that evaluates bterms many times over one T[] (sampleb's ARMS / slice callback,
+ * lib/sampleb.c:33-41): T resident, an evaluation of J <= 64 abscissae is two kernel launches and ONE wait, the
+ * values arriving in pinned host memory without a copy call */
+typedef struct stb_bctx stb_bctx_t;
+stb_bctx_t *stb_bterms_create(const uint32_t *T, int I);
+int stb_bterms_eval(stb_bctx_t *c, const double *x_host, int J, double Q, double shape, double apar, double *out_host);
+void stb_bterms_free(stb_bctx_t *c);
 
 /* ---- device-resident group set + grid evaluation (host-friendly wrappers over the above) ----
  * stb_groups_t owns device copies of the flat (n,t) pairs and the per-restaurant T, bpar, plus

@@ -99,6 +99,8 @@ static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
   if (ck > form) form = ck;
   const size_t hb = stb_hb_workspace(N, M, D);
   if (hb > form) form = hb;
+  const size_t gr = stb_grid_workspace(N, M, D);
+  if (gr > form) form = gr;
   if (stb_ablation_workspace) {
     const size_t ab = stb_ablation_workspace(N, M, D);
     if (ab > form) form = ab;
@@ -282,6 +284,7 @@ int stb_fill_status_of(last_fill *lf) {
     return 1;
   }
   lf->hdr = nullptr;
+  lf->fell_back = true;
   g_fallbacks++;
   fill_args A = lf->A;
   pc_geometry(A);
@@ -300,6 +303,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
                        hipStream_t st) {
   const char *who = vtable ? "stb_fill_V" : "stb_fill_S";
   g_last.hdr = nullptr;  // whatever this thread filled before is no longer "the last fill"
+  g_last.fell_back = false;
   if (D < 1) return stb_fail("%s: D=%d", who, D);
   if (N < 2 || M < 2) return stb_fail("%s: bounds N=%u M=%u too small", who, N, M);
   if (!a_host || !d_tables || !d_ws || (!vtable && !d_S1)) return stb_fail("%s: null pointer", who);
@@ -377,7 +381,9 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     }
     case FORM_HB: {
       unsigned *hdr = nullptr;
-      if (stb_launch_hb(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
+      if (g_dot_req && g_dot_req->col0 == 4) {  // (the walking waves sum their strips' listed cells themselves: grid_hb.hip)
+        if (stb_launch_grid(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
+      } else if (stb_launch_hb(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
       g_last.hdr = hdr;
       g_last.A = A;
       g_last.D = D;

@@ -58,8 +58,6 @@
                            // the word its spine wave writes; 125 strips' words in four lines made those lines the
                            // busiest of the chip and the spine's stores to them slow: its store queue filled up)
 #define HB_SPIN 48         // looks at a neighbour's counter, ~0.1 us apart, before the out-of-line wait
-#define HB2_MAXR 48        // rows of a block at most in the self-summing form (DOT = 2)
-#define HB2_MAXG 16        // rows of a group at most there (4 bits of a cell's position)
 // timeline stamps of the spine: the 100 MHz wall clock, or (diagnostic build -DHB_TL_CYCLES) the shader clock,
 // which tells a slower clock from waiting
 #ifdef HB_TL_CYCLES
@@ -90,13 +88,13 @@ struct hb_args {
   int n_cnt;                   // ticket counters: a multiple of D
   int order_lds;               // 1: the tile order fits the dynamic LDS segment
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
+  int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
   // per item = (record index of the tile) * HB_DOT_NQ + (group of 4 rows of the block), and where the sums go
   const unsigned *item_ptr;        // [n_rec * HB_DOT_NQ + 1] first entry of every item
   const unsigned short *ent_pos;   // row-in-group << 8 | element of the wave (halo included) of each occurring cell
   const unsigned *ent_cnt;         // its occurrence count
-  double *dotp;                    // [D][n_tiles] sum of count * log S per tile (DOT = 1); [D][JW][2] per strip (DOT = 2)
-  int G;                           // DOT = 2: rows per group (the strip's listed cells are looked up every G rows)
+  double *dotp;                    // [D][n_tiles] sum of count * log S per tile
   unsigned long long *dbg;     // STB_HB_TIMELINE: wall-clock stamps, table 0: [JW][NB + 2] spine (start, block starts, end),
                                // then [n_tiles][4] workers (claimed, inputs loaded, done, hardware id)
 };
@@ -179,38 +177,31 @@ template <int C, int DOT>
 __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
   constexpr int NG = (C == 4 && DOT == 0) ? 2 : 1, CG = C / NG;  // a worker lane's groups of adjacent elements (see the workers)
-  // The self-summing spine (DOT = 2) has no tile workers: every workgroup walks strips, two workgroups share a
-  // compute unit when the batch is large, and LDS is what limits that: its rings are sized for blocks of at most
-  // 48 rows and hold half as many blocks.
-  constexpr int MHL = (DOT == 2) ? HB2_MAXR / C : HB_MAXHL;  // halo lanes at most
-  constexpr int SL = (DOT == 2) ? 4 : HB_SLOTS, SLH = SL / 2;  // ring between two spine waves; looked after every SLH-th block
-  constexpr int FSL = (DOT == 2) ? 4 : HB_FSLOTS;
   __shared__ double2 lt[128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
-  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][SL][MHL * C];
-  __shared__ int xe[HB_PMAX][SL][MHL];
-  __shared__ __attribute__((aligned(16))) double fv[FSL][MHL * C];
-  __shared__ int fe[FSL][MHL];
+  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
+  __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
+  __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
+  __shared__ int fe[HB_FSLOTS][HB_MAXHL];
   __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
   __shared__ unsigned s_ticket;
-  // dynamic segment.  Summing forms: per wave four (DOT = 1) or G (DOT = 2) rows of the wave's 64 C significands;
-  // then, in the storing form, the tile order when it fits (a ticket then costs no dependent global load).
+  // dynamic segment.  Summing form: per wave four rows of the wave's 64 C significands; then, in both forms,
+  // the tile order when it fits (a ticket then costs no dependent global load).
   extern __shared__ __attribute__((aligned(16))) double hb_dyn[];
-  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT == 1 ? (size_t)HB_NW * 4 * 64 * C : 0));
+  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT ? (size_t)HB_NW * 4 * 64 * C : 0));
   __shared__ int w_se[DOT ? HB_NW : 1][64];
-  __shared__ int s_done[DOT == 2 ? 1 : HB_MAXCNT];  // ticket counters this workgroup has found exhausted
-  __shared__ unsigned s_recoff[DOT == 2 ? 1 : HB_RECOFF_LDS];  // first record of every strip (a tile's record costs no global load)
+  __shared__ int s_done[HB_MAXCNT];  // ticket counters this workgroup has found exhausted
+  __shared__ unsigned s_recoff[HB_RECOFF_LDS];  // first record of every strip (a tile's record costs no global load)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
   if (tid < 128) lt[tid] = A.lt[tid];
-  const bool order_in_lds = DOT != 2 && X.order_lds != 0;
+  const bool order_in_lds = X.order_lds != 0;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
-  if constexpr (DOT != 2)
-    for (int i = tid; i < HB_MAXCNT; i += blockDim.x) s_done[i] = 0;
-  const bool recoff_in_lds = DOT != 2 && X.JW + 2 <= HB_RECOFF_LDS;
+  for (int i = tid; i < HB_MAXCNT; i += blockDim.x) s_done[i] = 0;
+  const bool recoff_in_lds = X.JW + 2 <= HB_RECOFF_LDS;
   if (recoff_in_lds)
     for (int i = tid; i < X.JW + 2; i += blockDim.x) s_recoff[i] = X.rec_off[i];
   __syncthreads();
@@ -273,57 +264,31 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           coef[i] = (double)(1 + b0 * R) - (double)(m0 + i) * a;
         }
         int ep = 1 + PC_BIAS;
-        int one_hi2 = 0x3ff00000;
-        asm volatile("" : "+v"(one_hi2));
         if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
         const bool has_next = (w + 1 < P) && (jw + 1 < X.JW);
         const int *left_cnt = (w == 0) ? &fetched : &posted[w > 0 ? w - 1 : 0];
         const double *left_v = (w == 0) ? &fv[0][0] : &xv[w > 0 ? w - 1 : 0][0][0];
         const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
-        const int left_mask = (w == 0) ? FSL - 1 : SL - 1;
+        const int left_mask = (w == 0) ? HB_FSLOTS - 1 : HB_SLOTS - 1;
         unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
         // own records: strip index jw + 1, blocks from b0; the halo of strip 0: strip index 0, blocks from 0
         // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
         // together with every write-through store of the records still under way)
         const bool own = lane >= HL;
-        // (self-summing form: nobody reads a record but the next workgroup's fetcher, and only the rightmost HL
-        // lanes of this workgroup's last strip: one compact record per (table, workgroup, block))
-        const bool rec2 = (DOT == 2) && (w == P - 1) && (jw + 1 < X.JW);
-        const size_t rec_base = (DOT == 2) ? ((size_t)d * X.B + j) * (size_t)NB
-                                           : (own ? tab_rec + rec_off(jw + 1) - (size_t)b0 : tab_rec + rec_off(0));
-        const int slot = (DOT == 2) ? lane - U : (own ? lane - HL : lane + U - HL);
-        const int rec_w = (DOT == 2) ? HL : U;  // lanes of a record
-        unsigned long long *rec_v = X.ck_v + (rec_base * rec_w + slot) * C;
-        unsigned *rec_e = X.ck_e + rec_base * rec_w + slot;
+        const size_t rec_base = own ? tab_rec + rec_off(jw + 1) - (size_t)b0 : tab_rec + rec_off(0);
+        const int slot = own ? lane - HL : lane + U - HL;
+        unsigned long long *rec_v = X.ck_v + (rec_base * U + slot) * C;
+        unsigned *rec_e = X.ck_e + rec_base * U + slot;
         unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
         double s = 1.0;
-        // ---- self-summing form: the strip's listed cells, one contiguous list in (block, group of G rows) order ----
-        constexpr int WS = 64 * C;
-        const int G = (DOT == 2) ? X.G : 0, NQ = (DOT == 2) ? R / G : 0;
-        double *stage = hb_dyn + (size_t)w * (size_t)(G * WS);
-        int *se = &w_se[DOT ? w : 0][0];
-        const unsigned *iptr = nullptr;
-        unsigned ip = 0, pp = 0, cc = 0;
-        long long accK = 0;   // sum of count x binary exponent (exact)
-        double accF = 0.0;    // sum of count x log of the significand's mantissa part
-        if constexpr (DOT == 2) {
-          iptr = X.item_ptr + ((size_t)X.rec_off[jw + 1]) * (size_t)NQ;  // items of tile (jw, b0), then block by block
-          if (lane <= NQ) ip = iptr[lane];
-          const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)ip, 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)ip, 1);
-          if (e0 + lane < e1) {
-            pp = X.ent_pos[e0 + lane];
-            cc = X.ent_cnt[e0 + lane];
-          }
-        }
         // Everything is set up (the loads above included) before the wave dozes until the fetcher has the first
         // halo: a strip can never make up for a late start -- its neighbours walk at the same pace -- so what a
         // workgroup loses at its start is added to the end of the fill, once per workgroup of the table.
         while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
-        // ... and until its left neighbour in the workgroup is about to hand over the first halo: a wave that spins
-        // on the counter inside the block loop (every 64 cycles) takes issue slots from the spine wave it shares a
-        // SIMD with -- an fp64 instruction holds a SIMD's vector issue for 8 cycles, so ONE walking wave saturates it
-        // -- for as many blocks as the diagonal is away (strip 6 of a workgroup of 7: 26 blocks)
-        if (w > 0)
+        // ... and until its left neighbour in the workgroup is about to hand over the first halo: a wave that spins on
+        // the counter inside the block loop (every 64 cycles) takes issue slots from the spine wave it shares a SIMD
+        // with (waves w and w + 4 of a workgroup) for as many blocks as the diagonal is away
+        if (w > 0 && X.doze)
           while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_s_setprio(3);
         if (dbg) dbg[0] = HB_STAMP();
@@ -333,12 +298,12 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           if (has_next) {
             // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
             // but the last 4, which covers this block and the next three)
-            if ((b & (SLH - 1)) == 0 || b == b0) wait_ge(&taken[w + 1], b - SLH, 0x400u);
+            if ((b & 3) == 0 || b == b0) wait_ge(&taken[w + 1], b - 4, 0x400u);
             if (lane >= U) {
-              double *dst = &xv[w][b & (SL - 1)][(lane - U) * C];
+              double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
 #pragma unroll
               for (int i = 0; i < C; i++) dst[i] = v[i];
-              xe[w][b & (SL - 1)][lane - U] = ep;
+              xe[w][b & (HB_SLOTS - 1)][lane - U] = ep;
             }
             lds_post(&posted[w], b + 1);
           }
@@ -346,8 +311,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           // exact: they go to strip index 0 at the place a left neighbour's rightmost lanes would have).
           // (A publisher wave that takes the row from LDS and stores it in the spine's stead was tried: the spine
           // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
-          if (((DOT == 2) ? (rec2 && lane >= U) : (own || jw == 0)) && !(HB_DIAG & 1)) {
-            unsigned long long *dst = rec_v + (size_t)b * (size_t)(rec_w * C);
+          if ((own || jw == 0) && !(HB_DIAG & 1)) {
+            unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
             if constexpr (C == 1) {
               __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
@@ -357,9 +322,9 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
                 hb_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN,
                               (unsigned long long)__double_as_longlong(v[i + 1]) | HB_WRITTEN);
             }
-            __hip_atomic_store(rec_e + (size_t)b * (size_t)rec_w, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (DOT != 2 && lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
           if (jw > 0) {
             // (the counter and the data are asked for together -- LDS serves a wave's requests in order, so data
@@ -367,8 +332,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             // waited for and the data read again: one LDS round trip instead of two)
             double hv[C];
             int he = 0;
-            const double *src = left_v + (b & left_mask) * (MHL * C) + lane * C;
-            const int *srce = left_e + (b & left_mask) * MHL + lane;
+            const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
+            const int *srce = left_e + (b & left_mask) * HB_MAXHL + lane;
             const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
             asm volatile("" ::: "memory");
             if (lane < HL) {
@@ -398,99 +363,12 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             const int dl = wave_shr1(ep, ep) - ep;
             s = ldexp(1.0, min(max(dl, -1100), 220));
           }
-          if constexpr (DOT == 2) {
-            // (the coefficient is taken from its closed form again: what + 1 a row drifts by stays inside a block)
-#pragma unroll
-            for (int i = 0; i < C; i++) coef[i] = (double)(1 + b * R) - (double)(m0 + i) * a;
-            se[lane] = ep;
-            unsigned ipn = 0;  // the next block's items
-            if (lane <= NQ && b + 1 < NB) ipn = iptr[(size_t)(b + 1 - b0) * NQ + lane];
-            for (int q = 0; q < NQ; q++) {
-              const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)ip, q), e1 = (unsigned)__builtin_amdgcn_readlane((int)ip, q + 1);
-              // the first 64 cells of the next group's list are asked for now: they arrive while this group is walked
-              const unsigned f1 = (q + 2 <= NQ) ? (unsigned)__builtin_amdgcn_readlane((int)ip, q + 2)
-                                                : ((b + 1 < NB) ? (unsigned)__builtin_amdgcn_readlane((int)ipn, 1) : e1);
-              unsigned ppn = 0, ccn = 0;
-              if (e1 + lane < f1 && !(X.diag & 16)) {
-                ppn = X.ent_pos[e1 + lane];
-                ccn = X.ent_cnt[e1 + lane];
-              }
-              if (e0 != e1 && !(X.diag & 8)) {
-                for (int u = 0; u < G; u += 4) {
-#pragma unroll
-                  for (int k = 0; k < 4; k++) {
-                    hb_row<C>(v, coef, s);
-                    double *dst = stage + (u + k) * WS + lane * C;
-                    if constexpr (C == 4) {
-                      *reinterpret_cast<hb_double2 *>(dst) = hb_double2{v[0], v[1]};
-                      *reinterpret_cast<hb_double2 *>(dst + 2) = hb_double2{v[2], v[3]};
-                    } else if constexpr (C == 2) {
-                      *reinterpret_cast<hb_double2 *>(dst) = hb_double2{v[0], v[1]};
-                    } else {
-                      dst[0] = v[0];
-                    }
-                  }
-                }
-                // every lane looks one listed cell up: the exponent goes to an integer sum, the rest to a double
-                const unsigned ne = (X.diag & 4) ? 0u : e1 - e0;
-                unsigned kk = lane, pos = pp, cnt = cc;
-                for (;;) {
-                  if (kk < ne) {
-                    const int cw = (int)(pos & 255u);
-                    const double x = stage[(pos >> 8) * WS + cw];
-                    const int hi = __double2hiint(x);
-                    const double2 t = lt[(hi >> 13) & 127];
-                    const double z = __hiloint2double(mantissa_of_one(hi, one_hi2), __double2loint(x));
-                    const double rr = fma(z, t.x, -1.0);
-                    double pl = fma(rr, 0.2, -0.25);
-                    pl = fma(rr, pl, 1.0 / 3.0);
-                    pl = fma(rr, pl, -0.5);
-                    pl = fma(rr, pl, 1.0);
-                    const int kx = (int)((hi >> 20) & 0x7ff) - 1023 + se[cw / C];
-                    accK += (long long)(int)cnt * (long long)kx;
-                    accF = fma((double)cnt, fma(rr, pl, t.y), accF);
-                  }
-                  if (kk - lane + 64 >= ne) break;  // (wave-uniform)
-                  kk += 64;
-                  pos = cnt = 0;
-                  if (kk < ne) {
-                    pos = X.ent_pos[e0 + kk];
-                    cnt = X.ent_cnt[e0 + kk];
-                  }
-                }
-              } else {
-                // (a group none of whose cells occurs is only walked)
-                for (int u = 0; u < G; u += 4) {
-#pragma unroll
-                  for (int k = 0; k < 4; k++) hb_row<C>(v, coef, s);
-                }
-              }
-              pp = ppn;
-              cc = ccn;
-            }
-            ip = ipn;
-          } else {
           for (int r = 0; r < R; r += 8) {
 #pragma unroll
             for (int u = 0; u < 8; u++) hb_row<C>(v, coef, s);
           }
-          }
         }
-        if constexpr (DOT == 2) {
-          // the strip's two sums, over the wave in a fixed tree: the same bits on every run.  (The exponent sum is
-          // an integer well below 2^53: exact in a double, whatever the order.)
-          double kd = (double)accK;
-#pragma unroll
-          for (int o = 32; o >= 1; o >>= 1) {
-            kd += __shfl_xor(kd, o);
-            accF += __shfl_xor(accF, o);
-          }
-          if (lane == 0) {
-            X.dotp[((size_t)d * X.JW + jw) * 2] = kd;
-            X.dotp[((size_t)d * X.JW + jw) * 2 + 1] = accF;
-          }
-        }
-        if (DOT != 2 && lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[NB + 1] = HB_STAMP();
         if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
         __builtin_amdgcn_s_setprio(0);
@@ -502,10 +380,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       const int grp = lane / gl, sub = lane % gl, ngrp = 64 / gl;
       const bool act = sub < HL;
       const int bL0 = hb_first_block(jw0 - 1, UC, R);
-      // (strip jw0 - 1 has strip index jw0; self-summing form: the compact record of workgroup j - 1)
-      const size_t rec_left = (DOT == 2) ? ((size_t)d * X.B + (j - 1)) * (size_t)NB : tab_rec + rec_off(jw0) - (size_t)bL0;
-      const int slot = (DOT == 2) ? sub : sub + U - HL;
-      const int rec_w = (DOT == 2) ? HL : U;
+      const size_t rec_left = tab_rec + rec_off(jw0) - (size_t)bL0;  // (strip jw0 - 1 has strip index jw0)
+      const int slot = sub + U - HL;
       int bb = hb_first_block(jw0, UC, R);  // blocks below it are delivered
       // (the left strip writes records from its own first block on; the first one that arrives wakes the spine
       // waves, and is delivered with the same look that found it)
@@ -521,10 +397,10 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
 #pragma unroll
         for (int i = 0; i < C; i++) bv[i] = 1;
         if (want) {
-          const unsigned long long *src = X.ck_v + ((rec_left + mb) * rec_w + slot) * C;
+          const unsigned long long *src = X.ck_v + ((rec_left + mb) * U + slot) * C;
 #pragma unroll
           for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          be = __hip_atomic_load(X.ck_e + (rec_left + mb) * rec_w + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          be = __hip_atomic_load(X.ck_e + (rec_left + mb) * U + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const int tk = lds_peek(&taken[0]);
         bool have = be != 0;
@@ -534,13 +410,13 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         // leading groups that are complete, in range, and whose ring slot spine wave 0 has read
         int k = miss ? (int)(__builtin_ctzll(miss) / gl) : ngrp;
         k = min(k, NB - bb);
-        k = min(k, tk + FSL - bb);
+        k = min(k, tk + HB_FSLOTS - bb);
         if (k > 0) {
           if (want && grp < k) {
-            double *dst = &fv[mb & (FSL - 1)][sub * C];
+            double *dst = &fv[mb & (HB_FSLOTS - 1)][sub * C];
 #pragma unroll
             for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)(bv[i] & ~HB_WRITTEN));
-            fe[mb & (FSL - 1)][sub] = (int)(be - HB_EOFF32);
+            fe[mb & (HB_FSLOTS - 1)][sub] = (int)(be - HB_EOFF32);
           }
           bb += k;
           lds_post(&fetched, bb);
@@ -579,7 +455,6 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
     // free compute unit, this one must give its place up, or its waves would sit on tiles of strips whose
     // spine cannot start.  Waves without a part (no strip, no fetching) sleep until the spine is through:
     // a worker on the spine's compute unit takes issue slots from it.
-    if constexpr (DOT == 2) return;  // (no tiles: whoever is through, or has no part, leaves)
     if (X.spare_work && (wave > P || (wave == P && j == 0) || (wave < P && jw0 + wave >= X.JW))) {
       // (tunable: the spare waves work on tiles from the start, once every workgroup of the grid is running)
       unsigned spins = 0;
@@ -597,7 +472,6 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
     if (__hip_atomic_load(X.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) return;
   }
 
-  if constexpr (DOT == 2) return;  // (the self-summing form launches spine workgroups only)
   // =========================================================================================
   // tile workers (every wave for itself)
   {
@@ -930,26 +804,24 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
 
 struct hb_geom {
   int C, P, B, JW, NB, R, HL, U;
-  int G;  // self-summing form: rows per group
   unsigned n_tiles, n_rec;
   size_t off_prog, off_cke, off_ckv, zero_bytes, bytes;
   bool ok;
 };
 
-static int hb_cus() {
+int stb_cu_count() {  // compute units of the current device (256 on an MI355X)
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
     cus = 256;
   return cus;
 }
 
-// summing: 0 the storing fill, 1 tile workers sum their tiles' listed cells, 2 the spine sums its own strip's
-static hb_geom hb_geometry(unsigned N, unsigned M, int D, int summing = 0) {
+static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) {
   hb_geom g;
   memset(&g, 0, sizeof(g));
   g.ok = false;
   if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return g;
-  const int cus = hb_cus();
+  const int cus = stb_cu_count();
   // 2 columns per lane walk faster (26 against 32.5 ns a row) but need 2.6 times the spine waves of 4 (80
   // against 208 own columns a strip): 2 while the spine waves of all tables fit on ~80 compute units at one per
   // SIMD.  (MI355X, tools/ab_ck.py: N = M = 10^4, 1 table 0.36 against 0.46-0.50 ms, 2 tables 0.46 against 0.49,
@@ -957,16 +829,11 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int summing = 0) {
   {
     const unsigned cmax0 = (M < N - 1) ? M : N - 1;
     const uint64_t waves2 = (uint64_t)D * ((cmax0 - 1 + 79) / 80);
-    // (320 on the 256 compute units of an MI355X)
-    g.C = stb_env_int("STB_HB_C", waves2 <= (uint64_t)cus * 5 / 4 ? 2 : 4);
-    // The self-summing form has no workers to leave room for: 2 columns per lane -- the faster walk -- while
-    // every strip of the batch has a SIMD to itself.
-    if (summing == 2) g.C = stb_env_int("STB_HB2_C", waves2 <= (uint64_t)cus * 4 ? 2 : 4);
+    g.C = stb_env_int("STB_HB_C", waves2 <= (uint64_t)cus * 5 / 4 ? 2 : 4);  // (320 on 256 compute units)
   }
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
   // (a summing fill's cell lists are laid out for one strip shape, whatever the number of discounts)
-  if (summing == 1) g.C = 4;
-  if (summing == 2 && g.C == 1) g.C = 2;
+  if (summing) g.C = 4;
   g.P = 4;  // (one spine wave per SIMD: two on one slow each other by a third; see below)
   // a block is a renormalisation period (or less): rows in eights, halo lanes R / C <= 32
   int Pc = stb_period_rows(N);
@@ -975,7 +842,6 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int summing = 0) {
   int R = stb_env_int("STB_HB_ROWS", 48);
   if (R > Pc) R = Pc;
   if (R > HB_MAXHL * g.C) R = HB_MAXHL * g.C;
-  if (summing == 2 && R > HB2_MAXR) R = HB2_MAXR;
   R = R / 8 * 8;
   if (R < 8) return g;
   g.R = R;
@@ -996,25 +862,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int summing = 0) {
     // (a summing fill's tiles are cheap: its spine keeps a wave per SIMD while all its workgroups fit on the chip)
     // (230 and 100 on the 256 compute units of an MI355X)
     g.P = stb_env_int(summing ? "STB_HB_DOT_P" : "STB_HB_P", ((int64_t)b4 * D > (summing ? cus * 9 / 10 : cus * 2 / 5)) ? 7 : 4);
-    // self-summing form: every workgroup walks strips and all of them should be on the chip at once, two to a
-    // compute unit at most: 4 strips a workgroup while they are, 7 beyond
-    if (summing == 2) g.P = stb_env_int("STB_HB2_P", ((int64_t)b4 * D > 2 * cus) ? 7 : 4);
     if (g.P < 1 || g.P > HB_PMAX) g.P = 4;
-  }
-  if (summing == 2) {
-    // rows per group: the more rows, the better the 64 lanes of a look-up pass are used (a strip of 80 columns has
-    // ~1.6 listed cells a row at 10^6 pairs over a 10^4 x 10^4 table, one of 208 columns ~4), but G rows of 64 C
-    // doubles are staged in LDS per spine wave (1 KB a row with 2 columns per lane, 2 KB with 4), beside ~20 KB of
-    // rings, and two workgroups must fit a compute unit's 160 KB once there are more workgroups than units
-    const bool two_per_cu = (int64_t)((g.JW + g.P - 1) / g.P) * D > cus;
-    int Gd = (g.C == 2) ? (g.P <= 4 ? 12 : (two_per_cu ? 6 : 12)) : (g.P <= 4 ? (two_per_cu ? 4 : 8) : 4);
-    Gd = stb_env_int("STB_HB2_G", Gd);
-    if (Gd < 4) Gd = 4;
-    if (Gd > HB2_MAXG) Gd = HB2_MAXG;
-    Gd = Gd / 4 * 4;
-    while (Gd > 4 && R % Gd != 0) Gd -= 4;
-    if (R % Gd != 0) return g;  // (R is a multiple of 8: cannot happen)
-    g.G = Gd;
   }
   g.B = (g.JW + g.P - 1) / g.P;
   g.NB = (int)((N - 1 + R - 1) / R);  // the state before block b is row 1 + b R
@@ -1030,18 +878,6 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int summing = 0) {
   g.n_rec = g.n_tiles + (unsigned)g.NB;
   size_t o = HB_HDR_BYTES;
   g.off_prog = o;
-  if (summing == 2) {
-    // compact records: the rightmost HL lanes of a workgroup's last strip, per (table, workgroup, block)
-    o += 256;
-    g.off_cke = o;
-    o += stb_align_up((size_t)D * g.B * g.NB * g.HL * sizeof(unsigned), 256);
-    g.off_ckv = o;
-    o += stb_align_up((size_t)D * g.B * g.NB * g.HL * g.C * 8, 256);
-    g.zero_bytes = o;
-    g.bytes = o;
-    g.ok = true;
-    return g;
-  }
   o += stb_align_up((size_t)D * g.JW * HB_PROG_STRIDE * sizeof(unsigned), 256);
   g.off_cke = o;
   o += stb_align_up((size_t)D * g.n_rec * g.U * sizeof(unsigned), 256);
@@ -1173,9 +1009,9 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
 
 // what the builder of a summing fill's cell lists has to know: the shape of the tiles and where a strip's
 // records start (device array of JW + 2 words; a tile's record index is its item base)
-int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int mode) {
-  const hb_geom g = hb_geometry(N, M, D, mode == 2 ? 2 : 1);
-  if (!g.ok || (mode != 2 && g.R / 4 > HB_DOT_NQ)) return 1;
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
+  const hb_geom g = hb_geometry(N, M, D, true);
+  if (!g.ok || g.R / 4 > HB_DOT_NQ) return 1;
   const unsigned *rec_off = nullptr, *order = nullptr;
   if (hb_order_list(g, N, M, &rec_off, &order)) return 1;
   out->R = g.R;
@@ -1183,8 +1019,8 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int mode) {
   out->HC = g.HL * g.C;
   out->NB = g.NB;
   out->JW = g.JW;
-  out->NQ = (mode == 2) ? g.R / g.G : HB_DOT_NQ;
-  out->G = (mode == 2) ? g.G : 4;
+  out->NQ = HB_DOT_NQ;
+  out->G = 4;
   out->C = g.C;
   out->n_tiles = g.n_tiles;
   out->n_rec = g.n_rec;
@@ -1195,16 +1031,12 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int mode) {
 
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
   const unsigned N = A.N, M = A.M;
-  const int mode = !dot ? 0 : (dot->col0 == 4 ? 2 : 1);  // 1: tile workers sum, 2: the spine sums its own strips
-  const hb_geom g = hb_geometry(N, M, D, mode);
+  const hb_geom g = hb_geometry(N, M, D, dot != nullptr);
   if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
-  if (dot && (!dot->item_ptr || (dot->col0 != 3 && dot->col0 != 4)))
+  if (dot && (!dot->item_ptr || dot->col0 != 3))
     return stb_fail("stb_fill_S: the halo-block form sums over cell lists built for its tiles");
-  if (mode == 1 && g.R / 4 > HB_DOT_NQ) return stb_fail("stb_fill_S: blocks of %d rows are too long for the summing form", g.R);
-  if (mode == 2 && (dot->geom_C != g.C || dot->geom_R != g.R || dot->geom_G != g.G))
-    return stb_fail("stb_fill_S: cell lists built for %d columns a lane, blocks of %d rows, groups of %d; the fill walks %d, %d, %d",
-                    dot->geom_C, dot->geom_R, dot->geom_G, g.C, g.R, g.G);
+  if (dot && g.R / 4 > HB_DOT_NQ) return stb_fail("stb_fill_S: blocks of %d rows are too long for the summing form", g.R);
   hb_args X;
   memset(&X, 0, sizeof(X));
   X.hdr = (unsigned *)ws;
@@ -1232,13 +1064,13 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", dot ? 6 : (g.C == 4 ? 4 : 3));
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
+  X.doze = stb_env_int("STB_HB_DOZE", 1);
   if (dot) {
     X.item_ptr = dot->item_ptr;
     X.ent_pos = dot->ent_pos;
     X.ent_cnt = dot->ent_cnt;
     X.dotp = dot->dotp;
-    X.G = g.G;
-    const_cast<dot_request *>(dot)->parts_per_table = (mode == 2) ? g.JW : (int)g.n_tiles;
+    const_cast<dot_request *>(dot)->parts_per_table = (int)g.n_tiles;
   }
   if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");
@@ -1247,12 +1079,12 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
     HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
   }
-  HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  if (!dot || dot->ws_zero < g.zero_bytes) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  if (dot) const_cast<dot_request *>(dot)->zero_bytes = g.zero_bytes;
   *hdr_out = X.hdr;
-  // (the self-summing form takes column 1 -- the pairs with t = 1 -- from strip 0's halo: no S1 vector)
-  if (mode != 2 && stb_launch_s1(A, D, st)) return 1;
+  if (!(dot && dot->no_s1) && stb_launch_s1(A, D, st)) return 1;
   // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
-  const int cus = hb_cus();
+  const int cus = stb_cu_count();
   // A storing fill takes the whole chip: idle workers cost nothing any more (they wait on progress words that have
   // a line each, and ask counters of their own for tiles).  A summing fill's tiles are cheap and its spine decides:
   // ~D N / 250 worker workgroups keep up with it, and fewer waiting waves leave it the memory side (2 discounts:
@@ -1266,7 +1098,6 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     if (want < grid) grid = (unsigned)want;
   }
   if (grid < X.n_spine + min_workers) grid = X.n_spine + min_workers;
-  if (mode == 2) grid = X.n_spine;
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
   // the tile order goes to LDS when it fits beside the rest (a storing kernel's ~80 KB; a summing kernel's staging
   // rows leave no room for it)
@@ -1280,18 +1111,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     X.n_cnt = Sn * Dg;
   }
   if (X.n_cnt < 1 || X.n_cnt > HB_MAXCNT) return stb_fail("stb_fill_S: %d ticket counters", X.n_cnt);
-  if (mode == 2) {
-    size_t shm = (size_t)g.P * g.G * 64 * g.C * sizeof(double);
-    // While there are no more workgroups than compute units each should have a unit to itself -- two spine waves on
-    // one SIMD walk at half the pace, and every strip of a table moves at the pace of the slowest: ask for more than
-    // half of a unit's LDS.
-    if ((int)X.n_spine <= cus && shm < 84 * 1024 && stb_env_int("STB_HB2_ALONE", 1)) shm = 84 * 1024;
-    switch (g.C) {
-      case 2: STB_LAUNCH_SHM((k_fill_hb<2, 2>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-      case 4: STB_LAUNCH_SHM((k_fill_hb<4, 2>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-      default: return stb_fail("stb_fill_S: no self-summing halo-block kernel for %d columns per lane", g.C);
-    }
-  } else if (dot) {
+  if (dot) {
     const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
     switch (g.C) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;

@@ -1,0 +1,666 @@
+// grid_hb.hip -- the fused grid evaluation of aterms' table part: for every discount a_d of a grid,
+//     sum over the pairs (n, t), n > 1, of S_S(n, t; a_d)            (reference lib/samplea.c:68-80)
+// without ever storing a table.  The table recurrence of S_remake_part (reference lib/stable.c:321-388),
+//     S^n_m = (n-1-m a) S^{n-1}_m + S^{n-1}_{m-1},
+// is walked as in the halo-block fill (fill_hb.hip: a wave owns a strip of columns of one table for all rows,
+// block-floating cells, blocks of R rows behind a halo of R columns, hand-overs through LDS inside a workgroup and
+// through records in HBM between workgroups), but here the walking wave itself sums its strip's listed cells:
+// no tile workers, no second walk of a tile, no S1 vector (column 1 is the last element of strip 0's halo).
+//
+// What it is built around (MI355X, tools/ubench/rowpace.hip and the timelines in profiles/):
+//   * a lone wave walks a row of 2 columns per lane in 32 cycles, of 4 in 50, and one walking wave keeps a SIMD's
+//     vector issue busy: a second one on the same SIMD shares it, and every strip of a table moves at the pace
+//     of the slowest.  While the batch has no more strips than the chip has SIMDs every strip gets its own
+//     (a workgroup per compute unit, 4 strips each); beyond that the launch is cut into PHASES of blocks so that
+//     the strips the diagonal has not reached yet do not hold places (strip state travels between phases through
+//     HBM: 64 C doubles a strip);
+//   * a row of 64 C doubles staged in LDS costs 13 cycles of a compute unit's LDS store path per kilobyte, which
+//     four walking waves saturate: only every other row is staged, and a listed cell of a row in between is
+//     taken from the staged row above it by one step of the recurrence, in the look-up;
+//   * a look-up pass costs the same for 1 or 64 cells: groups of G rows are sized so that a pass is mostly full;
+//   * the log: exponent field + lane exponent go to an exact integer sum, the mantissa part to a double.
+#include <mutex>
+#include <vector>
+
+#include "fill_chain.h"
+
+#define GH_PMAX 7
+#define GH_NWMAX 8
+#define GH_MAXR 48            // rows of a block at most
+#define GH_SL 4               // ring of hand-overs between two spine waves of a workgroup (blocks)
+#define GH_FSL 4              // ring of hand-overs from the fetcher to spine wave 0
+#define GH_EOFF32 (1u << 30)
+#define GH_WRITTEN 0x8000000000000000ull
+#define GH_SPIN 48
+#define GH_MAXPH 16           // phases at most
+
+struct gh_args {
+  const double *a;             // [D] discounts
+  const double2 *lt;           // log table
+  unsigned *hdr;               // [1] error code, [2] error detail (shared by the phases)
+  unsigned *ticket;            // this phase's role ticket
+  unsigned long long *ck_v;    // [D][B][NB][HL * C] records: the rightmost HL lanes of a workgroup's last strip before a block
+  unsigned *ck_e;              // [D][B][NB][HL]     ... and their lane exponents + GH_EOFF32
+  double *state_v;             // [D][JW][64 * C]  a strip's significands between two phases
+  int *state_e;                // [D][JW][64]      ... and lane exponents
+  const unsigned *tile_off;    // [JW + 2], entry j + 1: tiles of the strips before strip j (a strip's tiles are its blocks from its first one on)
+  const unsigned *dense;       // [n_tiles * NQ][64] the listed cells of every (tile, group of G rows), a word per lane:
+                               // (row in group << 8 | element of the wave, halo included) | count << 13, 0 for none;
+                               // 0xffffffff in lane 63: more than 63 cells, or a large count -- see the three lists below
+  const unsigned *item_ptr;    // [n_tiles * NQ + 1] first list entry of every (tile, group)
+  const unsigned short *ent_pos;  // row in group << 8 | element of the wave
+  const unsigned *ent_cnt;     // occurrence count
+  double *dotp;                // [D][JW][2]: sum of count x binary exponent (an integer), sum of count x log of the mantissa part
+  unsigned N, M;
+  int D, B, JW, NB;            // tables, workgroups per table (all phases), strips per table, blocks
+  int P, R, HL, U;             // spine waves per workgroup, rows per block, halo lanes, own lanes
+  int JWa, b_begin, b_end;     // this phase: strips whose first block lies before b_end, blocks [b_begin, b_end)
+  unsigned long long timeout;  // wall_clock64 ticks a wait may last
+  int poll_nap;
+  int diag;                    // STB_GRID_DIAG: 4 no look-ups, 8 nothing staged either (results wrong)
+  unsigned long long *dbg;     // STB_HB_TIMELINE: table 0, [JW][NB + 2] (start, block starts, end)
+};
+
+typedef double gh_double2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gh_store_wt16(unsigned long long *p, unsigned long long a, unsigned long long b) {
+  typedef unsigned long long gh_u64x2 __attribute__((ext_vector_type(2)));
+  const gh_u64x2 v2 = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v2) : "memory");
+}
+
+template <int C>
+__device__ __forceinline__ void gh_renorm(double (&v)[C], int &ep) {
+  double vmax = v[0];
+#pragma unroll
+  for (int i = 1; i < C; i++) vmax = fmax(vmax, v[i]);
+  const int sh = (vmax != 0.0) ? __builtin_amdgcn_frexp_exp(vmax) + PC_BIAS : 0;
+#pragma unroll
+  for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -sh);
+  ep += sh;
+}
+
+template <int C>
+__device__ __forceinline__ void gh_row(double (&v)[C], double (&coef)[C], double s) {
+  const double t0 = wave_shr1_zero(v[C - 1]) * s;
+#pragma unroll
+  for (int i = C - 1; i >= 1; i--) v[i] = fma(coef[i], v[i], v[i - 1]);
+  v[0] = fma(coef[0], v[0], t0);
+#pragma unroll
+  for (int i = 0; i < C; i++) coef[i] += 1.0;
+}
+
+__host__ __device__ static inline int gh_first_block(int j, int UC, int R) { return (int)(((long long)j * UC) / R); }
+
+// One look-up pass: every lane with `valid` takes one listed cell of the group just walked.  Rows 0, 2, 4, .. of
+// the group are staged (row r at stage + (r / 2) WS); a cell of an odd row is one step of the recurrence away from
+// the staged row above it -- the very operations the walking wave itself performs for that cell.
+template <int C>
+__device__ __forceinline__ void gh_lookup(bool valid, unsigned pos, unsigned cnt, const double *stage, const int *se,
+                                          const double2 *lt, double a, int mE0, int nrow0, int one_hi, long long &accK, double &accF) {
+  constexpr int WS = 64 * C;
+  if (valid) {
+    const int cw = (int)(pos & 255u), r = (int)(pos >> 8) & 31;
+    const double *row = stage + (r >> 1) * WS;
+    const double A = row[cw];
+    const double Bq = row[cw - 1 < 0 ? 0 : cw - 1];
+    const int ln = cw / C;
+    const int e = se[ln];
+    // (the element to the left lives in the lane to the left, under that lane's exponent: the factor the walk uses)
+    const int dl = (ln > 0 ? se[ln - 1] : e) - e;
+    const double sfac = ((cw & (C - 1)) == 0) ? ldexp(1.0, min(max(dl, -1100), 220)) : 1.0;
+    // coefficient of row n = nrow0 + r at column m = mE0 + cw: n - 1 - m a
+    const double coef = fma(-(double)(mE0 + cw), a, (double)(nrow0 + r - 1));
+    const double x = (r & 1) ? fma(coef, A, Bq * sfac) : A;
+    const int hi = __double2hiint(x);
+    const double2 t = lt[(hi >> 13) & 127];
+    const double z = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x));
+    const double rr = fma(z, t.x, -1.0);
+    double pl = fma(rr, 0.2, -0.25);
+    pl = fma(rr, pl, 1.0 / 3.0);
+    pl = fma(rr, pl, -0.5);
+    pl = fma(rr, pl, 1.0);
+    const int kx = (int)((hi >> 20) & 0x7ff) - 1023 + e;
+    accK += (long long)(int)cnt * (long long)kx;
+    accF = fma((double)cnt, fma(rr, pl, t.y), accF);
+  }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
+  static_assert(C == 2 || C == 4, "columns per lane");
+  static_assert(G % 2 == 0 && G >= 2 && G <= 32, "rows per group");
+  constexpr int WS = 64 * C, SR = G / 2;  // doubles of a staged row, staged rows of a group
+  constexpr int MHL = GH_MAXR / C;
+  constexpr int SL = GH_SL, SLH = SL / 2, FSL = GH_FSL;
+  __shared__ double2 lt[128];
+  __shared__ __attribute__((aligned(16))) double xv[GH_PMAX][SL][MHL * C];
+  __shared__ int xe[GH_PMAX][SL][MHL];
+  __shared__ __attribute__((aligned(16))) double fv[FSL][MHL * C];
+  __shared__ int fe[FSL][MHL];
+  __shared__ int posted[GH_NWMAX], taken[GH_NWMAX], fetched, s_abort, s_awake;
+  __shared__ unsigned s_ticket;
+  __shared__ int w_se[GH_PMAX][64];
+  extern __shared__ __attribute__((aligned(16))) double gh_dyn[];  // per spine wave SR staged rows
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_ticket = atomicAdd(X.ticket, 1u);
+  if (tid < 128) lt[tid] = X.lt[tid];
+  __syncthreads();
+  const unsigned ticket = s_ticket;
+  const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
+  const int UC = U * C;
+  const int bB = X.b_begin, bE = X.b_end;
+  // strip-major tickets: a strip only ever waits for strips with smaller tickets, which are running or done
+  const int j = (int)(ticket / (unsigned)X.D);
+  const int d = (int)(ticket % (unsigned)X.D);
+  const int jw0 = j * P;
+  if (tid < GH_NWMAX) {
+    const int jw = jw0 + tid;
+    const int b0 = (jw < X.JWa) ? max(gh_first_block(jw, UC, R), bB) : bE;
+    posted[tid] = b0;
+    taken[tid] = b0;
+  }
+  if (tid == 0) {
+    fetched = max(gh_first_block(jw0, UC, R), bB);
+    s_abort = 0;
+    s_awake = (j == 0) ? 1 : 0;
+  }
+  __syncthreads();
+  const unsigned who = (unsigned)(j | (d << 16));
+
+  if (wave < P) {
+    // ================= spine waves =================
+    const int w = wave;
+    const int jw = jw0 + w;
+    if (jw >= X.JWa) return;
+    bool aborted = false;
+    auto wait_ge = [&](const int *cnt, int need, unsigned code) {
+      if (aborted) return;
+      for (int k = 0; k < GH_SPIN; k++) {
+        if (lds_peek(cnt) >= need) {
+          asm volatile("" ::: "memory");
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!chain_wait_slow(cnt, need, &s_abort, X.hdr, X.timeout, code, who, 1)) aborted = true;
+      asm volatile("" ::: "memory");
+    };
+    const int b00 = gh_first_block(jw, UC, R);  // the strip's own first block
+    const int b0 = max(b00, bB);                // ... and its first one in this phase
+    const double a = X.a[d];
+    const int mE0 = 2 + (jw * U - HL) * C;      // column of the wave's first element (halo included; <= 0 in strip 0's halo)
+    const int m0 = mE0 + lane * C;
+    const size_t strip = (size_t)d * X.JW + jw;
+    double v[C], coef[C];
+    int ep = 1 + PC_BIAS;
+    if (b00 < bB) {
+      // (the state the previous phase left: plain loads, another launch wrote it)
+#pragma unroll
+      for (int i = 0; i < C; i++) v[i] = X.state_v[(strip * 64 + lane) * C + i];
+      ep = X.state_e[strip * 64 + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < C; i++) v[i] = 0.0;
+      if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
+    }
+#pragma unroll
+    for (int i = 0; i < C; i++) coef[i] = 0.0;
+    int one_hi = 0x3ff00000;
+    asm volatile("" : "+v"(one_hi));
+    const bool has_next = (w + 1 < P) && (jw + 1 < X.JWa);
+    const int *left_cnt = (w == 0) ? &fetched : &posted[w > 0 ? w - 1 : 0];
+    const double *left_v = (w == 0) ? &fv[0][0] : &xv[w > 0 ? w - 1 : 0][0][0];
+    const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
+    const int left_mask = (w == 0) ? FSL - 1 : SL - 1;
+    unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
+    // records: only the next workgroup's fetcher reads them, and only the rightmost HL lanes of this workgroup's last strip
+    const bool rec = (w == P - 1) && (jw + 1 < X.JWa) && lane >= U;
+    const size_t rec_base = ((size_t)d * X.B + j) * (size_t)NB;
+    unsigned long long *rec_v = X.ck_v + (rec_base * HL + (lane - U)) * C;
+    unsigned *rec_e = X.ck_e + rec_base * HL + (lane - U);
+    double s = 1.0;
+    double *stage = gh_dyn + (size_t)w * (size_t)(SR * WS);
+    int *se = &w_se[w][0];
+    const int NQ = R / G;
+    // the strip's listed cells, group after group in (block, group of G rows) order: a word per lane, asked for a
+    // group ahead (the address needs no look-up)
+    const size_t item0 = (size_t)X.tile_off[jw + 1] * (size_t)NQ;  // items of tile (jw, b00)
+    const unsigned *dns = X.dense + (item0 + (size_t)(b0 - b00) * NQ) * 64 + lane;  // the next group's word
+    unsigned wcur = (b0 < bE) ? *dns : 0u;
+    dns += 64;
+    long long accK = 0;
+    double accF = 0.0;
+    // Everything is set up before the wave dozes until its first halo is about to arrive: a strip never makes up
+    // for a late start, and a wave that spins takes issue slots from the walking wave it shares a SIMD with.
+    while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
+    if (w > 0)
+      while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_setprio(3);
+    if (dbg) dbg[0] = wall_clock64();
+    for (int b = b0; b < bE; b++) {
+      if (b > b00) gh_renorm<C>(v, ep);
+      // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
+      if (has_next) {
+        if ((b & (SLH - 1)) == 0 || b == b0) wait_ge(&taken[w + 1], b - SLH, 0x400u);
+        if (lane >= U) {
+          double *dst = &xv[w][b & (SL - 1)][(lane - U) * C];
+#pragma unroll
+          for (int i = 0; i < C; i++) dst[i] = v[i];
+          xe[w][b & (SL - 1)][lane - U] = ep;
+        }
+        lds_post(&posted[w], b + 1);
+      }
+      // ---- ... and for the next workgroup: the record of the block ----
+      if (rec) {
+        unsigned long long *dst = rec_v + (size_t)b * (size_t)(HL * C);
+#pragma unroll
+        for (int i = 0; i < C; i += 2)
+          gh_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]) | GH_WRITTEN,
+                        (unsigned long long)__double_as_longlong(v[i + 1]) | GH_WRITTEN);
+        __hip_atomic_store(rec_e + (size_t)b * (size_t)HL, (unsigned)ep + GH_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
+      if (jw > 0) {
+        double hv[C];
+        int he = 0;
+        const double *src = left_v + (b & left_mask) * (MHL * C) + lane * C;
+        const int *srce = left_e + (b & left_mask) * MHL + lane;
+        const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
+        asm volatile("" ::: "memory");
+        if (lane < HL) {
+#pragma unroll
+          for (int i = 0; i < C; i++) hv[i] = src[i];
+          he = *srce;
+        }
+        if (seen < b + 1) {
+          wait_ge(left_cnt, b + 1, 0x100u);
+          if (lane < HL) {
+#pragma unroll
+            for (int i = 0; i < C; i++) hv[i] = src[i];
+            he = *srce;
+          }
+        }
+        if (lane < HL) {
+#pragma unroll
+          for (int i = 0; i < C; i++) v[i] = hv[i];
+          ep = he;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_post(&taken[w], b + 1);
+      }
+      if (dbg) dbg[1 + b] = wall_clock64();
+      {
+        const int dl = wave_shr1(ep, ep) - ep;
+        s = ldexp(1.0, min(max(dl, -1100), 220));
+      }
+      // (the coefficient n - 1 - m a of the next row, from its closed form at every block: + 1 a row drifts)
+#pragma unroll
+      for (int i = 0; i < C; i++) coef[i] = (double)(1 + b * R) - (double)(m0 + i) * a;
+      se[lane] = ep;
+      for (int q = 0; q < NQ; q++) {
+        // (this group's list is looked at BEFORE the next one is asked for: the compiler waits for every load under
+        // way where a loaded register is first read inside a loop, the one just issued included)
+        const bool listed = __ballot(wcur != 0) != 0;
+        asm volatile("" ::: "memory");
+        // the next group's list is asked for now: it arrives while this group is walked
+        unsigned wnext = 0;
+        if (q + 1 < NQ || b + 1 < bE) wnext = *dns;
+        dns += 64;
+        if (listed && !(X.diag & 8)) {
+#pragma unroll
+          for (int r = 0; r < G; r++) {
+            gh_row<C>(v, coef, s);
+            if ((r & 1) == 0) {
+              double *dst = stage + (r >> 1) * WS + lane * C;
+              if constexpr (C == 4) {
+                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
+                *reinterpret_cast<gh_double2 *>(dst + 2) = gh_double2{v[2], v[3]};
+              } else {
+                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
+              }
+            }
+          }
+          const int nrow0 = 2 + b * R + q * G;  // the row the group's first step produces
+          if ((unsigned)__builtin_amdgcn_readlane((int)wcur, 63) != 0xffffffffu) {
+            if (!(X.diag & 4)) gh_lookup<C>(wcur != 0, wcur & 0x1fffu, wcur >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+          } else {
+            // (more than 63 listed cells in the group, or a count of 2^19 or more: rare; the lists in CSR form)
+            const size_t item = item0 + (size_t)(b - b00) * NQ + q;
+            const unsigned e0 = X.item_ptr[item], e1 = X.item_ptr[item + 1];
+            for (unsigned kk = e0; kk < e1; kk += 64) {
+              unsigned pos = 0, cnt = 0;
+              if (kk + lane < e1) {
+                pos = X.ent_pos[kk + lane];
+                cnt = X.ent_cnt[kk + lane];
+              }
+              gh_lookup<C>(kk + lane < e1, pos, cnt, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+            }
+          }
+        } else {
+          // (a group none of whose cells occurs is only walked)
+#pragma unroll
+          for (int r = 0; r < G; r++) gh_row<C>(v, coef, s);
+        }
+        wcur = wnext;
+      }
+    }
+    // the strip's two sums, over the wave in a fixed tree: the same bits on every run.  (The exponent sum is an
+    // integer well below 2^53: exact in a double, whatever the order.)
+    double kd = (double)accK;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      kd += __shfl_xor(kd, o);
+      accF += __shfl_xor(accF, o);
+    }
+    if (lane == 0) {
+      double *out = X.dotp + strip * 2;
+      if (b00 < bB) {  // (what the earlier phases summed: this wave is the strip's only writer in this launch)
+        kd += out[0];
+        accF = out[1] + accF;
+      }
+      out[0] = kd;
+      out[1] = accF;
+    }
+    if (bE < NB) {
+#pragma unroll
+      for (int i = 0; i < C; i++) X.state_v[(strip * 64 + lane) * C + i] = v[i];
+      X.state_e[strip * 64 + lane] = ep;
+    }
+    if (dbg) dbg[NB + 1] = wall_clock64();
+    __builtin_amdgcn_s_setprio(0);
+  } else if (wave == P && j > 0 && jw0 < X.JWa) {
+    // ================= fetcher: the left workgroup's last strip's records -> LDS, for spine wave 0 =================
+    const int gl = (HL <= 16) ? 16 : 32;
+    const int grp = lane / gl, sub = lane % gl, ngrp = 64 / gl;
+    const bool act = sub < HL;
+    const size_t rec_left = ((size_t)d * X.B + (j - 1)) * (size_t)NB;
+    int bb = max(gh_first_block(jw0, UC, R), bB);  // blocks below it are delivered
+    bool woke = false;
+    unsigned long long t_begin = 0;
+    bool timing = false;
+    unsigned idle = 0;
+    while (bb < bE) {
+      const int mb = bb + grp;
+      const bool want = act && mb < bE;
+      unsigned long long bv[C];
+      unsigned be = 1;
+#pragma unroll
+      for (int i = 0; i < C; i++) bv[i] = 1;
+      if (want) {
+        const unsigned long long *src = X.ck_v + ((rec_left + mb) * HL + sub) * C;
+#pragma unroll
+        for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        be = __hip_atomic_load(X.ck_e + (rec_left + mb) * HL + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int tk = lds_peek(&taken[0]);
+      bool have = be != 0;
+#pragma unroll
+      for (int i = 0; i < C; i++) have = have && bv[i] != 0;
+      const unsigned long long miss = ~__ballot(have);
+      int k = miss ? (int)(__builtin_ctzll(miss) / gl) : ngrp;
+      k = min(k, bE - bb);
+      k = min(k, tk + FSL - bb);
+      if (k > 0) {
+        if (want && grp < k) {
+          double *dst = &fv[mb & (FSL - 1)][sub * C];
+#pragma unroll
+          for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)(bv[i] & ~GH_WRITTEN));
+          fe[mb & (FSL - 1)][sub] = (int)(be - GH_EOFF32);
+        }
+        bb += k;
+        lds_post(&fetched, bb);
+        if (!woke) {
+          woke = true;
+          lds_post(&s_awake, 1);
+        }
+        timing = false;
+        idle = 0;
+        continue;
+      }
+      for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
+      if (!woke) __builtin_amdgcn_s_sleep(4);
+      if ((++idle & 31) != 0 && X.timeout != 0) continue;
+      if (!timing) {
+        timing = true;
+        t_begin = wall_clock64();
+      }
+      const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (err != 0 || lds_peek(&s_abort) || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+        if (lane == 0) {
+          __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (err == 0) {
+            __hip_atomic_store(X.hdr + 2, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        lds_post(&fetched, 0x7fffffff);  // release the spine: it runs on with stale halos
+        lds_post(&s_awake, 1);
+        break;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
+  grid_geom g;
+  memset(&g, 0, sizeof(g));
+  *out = g;
+  if (N < 3 || M < 2 || D < 1 || N >= (1u << 20)) return 1;
+  const int cus = stb_cu_count();
+  const unsigned cmax = (M < N - 1) ? M : N - 1;  // columns 2..cmax hold stored cells: elements 0 .. cmax - 2
+  int Pc = stb_period_rows(N);
+  const int Penv = stb_env_int("STB_FILL_P", 0);
+  if (Penv > 0 && Penv < Pc) Pc = Penv;
+  int R = stb_env_int("STB_GRID_ROWS", GH_MAXR);
+  if (R > Pc) R = Pc;
+  if (R > GH_MAXR) R = GH_MAXR;
+  R = R / 8 * 8;
+  if (R < 8) return 1;
+  // 2 columns per lane -- the faster walk, 32 against 50 cycles a row -- while every strip of the batch gets a SIMD
+  // to itself (one workgroup of 4 strips per compute unit); 4 beyond: 2.6 times fewer waves for the same columns
+  {
+    const int HL2 = R / 2, U2 = 64 - HL2;
+    const uint64_t strips2 = (cmax - 1 + U2 * 2 - 1) / (U2 * 2);
+    const uint64_t wgs2 = (strips2 + 3) / 4 * (uint64_t)D;
+    g.C = stb_env_int("STB_GRID_C", wgs2 <= (uint64_t)cus ? 2 : 4);
+    if (g.C != 2 && g.C != 4) g.C = 2;
+  }
+  g.R = R;
+  g.HL = R / g.C;
+  g.U = 64 - g.HL;
+  const int UC = g.U * g.C;
+  g.JW = (int)((cmax - 1 + UC - 1) / UC);
+  if (g.JW < 1) g.JW = 1;
+  g.NB = (int)((N - 1 + R - 1) / R);
+  if (g.JW >= 65535 || g.NB >= 65536) return 1;
+  // strips per workgroup: 4, a walking wave per SIMD (MI355X, 64 discounts x 10^6 pairs, N = M = 10^4, groups of 12
+  // rows, kernel ms: 3 strips 1.84, 4: 1.73, 5: 1.81, 6: 1.90, 7: 1.85)
+  g.P = stb_env_int("STB_GRID_P", 4);
+  if (g.P < 1 || g.P > GH_PMAX) g.P = 4;
+  g.B = (g.JW + g.P - 1) / g.P;
+  // rows per group: a look-up pass costs the same for 1 or 64 listed cells (10^6 pairs over a 10^4 x 10^4 table: 1.6
+  // a row in a strip of 80 columns, 4.2 in one of 208), and half of a group's rows are staged in LDS per walking wave
+  // (1 KB a row with 2 columns per lane, 2 KB with 4) beside ~16 KB of rings: two workgroups must fit a compute unit's
+  // 160 KB once there are more workgroups than units
+  {
+    // (4 columns per lane, 64 discounts as above: groups of 8 rows 1.85, 12: 1.73, 16: 1.97)
+    const bool two_per_cu = (int64_t)g.B * D > cus;
+    int Gd = (g.C == 2) ? 24 : ((g.P > 4 && two_per_cu) ? 8 : 12);
+    Gd = stb_env_int("STB_GRID_G", Gd);
+    while (Gd > 2 && (R % Gd != 0 || (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24))) Gd -= 2;
+    if (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24) Gd = 8;
+    if (R % Gd != 0) return 1;  // (R is a multiple of 8: cannot happen)
+    g.G = Gd;
+    g.NQ = R / Gd;
+  }
+  uint64_t nt = 0;
+  for (int j = 0; j < g.JW; j++) {
+    const int b0 = gh_first_block(j, UC, R);
+    if (b0 >= g.NB) return 1;  // (cannot happen: column 2 + j U C <= N - 1)
+    nt += (uint64_t)(g.NB - b0);
+  }
+  if (nt * g.NQ >= (1ull << 31)) return 1;
+  g.n_tiles = (unsigned)nt;
+  // Phases.  One walking wave keeps a SIMD's vector issue busy and every strip of a table moves at the pace of the
+  // slowest, while the strips right of the diagonal have nothing to do yet: with more strips than SIMDs the launch is
+  // cut into phases of blocks, each launched with the strips the diagonal reaches before its end -- evenly spread
+  // by the dispatcher because they all work for the whole phase.
+  {
+    // (Measured, 64 discounts as above: 1 launch 1.62, 2: 1.66, 4: 1.73, 6: 1.77 -- what the phases gain in balance
+    // they lose at their starts, where every table's chain of strips builds up again: one launch unless asked.)
+    int ph = stb_env_int("STB_GRID_PHASES", 1);
+    if (ph < 1) ph = 1;
+    if (ph > GH_MAXPH) ph = GH_MAXPH;
+    if (ph > g.NB) ph = g.NB;
+    g.phases = ph;
+  }
+  size_t o = 256 + 64 * GH_MAXPH;  // header: error words, then a ticket word per phase on a line of its own
+  o = stb_align_up(o, 256);
+  g.off_cke = o;
+  o += stb_align_up((size_t)D * g.B * g.NB * g.HL * sizeof(unsigned), 256);
+  g.off_ckv = o;
+  o += stb_align_up((size_t)D * g.B * g.NB * g.HL * g.C * 8, 256);
+  g.zero_bytes = o;
+  g.off_state_e = o;
+  o += stb_align_up((size_t)D * g.JW * 64 * sizeof(int), 256);
+  g.off_state_v = o;
+  o += stb_align_up((size_t)D * g.JW * 64 * g.C * 8, 256);
+  g.bytes = o;
+  g.ok = 1;
+  *out = g;
+  return 0;
+}
+
+size_t stb_grid_workspace(unsigned N, unsigned M, int D) {
+  // (the strip shape depends on the batch and on tunables: room for either number of columns per lane)
+  size_t need = 0;
+  grid_geom g;
+  if (stb_grid_geometry(N, M, D, &g) == 0) need = g.bytes;
+  const int cs[2] = {2, 4};
+  const int Pc = stb_period_rows(N);
+  int R = GH_MAXR < Pc ? GH_MAXR : Pc;
+  R = R / 8 * 8;
+  if (R < 8 || N < 3 || M < 2) return need;
+  const unsigned cmax = (M < N - 1) ? M : N - 1;
+  for (int c : cs) {
+    const int HL = R / c, U = 64 - HL, UC = U * c;
+    const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R, B = (JW + 3) / 4;
+    const size_t b = 4096 + (size_t)D * B * NB * HL * (4 + 8 * c) + (size_t)D * JW * 64 * (4 + 8 * c) + 2048;
+    if (b > need) need = b;
+  }
+  return need + 256;
+}
+
+// first tile of every strip (entry j + 1; a strip's tiles are its blocks from its first one on), [JW + 2] words
+void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off) {
+  off.assign((size_t)g.JW + 2, 0u);
+  const int UC = g.U * g.C;
+  unsigned o = 0;
+  for (int j = 0; j < g.JW; j++) {
+    off[j + 1] = o;
+    o += (unsigned)(g.NB - gh_first_block(j, UC, g.R));
+  }
+  off[0] = o;  // (the total, for whoever wants to check)
+}
+
+template <int C>
+static int gh_launch(const gh_args &X, int G, unsigned grid, int P, hipStream_t st) {
+  const size_t shm = (size_t)P * (size_t)(G / 2) * 64 * C * sizeof(double);
+  size_t ask = shm;
+  // While there are no more workgroups than compute units each should have a unit to itself (two walking waves on
+  // one SIMD share its issue, and every strip moves at the pace of the slowest): ask for more than half of a unit's LDS.
+  if ((int)grid <= stb_cu_count() && ask < 84 * 1024 && stb_env_int("STB_GRID_ALONE", 1)) ask = 84 * 1024;
+  const dim3 block(64 * (P + 1));
+  switch (G) {
+    case 8: STB_LAUNCH_SHM((k_grid_hb<C, 8>), dim3(grid), block, ask, st, X); break;
+    case 12: STB_LAUNCH_SHM((k_grid_hb<C, 12>), dim3(grid), block, ask, st, X); break;
+    case 16: STB_LAUNCH_SHM((k_grid_hb<C, 16>), dim3(grid), block, ask, st, X); break;
+    case 24: STB_LAUNCH_SHM((k_grid_hb<C, 24>), dim3(grid), block, ask, st, X); break;
+    default: return stb_fail("stb_groups_aterms: no grid kernel for groups of %d rows", G);
+  }
+  return 0;
+}
+
+int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
+  const unsigned N = A.N, M = A.M;
+  grid_geom g;
+  if (stb_grid_geometry(N, M, D, &g)) return stb_fail("stb_groups_aterms: the grid form does not take N=%u M=%u D=%d", N, M, D);
+  if (g.bytes > ws_left) return stb_fail("stb_groups_aterms: workspace too small for the grid form (%zu > %zu)", g.bytes, ws_left);
+  if (!dot || !dot->item_ptr || !dot->tile_off || !dot->dense || dot->col0 != 4)
+    return stb_fail("stb_groups_aterms: the grid form sums over cell lists built for its strips");
+  if (dot->geom_C != g.C || dot->geom_R != g.R || dot->geom_G != g.G)
+    return stb_fail("stb_groups_aterms: cell lists built for %d columns a lane, blocks of %d rows, groups of %d; the walk is %d, %d, %d",
+                    dot->geom_C, dot->geom_R, dot->geom_G, g.C, g.R, g.G);
+  gh_args X;
+  memset(&X, 0, sizeof(X));
+  X.a = A.a;
+  X.lt = A.lt;
+  X.hdr = (unsigned *)ws;
+  X.ck_e = (unsigned *)(ws + g.off_cke);
+  X.ck_v = (unsigned long long *)(ws + g.off_ckv);
+  X.state_e = (int *)(ws + g.off_state_e);
+  X.state_v = (double *)(ws + g.off_state_v);
+  X.tile_off = dot->tile_off;
+  X.dense = dot->dense;
+  X.item_ptr = dot->item_ptr;
+  X.ent_pos = dot->ent_pos;
+  X.ent_cnt = dot->ent_cnt;
+  X.dotp = dot->dotp;
+  X.N = N;
+  X.M = M;
+  X.D = D;
+  X.B = g.B;
+  X.JW = g.JW;
+  X.NB = g.NB;
+  X.P = g.P;
+  X.R = g.R;
+  X.HL = g.HL;
+  X.U = g.U;
+  X.timeout = (unsigned long long)stb_env_int("STB_CHAIN_TIMEOUT_MS", 2000) * 100000ull;  // wall_clock64: 100 MHz
+  X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
+  if (X.poll_nap < 1) X.poll_nap = 1;
+  X.diag = stb_env_int("STB_GRID_DIAG", 0);
+  const_cast<dot_request *>(dot)->parts_per_table = g.JW;
+  const char *tl_file = getenv("STB_HB_TIMELINE");
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2);
+  if (tl_file && *tl_file) {
+    HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
+    HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
+  }
+  if (!dot || dot->ws_zero < g.zero_bytes) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  if (dot) const_cast<dot_request *>(dot)->zero_bytes = g.zero_bytes;
+  *hdr_out = X.hdr;
+  const int UC = g.U * g.C;
+  for (int ph = 0; ph < g.phases; ph++) {
+    X.b_begin = (int)((int64_t)g.NB * ph / g.phases);
+    X.b_end = (int)((int64_t)g.NB * (ph + 1) / g.phases);
+    if (X.b_end <= X.b_begin) continue;
+    int jwa = 0;
+    while (jwa < g.JW && gh_first_block(jwa, UC, g.R) < X.b_end) jwa++;
+    X.JWa = jwa;
+    X.ticket = X.hdr + 64 + 16 * ph;
+    const unsigned grid = (unsigned)((jwa + g.P - 1) / g.P) * (unsigned)D;
+    if (g.C == 2 ? gh_launch<2>(X, g.G, grid, g.P, st) : gh_launch<4>(X, g.G, grid, g.P, st)) return 1;
+  }
+  HIPCHK(hipGetLastError());
+  if (X.dbg) {
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(dbg_words);
+    HIPCHK(hipMemcpy(h.data(), X.dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(X.dbg);
+    FILE *f = fopen(tl_file, "wb");
+    if (f) {
+      const int hd[8] = {g.JW, g.NB, 0, g.C, g.P, g.R, g.U, D};  // (the format of tools/timeline_hb.py, no tile part)
+      fwrite(hd, sizeof(int), 8, f);
+      fwrite(h.data(), 8, dbg_words, f);
+      fclose(f);
+    }
+  }
+  return 0;
+}

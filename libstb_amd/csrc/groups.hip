@@ -4,10 +4,15 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 
+#include <vector>
+
 #include "stb_common.h"
+
+void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off);  // grid_hb.hip
 
 #define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
 #define STB_NLISTS 5
+#define STB_WS_FORM 4096  // lean flow: the discounts at the start of d_ws_fill, the form's workspace from here
 
 // ------------------------------------------------------------------------------------------------
 // device-resident group set
@@ -46,14 +51,18 @@ struct stb_groups {
   unsigned nsg;
   int lists_ready[STB_NLISTS];
   int list_R[STB_NLISTS], list_G[STB_NLISTS];  // [3], [4]: the block and group length the list was built for
+  unsigned *d_tile_off[STB_NLISTS];            // [3], [4]: first tile of every strip (grid_hb.hip)
+  unsigned *d_dense[STB_NLISTS];               // [3], [4]: a word per lane and (tile, group): the list the walk reads
   uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
   // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
-  double *h_out;  // pinned, [2][Dmax]: what the stream copies the sums to
+  double *h_out;  // pinned, [2][Dmax] + 2: what the stream copies the sums to (lean flow: totals, then the fill's error words)
+  double *h_out_dev;           // the device's address of it
+  size_t ws_zero;              // bytes from the start of d_ws_fill + STB_WS_FORM known to be zero (lean flow)
+  int pend_lean;               // the queued evaluation took the lean flow
   hipEvent_t ev_dep;
   int pending, pend_D, pend_fuse, pend_v;
   int sel_which;  // the list layout aterms_prepare chose for a fused evaluation in the halo-block form
-  unsigned pend_fb0;
   double *pend_out;
   double pend_x[STB_TERMS_DMAX];
   last_fill pend_fill;
@@ -123,7 +132,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
                   g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
                   g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
-                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4]};
+                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -166,31 +175,54 @@ __global__ __launch_bounds__(256) void k_dot_reduce(const double *dotp, int part
   if (threadIdx.x == 0) out[d] += tot.hi + tot.lo;
 }
 
-// ... of the self-summing form: per strip an exact sum of binary exponents and a sum of mantissa logs.  `inf` pairs
-// have S_S = log 0 (lib/stable.c:948-949): the reference's sum is then -inf whatever the rest.
-__global__ __launch_bounds__(256) void k_dot2_reduce(const double *dotp, int parts, double *out, unsigned long long inf) {
+// Last launch of a fused evaluation in the halo-block or the grid form: per discount the fill's partial sums
+// (mode 1: one double per tile; mode 2: per strip an exact exponent sum and a mantissa-log sum) and the restaurant
+// terms' partial sums, each in a fixed order, their total written to pinned host memory together with the fill's
+// error words -- so that the host waits ONCE and copies nothing.
+__global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts, int mode, const dd_t *tpart, int nbt, unsigned long long inf,
+                                                   const unsigned *hdr, double *out_dev, double *out_host, int Dmax) {
   __shared__ dd_t red[4];
+  __shared__ double ks[4];
   const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
   const int d = blockIdx.x;
   dd_t acc{0.0, 0.0};
   double k = 0.0;  // (integers below 2^53: exact in any order)
-  for (int i = threadIdx.x; i < parts; i += 256) {
-    k += dotp[((size_t)d * parts + i) * 2];
-    dd_add(acc, dotp[((size_t)d * parts + i) * 2 + 1]);
+  if (mode == 2) {
+    for (int i = threadIdx.x; i < parts; i += 256) {
+      k += dotp[((size_t)d * parts + i) * 2];
+      dd_add(acc, dotp[((size_t)d * parts + i) * 2 + 1]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < parts; i += 256) dd_add(acc, dotp[(size_t)d * parts + i]);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) k += __shfl_down(k, off, 64);
-  __shared__ double ks[4];
   if ((threadIdx.x & 63) == 0) ks[threadIdx.x >> 6] = k;
   dd_t tot = block_reduce_dd(acc, red);
+  dd_t tv{0.0, 0.0};
+  for (int b = threadIdx.x; b < nbt; b += 256) dd_merge(tv, tpart[(size_t)d * nbt + b]);
+  tv = block_reduce_dd(tv, red);
   if (threadIdx.x == 0) {
-    k = (ks[0] + ks[1]) + (ks[2] + ks[3]);
-    // k ln2 in two pieces: k < 2^38 and LN2_HI has 32 trailing zero bits, so the first product rounds at 2^-53 relative
-    dd_add(tot, k * LN2_LO);
-    dd_add(tot, k * LN2_HI);
-    out[d] = inf ? -HUGE_VAL : tot.hi + tot.lo;
+    if (mode == 2) {
+      k = (ks[0] + ks[1]) + (ks[2] + ks[3]);
+      // k ln2 in two pieces: k < 2^38 and LN2_HI has 32 trailing zero bits, so the first product rounds at 2^-53 relative
+      dd_add(tot, k * LN2_LO);
+      dd_add(tot, k * LN2_HI);
+    }
+    const double dots = inf ? -HUGE_VAL : tot.hi + tot.lo;
+    const double terms = tv.hi + tv.lo;
+    out_dev[d] = dots;
+    out_dev[Dmax + d] = terms;
+    out_host[d] = terms + dots;
+    if (d == 0) {
+      out_host[2 * Dmax] = (double)hdr[1];
+      out_host[2 * Dmax + 1] = (double)hdr[2];
+    }
   }
 }
+
+int stb_restaurant_partials(const double *x_host, int D, const uint32_t *d_T, const double *d_bpar, uint64_t I, void *d_ws,
+                            size_t ws_bytes, double *a_out, const dd_t **partial_out, int *nb_out, hipStream_t st);  // sweep_terms.hip
 
 static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
                                         const uint16_t *tflat, const double *bpar, unsigned N, unsigned M, int Dmax) {
@@ -229,7 +261,8 @@ static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, 
   GCHK(stb_pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * Dmax));
   GCHK(stb_pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)N * Dmax));
   GCHK(stb_pool_malloc((void **)&g->d_out, sizeof(double) * 2 * Dmax));
-  GCHK(stb_pool_malloc((void **)&g->h_out, sizeof(double) * 2 * Dmax, 1));
+  GCHK(stb_pool_malloc((void **)&g->h_out, sizeof(double) * (2 * Dmax + 2), 1));
+  GCHK(hipHostGetDevicePointer((void **)&g->h_out_dev, g->h_out, 0));
   GCHK(hipEventCreateWithFlags(&g->ev_dep, hipEventDisableTiming));
   g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
   g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
@@ -293,10 +326,17 @@ __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G,
   if (g >= G) return;
   const unsigned nn = n[g], tt = t[g];
   uint64_t k;
-  if (nn <= 1) k = STB_KEY_SKIP;
-  else if (nn == tt || tt <= 1 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
+  // (column 1 -- t = 1 -- is a cell too: the last element of strip 0's halo, which that strip's tiles compute along;
+  // a pair with t = n contributes log 1 = 0; what is left as "other" has S_S = log 0, lib/stable.c:948-949)
+  if (nn <= 1 || nn == tt) k = STB_KEY_SKIP;
+  else if (tt == 0 || nn < tt || tt > M || nn > N) k = STB_KEY_OTHER;
   else {
-    const unsigned e = tt - 2, j = e / (unsigned)H.UC, cw = (unsigned)H.HC + (e - j * (unsigned)H.UC);
+    unsigned j = 0, cw = (unsigned)H.HC - 1u;  // t = 1
+    if (tt >= 2) {
+      const unsigned e = tt - 2;
+      j = e / (unsigned)H.UC;
+      cw = (unsigned)H.HC + (e - j * (unsigned)H.UC);
+    }
     const unsigned b = (nn - 2) / (unsigned)H.R, r = (nn - 2) - b * (unsigned)H.R;
     const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
     const unsigned rec = H.rec_off[j + 1] + (b - b0);  // (b >= b0: the cell lies on or below the diagonal)
@@ -306,7 +346,7 @@ __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G,
   payload[g] = (uint32_t)g;
 }
 
-// ... and for the strips of the self-summing k_fill_hb: key = (item << 12) | (row in group << 8) | element of the wave,
+// ... and for the strips of the grid form (grid_hb.hip): key = (item << 13) | (row in group << 8) | element of the wave,
 // item = (record index of tile (strip, block)) * NQ + group of G rows.  Column 1 (t = 1) is a cell too -- the last
 // element of strip 0's halo, which that strip computes along -- and a pair with t = n contributes log 1 = 0: what is
 // left as "other" are the pairs whose S_S is log 0 (lib/stable.c:948-949).
@@ -329,7 +369,7 @@ __global__ void k_item_keys_hb2(const uint32_t *n, const uint16_t *t, uint64_t G
     const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
     const unsigned rec = H.rec_off[j + 1] + (b - b0);
     const unsigned q = r / (unsigned)H.G;
-    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << 12) | ((uint64_t)(r - q * (unsigned)H.G) << 8) | cw;
+    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << 13) | ((uint64_t)(r - q * (unsigned)H.G) << 8) | cw;
   }
   key[g] = k;
   payload[g] = (uint32_t)g;
@@ -372,6 +412,27 @@ __global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigne
   }
 }
 
+// The grid form's dense layout: a word per lane and (tile, group) -- position | count << 13 of the lane's listed cell, 0
+// for none -- so that a group's list is ONE coalesced load at an address that needs no look-up (the walking wave asks
+// for it a group ahead).  A group with more than 63 cells, or a count of 2^19 or more, keeps only a marker in lane 63
+// and is taken from the CSR lists instead.
+#define STB_DENSE_MARK 0xffffffffu
+__global__ void k_dense_words(const unsigned *item_ptr, const unsigned short *pos, const unsigned *cnt, unsigned nitems, unsigned *dense) {
+  const unsigned i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (i >= nitems) return;
+  const unsigned b0 = item_ptr[i], b1 = item_ptr[i + 1], n = b1 - b0;
+  bool big = n > 63;
+  unsigned w = 0;
+  if (!big && lane < n) {
+    const unsigned c = cnt[b0 + lane];
+    if (c >= (1u << 19)) big = true;
+    w = (unsigned)pos[b0 + lane] | (c << 13);
+  }
+  big = __any(big);
+  if (big) w = (lane == 63) ? STB_DENSE_MARK : 0u;
+  dense[(size_t)i * 64 + lane] = w;
+}
+
 // item_ptr[i] = first run whose item index is >= i
 __global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned nitems, unsigned *ptr) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,19 +455,42 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
   memset(&H, 0, sizeof(H));
   if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
   if (which >= 3) {
-    // (the strip shape of the self-summing form depends on the number of discounts: a list per shape)
-    if (stb_hb_dot_info(N, M, D, &H, 2)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
-    which = (H.C == 2) ? 3 : 4;
+    // (the strip shape of the grid form depends on the number of discounts: a list per shape)
+    grid_geom gg;
+    if (stb_grid_geometry(N, M, D, &gg)) return stb_fail("stb_groups_aterms: no grid geometry for N=%u M=%u", N, M);
+    which = (gg.C == 2) ? 3 : 4;
+    H.R = gg.R;
+    H.UC = gg.U * gg.C;
+    H.HC = gg.HL * gg.C;
+    H.NB = gg.NB;
+    H.JW = gg.JW;
+    H.NQ = gg.NQ;
+    H.G = gg.G;
+    H.C = gg.C;
+    H.n_tiles = gg.n_tiles;
+    H.n_rec = gg.n_tiles;
     if (g->lists_ready[which] && (g->list_R[which] != H.R || g->list_G[which] != H.G)) {
       (void)hipStreamSynchronize(g->st);
       stb_pool_free(g->d_item_ptr[which]);
       stb_pool_free(g->d_ent_pos[which]);
       stb_pool_free(g->d_ent_cnt[which]);
+      stb_pool_free(g->d_tile_off[which]);
+      stb_pool_free(g->d_dense[which]);
+      g->d_dense[which] = nullptr;
       g->d_item_ptr[which] = nullptr;
       g->d_ent_pos[which] = nullptr;
       g->d_ent_cnt[which] = nullptr;
+      g->d_tile_off[which] = nullptr;
       g->lists_ready[which] = 0;
     }
+    if (!g->lists_ready[which] && !g->d_tile_off[which]) {
+      std::vector<unsigned> off;
+      stb_grid_tile_offsets(gg, off);
+      if (stb_pool_malloc((void **)&g->d_tile_off[which], off.size() * sizeof(unsigned)) != hipSuccess ||
+          hipMemcpy(g->d_tile_off[which], off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess)
+        return stb_fail("stb_groups_aterms: out of device memory");
+    }
+    H.rec_off = g->d_tile_off[which];
   }
   if (g->lists_ready[which]) return 0;
   if (!g->fused_ready) g->sparse = 0;
@@ -460,7 +544,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     }
     // the pairs outside the table, in their sorted order (the same whichever layout is built first; the
     // self-summing form has none but those whose S_S is log 0, which it only counts)
-    if (which >= 3) {
+    if (which >= 2) {
       g->n_inf = n_other;
     } else if (!g->d_n2) {
       g->G2 = n_other;
@@ -492,10 +576,19 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     }
     if (h_runs) {
       hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item,
-                         which >= 3 ? 12 : (which == 2 ? 10 : 9));
+                         which >= 3 ? 13 : (which == 2 ? 10 : 9));
       if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
+    if (which >= 3) {
+      if (stb_pool_malloc((void **)&g->d_dense[which], 4 * 64 * (size_t)(nitems ? nitems : 1)) != hipSuccess) {
+        stb_fail("stb_groups_aterms: out of device memory");
+        break;
+      }
+      if (nitems)
+        hipLaunchKernelGGL(k_dense_words, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which],
+                           g->d_ent_cnt[which], nitems, g->d_dense[which]);
+    }
     if (!g->d_dotp) {
       // partial sums: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
       // checkpointed one
@@ -597,12 +690,83 @@ static int groups_fused_setup(stb_groups_t *g) {
 // one evaluation in two halves: queue everything on the set's stream, the sums ending in pinned host
 // memory; then wait, check the fill and hand the values over.  aterms_finish returns 0, 1 (error) or 2
 // (the fused chain fill gave up waiting: the caller repeats the evaluation through stored tables).
-static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v) {
-  // (v = STB_FILL_CK with fuse: the summing checkpointed form and its cell lists; STB_FILL_HB: the halo-block form,
-  // its tile workers summing or -- g->sel_which 3 / 4 -- its spine)
-  const int which = (fuse && v == STB_FILL_HB) ? (g->sel_which >= 3 ? g->sel_which : 2) : ((fuse && v == STB_FILL_CK) ? 1 : 0);
+// The lean flow of a fused evaluation in the halo-block (tile workers sum) or the grid form (walking waves sum):
+//   launch 1  restaurant partial sums; the abscissae go to the device as kernel arguments
+//   launch 2  the table walk (its workspace is zero already: the previous evaluation left it so)
+//   launch 3  k_eval_tail: every reduction, the total and the walk's error words to pinned host memory
+//   then, behind what the host waits for, the workspace is zeroed for the next evaluation.
+// ONE wait (an event after launch 3), no copy in either direction, no S1 vector, no gather pass.
+static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, double *out_host, int which, bool timed) {
   g->pending = 0;
-  g->pend_fb0 = stb_fill_fallbacks();
+  char *ws0 = (char *)g->d_ws_fill;
+  double *a_dev = (double *)ws0;
+  char *ws = ws0 + STB_WS_FORM;
+  const size_t ws_left = g->ws_fill - STB_WS_FORM;
+  if (timed) HIPCHK(hipEventRecord(g->ev[0], g->st));
+  const dd_t *tpart = nullptr;
+  int nbt = 0;
+  if (stb_restaurant_partials(x_host, D, g->d_T, g->d_bpar, (uint64_t)g->I, g->d_ws_terms, g->ws_terms, a_dev, &tpart, &nbt, g->st))
+    return 1;
+  dot_request req;
+  req.item_ptr = g->d_item_ptr[which];
+  req.ent_pos = g->d_ent_pos[which];
+  req.ent_cnt = g->d_ent_cnt[which];
+  req.nsg = g->nsg;
+  req.col0 = which >= 3 ? 4 : 3;
+  if (which >= 3) {
+    req.geom_C = which == 3 ? 2 : 4;
+    req.geom_R = g->list_R[which];
+    req.geom_G = g->list_G[which];
+    req.tile_off = g->d_tile_off[which];
+    req.dense = g->d_dense[which];
+  }
+  req.dotp = g->d_dotp;
+  req.ws_zero = g->ws_zero;
+  req.no_s1 = 1;
+  fill_args A;
+  memset(&A, 0, sizeof(A));
+  A.a = a_dev;
+  A.N = g->N;
+  A.M = g->M;
+  A.tables = g->d_tables;
+  A.tstride = g->tstride;
+  A.S1 = g->d_S1;
+  A.s1stride = g->N;
+  if (stb_logtab(&A.lt)) return 1;
+  unsigned *hdr = nullptr;
+  g->ws_zero = 0;  // (whatever happens below, the workspace is no longer known to be zero)
+  if (which >= 3 ? stb_launch_grid(A, D, ws, ws_left, &req, &hdr, g->st) : stb_launch_hb(A, D, ws, ws_left, &req, &hdr, g->st)) return 1;
+  if ((size_t)D * req.parts_per_table * (which >= 3 ? 2 : 1) > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+  if (timed) HIPCHK(hipEventRecord(g->ev[1], g->st));
+  if (timed) HIPCHK(hipEventRecord(g->ev[2], g->st));
+  hipLaunchKernelGGL(k_eval_tail, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, which >= 3 ? 2 : 1, tpart, nbt,
+                     (unsigned long long)g->n_inf, hdr, g->d_out, g->h_out_dev, g->Dmax);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g->ev[3], g->st));
+  // zero for the next evaluation, behind the event the host waits for
+  if (req.zero_bytes) {
+    HIPCHK(hipMemsetAsync(ws, 0, req.zero_bytes, g->st));
+    g->ws_zero = req.zero_bytes;
+  }
+  g->pending = 1;
+  g->pend_lean = 1;
+  g->pend_D = D;
+  g->pend_fuse = 1;
+  g->pend_v = STB_FILL_HB;
+  g->pend_out = out_host;
+  memcpy(g->pend_x, x_host, sizeof(double) * D);
+  return 0;
+}
+
+static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v, bool timed = true) {
+  if (fuse && v == STB_FILL_HB && g->sparse && g->sel_which >= 2)
+    return aterms_issue_lean(g, x_host, D, out_host, g->sel_which, timed);
+  g->pend_lean = 0;
+  g->ws_zero = 0;  // (this flow's fills zero and use the workspace themselves)
+  // (what is left for this flow: the chain form, v = STB_FILL_CK with fuse: the summing checkpointed form and its cell
+  // lists, and every evaluation through stored tables)
+  const int which = (fuse && v == STB_FILL_CK) ? 1 : 0;
+  g->pending = 0;
   HIPCHK(hipEventRecord(g->ev[0], g->st));
   if (fuse) {
     // the chain form as a DOT kernel: sum over table cells of count * log S, no table in memory;
@@ -613,34 +777,23 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
       req.ent_pos = g->d_ent_pos[which];
       req.ent_cnt = g->d_ent_cnt[which];
       req.nsg = g->nsg;
-      req.col0 = which >= 3 ? 4 : which + 1;
-      if (which >= 3) {
-        req.geom_C = which == 3 ? 2 : 4;
-        req.geom_R = g->list_R[which];
-        req.geom_G = g->list_G[which];
-      }
+      req.col0 = which + 1;
     } else {
       req.cnt = g->d_cnt;
     }
     req.dotp = g->d_dotp;
     stb_set_dot_request(&req);
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
-                              g->ws_fill, which >= 2 ? STB_FILL_HB : (which ? STB_FILL_CK : STB_FILL_CHAIN), g->st);
+                              g->ws_fill, which ? STB_FILL_CK : STB_FILL_CHAIN, g->st);
     stb_set_dot_request(nullptr);
     if (rc) return 1;
     stb_fill_last(&g->pend_fill);
-    if ((size_t)D * req.parts_per_table * (which >= 3 ? 2 : 1) > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+    if ((size_t)D * req.parts_per_table > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
     HIPCHK(hipEventRecord(g->ev[1], g->st));
-    if (which >= 3) {
-      // (every pair that contributes is in the lists, column 1 included)
-      hipLaunchKernelGGL(k_dot2_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out,
-                         (unsigned long long)g->n_inf);
-    } else {
-      if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
-                      g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
-        return 1;
-      hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
-    }
+    if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n2, g->d_t2, g->G2,
+                    g->d_out, g->d_ws_sweep, g->ws_sweep, g->st))
+      return 1;
+    hipLaunchKernelGGL(k_dot_reduce, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, g->d_out);
   } else {
     if (stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
                    g->ws_fill, v, g->st))
@@ -670,9 +823,26 @@ static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float
   if (!g->pending) return stb_fail("stb_groups_wait: nothing queued");
   g->pending = 0;
   const int D = g->pend_D;
+  if (g->pend_lean) {
+    HIPCHK(hipEventSynchronize(g->ev[3]));
+    const unsigned code = (unsigned)g->h_out[2 * g->Dmax], detail = (unsigned)g->h_out[2 * g->Dmax + 1];
+    if (code != 0) {
+      stb_fail("stb_groups_aterms: the fused evaluation gave up waiting for a neighbour block (code 0x%x, block %u of table %u)", code,
+               detail & 0xffffu, detail >> 16);
+      return 2;  // (the caller repeats the evaluation through stored tables)
+    }
+    for (int d = 0; d < D; d++) g->pend_out[d] = g->h_out[d];
+    if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
+    if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));
+    if (ms_terms) HIPCHK(hipEventElapsedTime(ms_terms, g->ev[2], g->ev[3]));
+    return 0;
+  }
   HIPCHK(hipStreamSynchronize(g->st));
   if (stb_fill_status_of(&g->pend_fill)) return g->pend_fuse ? 2 : 1;
-  if (stb_fill_fallbacks() != g->pend_fb0) {
+  // (whether THIS fill was repeated in the producer/consumer form -- not a counter of the calling thread, which other
+  // sets' fills move too and which the waiting thread need not share with the issuing one; a fused evaluation stores no
+  // table to sweep again)
+  if (g->pend_fill.fell_back && !g->pend_fuse) {
     // the one-launch fill gave up and was repeated with the producer/consumer form: the sum above
     // read unfinished tables, take it again
     if (stb_sweep_S(g->d_tables, g->tstride, g->d_S1, g->N, D, g->N, g->M, g->d_n, g->d_t, g->G,
@@ -690,7 +860,7 @@ static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float
 
 static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out_host, bool fuse, int v,
                        float *ms_fill, float *ms_sweep, float *ms_terms) {
-  if (aterms_issue(g, x_host, D, out_host, fuse, v)) return 1;
+  if (aterms_issue(g, x_host, D, out_host, fuse, v, ms_fill || ms_sweep || ms_terms)) return 1;
   return aterms_finish(g, ms_fill, ms_sweep, ms_terms);
 }
 
@@ -720,11 +890,22 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   // against 0.76 / 0.83 chain, 4: 0.36 / 0.45 against 0.78 / 0.86, 8: 0.44 / 0.53 against 0.89 / 0.97, 16: 0.76 /
   // 0.86 against 0.98 / 1.07, 24: 1.07 / 1.15 against 1.25 / 1.34, 28: 1.22 against 1.32, 30: 1.55 against 1.37,
   // 64: 2.7 against 2.4.)
-  // ... and with the spine itself summing its strips' listed cells, no tile workers at all (STB_ATERMS_HB2=0
-  // switches it off): every discount count, see fill_hb.hip.
-  if (fuse && which == 0 && (v == STB_FILL_HB || v == STB_FILL_SCALED) && stb_env_int("STB_ATERMS_HB2", 1)) {
-    hb_dot_info H;
-    if (stb_hb_dot_info(g->N, g->M, D, &H, 2) == 0) which = (H.C == 2) ? 3 : 4;
+  // ... and with the walking waves themselves summing their strips' listed cells, no tile workers at all (grid_hb.hip):
+  // what a grid beyond the halo-block form's range takes instead of the chain form while the pairs are sparse in the
+  // table (its look-ups take one listed cell per lane and group of rows: 10^6 pairs over a 10^4 x 10^4 table, 2 % of
+  // the cells, fill them; 12 % -- the same pairs with n < 4000 -- overflow every group).  STB_ATERMS_GRID=1 / 0 forces
+  // it on (wherever its geometry exists) / off.  (MI355X, tools/ab_grid.py, 10^6 pairs, N = M = 10^4, kernel ms: 32
+  // discounts 1.44 = chain, 48: 1.56 against 1.88, 64: 1.62 against 2.39; N = M = 4000, 64 discounts: 1.35 against 0.57.)
+  if (fuse && which == 0 && (v == STB_FILL_HB || v == STB_FILL_SCALED)) {
+    const int force = stb_env_int("STB_ATERMS_GRID", -1);
+    grid_geom gg;
+    if (force != 0 && stb_grid_geometry(g->N, g->M, D, &gg) == 0) {
+      hb_dot_info H;
+      const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H) == 0 &&
+                            (unsigned)H.JW * (unsigned)D <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_WAVES", 1200);
+      const bool sparse_pairs = (double)g->G <= 0.04 * (double)stb_table_cells(g->N, g->M);
+      if (force > 0 || (!hb_range && sparse_pairs && stb_env_int("STB_ATERMS_HB", 1))) which = (gg.C == 2) ? 3 : 4;
+    }
   }
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
     hb_dot_info H;
@@ -773,7 +954,7 @@ extern "C" int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, in
     if (hipEventRecord(g->ev_dep, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(g->st, g->ev_dep, 0) != hipSuccess)
       rc = stb_fail("stb_groups_aterms_async: %s", hipGetErrorString(hipGetLastError()));
   }
-  if (!rc) rc = aterms_issue(g, x_host, D, out_host, fuse, v);
+  if (!rc) rc = aterms_issue(g, x_host, D, out_host, fuse, v, false);
   stb_device_leave(prev_dev);
   return rc;
 }

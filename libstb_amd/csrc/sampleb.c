@@ -19,19 +19,26 @@
 #include "../../include/stb_hip.h"
 #include "sampler_trace.h"
 
+#define NPRE 3 /* abscissae ARMS is known to ask for first (lib/arms.c:117-119) */
+
 typedef struct {
   double shape, Q, apar;
-  int I;
-  void *d_T, *d_out, *d_ws;
-  size_t ws_bytes;
+  stb_bctx_t *dev; /* T[] resident in HBM; an evaluation is two launches and one wait */
+  /* values evaluated ahead of time, served when ARMS asks for exactly these abscissae */
+  int npre;
+  double xpre[NPRE], ypre[NPRE];
 } b_posterior;
 
 static double bterms(double x, void *vp) {
   b_posterior *bp = vp;
   double val;
-  if (stb_bterms(&x, 1, bp->Q, bp->shape, bp->apar, bp->d_T, (uint64_t)bp->I, bp->d_out, bp->d_ws,
-                 bp->ws_bytes, NULL) ||
-      stb_memcpy_d2h(&val, bp->d_out, sizeof(val), NULL) || stb_stream_sync(NULL)) {
+  int i;
+  for (i = 0; i < bp->npre; i++)
+    if (x == bp->xpre[i]) {
+      stb_trace_add(x, bp->ypre[i]);
+      return bp->ypre[i];
+    }
+  if (stb_bterms_eval(bp->dev, &x, 1, bp->Q, bp->shape, bp->apar, &val)) {
     fprintf(stderr, "bterms(): device evaluation failed: %s\n", stb_last_error());
     exit(1);
   }
@@ -90,16 +97,11 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
     double initb[3] = {B_MIN, 1, B_MAX};
     b_posterior bp;
     bp.Q = Q;
-    bp.I = I;
     bp.apar = apar;
     bp.shape = shape;
-    bp.ws_bytes = stb_terms_workspace_bytes((uint64_t)I, 1);
-    bp.d_T = stb_device_malloc(sizeof(scnt_int) * (size_t)(I > 0 ? I : 1));
-    bp.d_out = stb_device_malloc(sizeof(double));
-    bp.d_ws = stb_device_malloc(bp.ws_bytes);
-    if (!bp.d_T || !bp.d_out || !bp.d_ws ||
-        (I > 0 && stb_memcpy_h2d(bp.d_T, T, sizeof(scnt_int) * (size_t)I, NULL)) ||
-        stb_stream_sync(NULL)) {
+    bp.npre = 0;
+    bp.dev = stb_bterms_create(T, I);
+    if (!bp.dev) {
       fprintf(stderr, "sampleb(): no device memory for T[] (%s)\n", stb_last_error());
       exit(1);
     }
@@ -110,6 +112,21 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
       initb[1] = b_in;
       if (fabs(initb[1] - B_MAX) / B_MAX < 0.00001) initb[1] = B_MAX * 0.999 + B_MIN * 0.001;
       if (fabs(initb[1] - B_MIN) / B_MIN < 0.00001) initb[1] = B_MIN * 0.999 + B_MAX * 0.001;
+      {
+        /* ARMS starts from three abscissae it fixes before any evaluation (lib/arms.c:117-119, the same
+         * expression here, so the same bits): evaluate them in ONE device call */
+        double x3[NPRE], y3[NPRE];
+        for (i = 0; i < NPRE; i++) x3[i] = initb[0] + (i + 1.0) * (initb[2] - initb[0]) / (NPRE + 1.0);
+        if (stb_bterms_eval(bp.dev, x3, NPRE, bp.Q, bp.shape, bp.apar, y3)) {
+          fprintf(stderr, "bterms(): device evaluation failed: %s\n", stb_last_error());
+          exit(1);
+        }
+        for (i = 0; i < NPRE; i++) {
+          bp.xpre[i] = x3[i];
+          bp.ypre[i] = y3[i];
+        }
+        bp.npre = NPRE;
+      }
       code = arms_simple(3, initb, initb + 2, bterms, &bp, 0, initb + 1, &myb);
       stb_trace_code(code);
       if (myb < B_MIN || myb > B_MAX) {
@@ -126,9 +143,7 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
         exit(1);
       }
     }
-    stb_device_free(bp.d_T);
-    stb_device_free(bp.d_out);
-    stb_device_free(bp.d_ws);
+    stb_bterms_free(bp.dev);
     if (verbose > 1) fprintf(stderr, "Sample b ~ G(%lg) = %lf\n", Q, myb);
   }
   return myb;

@@ -100,6 +100,7 @@ struct last_fill {
   fill_args A;
   int D = 0;
   bool s_table = false, can_fall_back = false;
+  bool fell_back = false;   // out of stb_fill_status_of: the fill gave up and was repeated with k_fill_pc
   hipStream_t st = nullptr;
 };
 void stb_fill_last(last_fill *out);       // the calling thread's last fill
@@ -131,8 +132,13 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   int col0 = 1;                            //         first column of slice 0: 1 (k_fill_chain), 2 (k_fill_ck); 3: k_fill_hb's tiles;
                                            //         4: k_fill_hb's strips (the spine sums), lists built for geom_*
   int geom_C = 0, geom_R = 0, geom_G = 0;  //         col0 = 4: columns per lane, rows per block, rows per group of the lists
+  const unsigned *tile_off = nullptr;      //         col0 = 4: first tile of every strip (device, stb_grid_tile_offsets)
+  const unsigned *dense = nullptr;         //         col0 = 4: a word per lane and (tile, group): position | count << 13
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
+  size_t ws_zero = 0;                      // in: bytes at the start of the workspace the caller knows to be zero (no memset then)
+  size_t zero_bytes = 0;                   // out: bytes at the start of the workspace the launch needs zero (and dirties)
+  int no_s1 = 0;                           // in: nobody reads the S1 vector (column 1 is among the listed cells)
 };
 void stb_set_dot_request(const dot_request *r);  // for the next stb_fill_S of this thread
 size_t stb_chain_workspace(unsigned N, unsigned M, int D);
@@ -148,6 +154,7 @@ int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
 unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D);  // partial sums per table of the summing form
 unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D);  // spine workgroups it launches for D tables
 
+int stb_cu_count();  // compute units of the current device
 // halo-block form (fill_hb.hip): a spine that walks blocks of rows alone + tile workers, one launch
 bool stb_hb_eligible(unsigned N, unsigned M, int D);
 size_t stb_hb_workspace(unsigned N, unsigned M, int D);
@@ -160,7 +167,19 @@ struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: i
   unsigned n_tiles, n_rec, n_spine;
   const unsigned *rec_off;     // device: first record of strip index s = j + 1 (s = 0: the halo of strip 0)
 };
-int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int mode = 1);  // mode 1: tile workers sum, 2: the spine does
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out);
+
+// the fused grid evaluation in which the walking waves sum their own strips' listed cells (grid_hb.hip)
+struct grid_geom {
+  int C, P, B, JW, NB, R, HL, U;  // columns per lane, strips per workgroup, workgroups per table, strips, blocks, rows per block, halo / own lanes
+  int G, NQ, phases;              // rows per group, groups per block, launches
+  unsigned n_tiles;               // (strip, block) pairs of a table
+  size_t off_cke, off_ckv, off_state_e, off_state_v, zero_bytes, bytes;
+  int ok;
+};
+int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out);
+size_t stb_grid_workspace(unsigned N, unsigned M, int D);
+int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);

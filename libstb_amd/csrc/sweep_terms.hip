@@ -81,6 +81,25 @@ __global__ __launch_bounds__(256) void k_reduce_final(const dd_t *partial, int n
   }
 }
 
+// the same with the base values in the kernel arguments and the result written to pinned host memory as well: an
+// evaluation is then two launches and ONE wait, no copy in either direction (sampleb's bterms)
+struct base_args {
+  double base[64];
+};
+__global__ __launch_bounds__(256) void k_reduce_final_host(const dd_t *partial, int nb, double *out, base_args B, double *out_host) {
+  __shared__ dd_t lds[4];
+  const int d = blockIdx.x;
+  dd_t v{0.0, 0.0};
+  for (int b = threadIdx.x; b < nb; b += 256) dd_merge(v, partial[(size_t)d * nb + b]);
+  v = block_reduce_dd(v, lds);
+  if (threadIdx.x == 0) {
+    dd_add(v, B.base[d]);
+    const double r = v.hi + v.lo;
+    out[d] = r;
+    out_host[d] = r;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: sweep.  Each block takes a contiguous chunk of pairs and DT discounts; the (n,t) pair is read
 // once per DT tables, the row offset computed once, and DT gathers issued.
@@ -184,8 +203,10 @@ struct terms_args {
 
 __global__ __launch_bounds__(256) void k_terms_partial(terms_args A, const uint32_t *T,
                                                        const double *bpar, uint64_t I, dd_t *partial,
-                                                       int nb) {
+                                                       int nb, double *a_out) {
   __shared__ dd_t lds[4];
+  // (a fused evaluation's first launch also puts the abscissae where the table walk reads its discounts)
+  if (a_out && blockIdx.x == 0 && threadIdx.x == 0) a_out[blockIdx.y] = A.x[blockIdx.y];
   const uint64_t i0 = (uint64_t)blockIdx.x * STB_TERMS_CHUNK;
   const uint64_t i1 = (i0 + STB_TERMS_CHUNK < I) ? i0 + STB_TERMS_CHUNK : I;
   const int d = blockIdx.y;
@@ -235,7 +256,7 @@ static int run_terms(terms_args &A, const double *base_host, const uint32_t *d_T
       HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * D, st));
     return 0;
   }
-  hipLaunchKernelGGL(k_terms_partial, dim3(nb, D), dim3(256), 0, st, A, d_T, d_bpar, I, partial, nb);
+  hipLaunchKernelGGL(k_terms_partial, dim3(nb, D), dim3(256), 0, st, A, d_T, d_bpar, I, partial, nb, (double *)nullptr);
   hipLaunchKernelGGL(k_reduce_final, dim3(D), dim3(256), 0, st, partial, nb, d_out,
                      base_host ? (const double *)d_base : (const double *)nullptr);
   HIPCHK(hipGetLastError());
@@ -257,6 +278,123 @@ extern "C" int stb_restaurant_terms(const double *x_host, int D, const uint32_t 
     A.p[d] = log(x_host[d]);  // host libm: one scalar per abscissa, same call as samplea.c:66
   }
   return run_terms(A, nullptr, d_T, d_bpar, I, d_out, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+// first launch of a fused aterms evaluation (groups.hip): the restaurant terms' partial sums -- reduced by that
+// evaluation's last launch -- and the abscissae written to a_out[0..D) for the table walk; returns the partials
+// and their number per abscissa
+int stb_restaurant_partials(const double *x_host, int D, const uint32_t *d_T, const double *d_bpar, uint64_t I, void *d_ws,
+                            size_t ws_bytes, double *a_out, const dd_t **partial_out, int *nb_out, hipStream_t st) {
+  if (D < 1 || D > STB_TERMS_DMAX) return stb_fail("stb_groups_aterms: D=%d (max %d)", D, STB_TERMS_DMAX);
+  if (ws_bytes < stb_terms_workspace_bytes(I, D)) return stb_fail("terms: workspace too small");
+  terms_args A;
+  memset(&A, 0, sizeof(A));
+  A.D = D;
+  A.mode = 0;
+  for (int d = 0; d < D; d++) {
+    if (!(x_host[d] > 0)) return stb_fail("stb_groups_aterms: x=%g", x_host[d]);
+    A.x[d] = x_host[d];
+    A.p[d] = log(x_host[d]);  // host libm: one scalar per abscissa, same call as samplea.c:66
+  }
+  int nb = terms_blocks(I);
+  if (nb < 1) nb = 1;  // (no restaurants: one empty partial per abscissa, and the abscissae still go out)
+  dd_t *partial = (dd_t *)((char *)d_ws + stb_align_up((size_t)D * sizeof(double), 256));
+  hipLaunchKernelGGL(k_terms_partial, dim3(nb, D), dim3(256), 0, st, A, d_T, d_bpar, I, partial, nb, a_out);
+  HIPCHK(hipGetLastError());
+  *partial_out = partial;
+  *nb_out = nb;
+  return 0;
+}
+
+// ---- bterms for sampleb: T[] resident, an evaluation = two launches and one wait ----
+struct stb_bctx {
+  int dev;
+  uint64_t I;
+  uint32_t *d_T;
+  double *d_out, *h_out, *h_out_dev;
+  void *d_ws;
+  size_t ws_bytes;
+  hipStream_t st;
+};
+
+extern "C" void stb_bterms_free(stb_bctx_t *c) {
+  STB_ENTRY;
+  if (!c) return;
+  const int prev = stb_device_enter(c->dev);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  stb_pool_free(c->d_T);
+  stb_pool_free(c->d_out);
+  stb_pool_free(c->d_ws);
+  stb_pool_free(c->h_out);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  stb_device_leave(prev);
+  free(c);
+}
+
+extern "C" stb_bctx_t *stb_bterms_create(const uint32_t *T, int I) {
+  STB_ENTRY;
+  if (stb_device_count() < 1) {
+    stb_fail("stb_bterms_create: no HIP device (libstb_amd has no CPU path)");
+    return nullptr;
+  }
+  stb_bctx_t *c = (stb_bctx_t *)calloc(1, sizeof(*c));
+  if (!c) return nullptr;
+  const int prev = stb_device_enter(stb_get_device());
+  bool ok = hipGetDevice(&c->dev) == hipSuccess;
+  c->I = (uint64_t)(I > 0 ? I : 0);
+  c->ws_bytes = stb_terms_workspace_bytes(c->I, STB_TERMS_DMAX);
+  ok = ok && hipStreamCreate(&c->st) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&c->d_T, sizeof(uint32_t) * (c->I ? c->I : 1)) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&c->d_out, sizeof(double) * STB_TERMS_DMAX) == hipSuccess;
+  ok = ok && stb_pool_malloc(&c->d_ws, c->ws_bytes) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&c->h_out, sizeof(double) * STB_TERMS_DMAX, 1) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0) == hipSuccess;
+  if (ok && c->I) ok = hipMemcpyAsync(c->d_T, T, sizeof(uint32_t) * c->I, hipMemcpyHostToDevice, c->st) == hipSuccess &&
+                       hipStreamSynchronize(c->st) == hipSuccess;
+  if (!ok) {
+    const hipError_t e = hipGetLastError();
+    stb_fail("stb_bterms_create: %s", e != hipSuccess ? hipGetErrorString(e) : "out of memory");
+    stb_device_leave(prev);
+    stb_bterms_free(c);
+    return nullptr;
+  }
+  stb_device_leave(prev);
+  return c;
+}
+
+// out_host[j] = bterms(x_j) (lib/sampleb.c:33-41), j < J <= 64; blocks until the values are there
+extern "C" int stb_bterms_eval(stb_bctx_t *c, const double *x_host, int J, double Q, double shape, double apar, double *out_host) {
+  STB_ENTRY;
+  if (!c) return stb_fail("stb_bterms_eval: null context");
+  if (J < 1 || J > STB_TERMS_DMAX) return stb_fail("stb_bterms_eval: J=%d (max %d)", J, STB_TERMS_DMAX);
+  if (!(apar > 0)) return stb_fail("stb_bterms_eval: apar=%g", apar);
+  terms_args A;
+  base_args B;
+  memset(&A, 0, sizeof(A));
+  memset(&B, 0, sizeof(B));
+  A.D = J;
+  A.mode = 1;
+  for (int j = 0; j < J; j++) {
+    if (!(x_host[j] > 0)) return stb_fail("stb_bterms_eval: x=%g", x_host[j]);
+    A.x[j] = x_host[j];
+    A.q[j] = x_host[j] / apar;
+    A.p[j] = lgamma(A.q[j]);                                     // lib/sampleb.c:36
+    B.base[j] = -Q * x_host[j] + (shape - 1) * log(x_host[j]);   // lib/sampleb.c:37
+  }
+  const int prev = stb_device_enter(c->dev);
+  int rc = 0;
+  int nb = terms_blocks(c->I);
+  if (nb < 1) nb = 1;
+  dd_t *partial = (dd_t *)((char *)c->d_ws + stb_align_up((size_t)STB_TERMS_DMAX * sizeof(double), 256));
+  hipLaunchKernelGGL(k_terms_partial, dim3(nb, J), dim3(256), 0, c->st, A, c->d_T, (const double *)nullptr, c->I, partial, nb,
+                     (double *)nullptr);
+  hipLaunchKernelGGL(k_reduce_final_host, dim3(J), dim3(256), 0, c->st, partial, nb, c->d_out, B, c->h_out_dev);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)
+    rc = stb_fail("stb_bterms_eval: %s", hipGetErrorString(hipGetLastError()));
+  else
+    for (int j = 0; j < J; j++) out_host[j] = c->h_out[j];
+  stb_device_leave(prev);
+  return rc;
 }
 
 extern "C" int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,

@@ -297,7 +297,7 @@ def test_fused_aterms_in_the_checkpointed_form(monkeypatch, golden_dir):
     n[6:40], t[6:40] = 400, 123
     x = np.array([0.11, 0.5, 0.83])
     outs = []
-    monkeypatch.setenv("STB_ATERMS_HB2", "0")
+    monkeypatch.setenv("STB_ATERMS_GRID", "0")
     for ck in ("1", "0"):
         monkeypatch.setenv("STB_ATERMS_CK", ck)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
@@ -334,7 +334,7 @@ def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
         try:
             x = np.ascontiguousarray(xs[:D])
             hb1, hb2, ch = np.zeros(D), np.zeros(D), np.zeros(D)
-            monkeypatch.setenv("STB_ATERMS_HB2", "0")   # (the default since round 4 is the self-summing spine: next test)
+            monkeypatch.setenv("STB_ATERMS_GRID", "0")   # (beyond 24 discounts sparse pairs take the grid form since round 4: tests below)
             monkeypatch.setenv("STB_ATERMS_HB", "1")
             fb = L.stb_fill_fallbacks()
             capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(hb1)))
@@ -365,7 +365,7 @@ def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
     n[44], t[44] = 211, 210    # next to the diagonal in strip 1's first block
     x = np.array([0.11, 0.5, 0.83])
     outs = []
-    monkeypatch.setenv("STB_ATERMS_HB2", "0")
+    monkeypatch.setenv("STB_ATERMS_GRID", "0")
     for hb in ("1", "0"):
         monkeypatch.setenv("STB_ATERMS_HB", hb)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
@@ -419,21 +419,27 @@ def _edge_pairs(C):
     n[42], t[42] = 300, UC + 1     # last own column of strip 0
     n[43], t[43] = 300, UC + 2     # first own column of strip 1
     n[44], t[44] = UC + 3, UC + 2  # next to the diagonal in strip 1's first block
+    n[60], t[60] = 301, UC + 2     # the same column in an odd row of a group (taken from the staged row above it)
+    n[61], t[61] = 302, UC + 2
+    n[62], t[62] = 52, 3
+    n[63], t[63] = 53, 3
     n[45], t[45] = 2, 1        # S^2_1 = 1 - a: a negative log
     n[46], t[46] = 13, 1
     n[47:60], t[47:60] = 900, 1    # column 1 in the last row, several times
     return g, n, t
 
 
-@pytest.mark.parametrize("C,P,G", [(2, 4, 12), (2, 7, 6), (2, 2, 4), (4, 4, 8), (4, 7, 4), (4, 3, 12)])
-def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G):
-    """the default for a grid since round 4: k_fill_hb<C, 2>, whose spine waves stage G rows at a time in LDS and
-    sum their own strip's listed cells (column 1 included; no tile workers, no S1 vector, no gather pass) --
-    against stored tables + gather at 1e-12, bit for bit run to run, at the ends of samplea's bracket
-    (A_MIN = 0.01, A_MAX = 0.98, lib/psample.h:89-94), in every strip shape"""
+@pytest.mark.parametrize("C,P,G,PH", [(2, 4, 24, 1), (2, 7, 12, 3), (2, 2, 8, 1), (4, 4, 12, 1), (4, 7, 8, 4), (4, 3, 16, 2), (4, 4, 24, 5)])
+def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G, PH):
+    """the default for a grid since round 4: k_grid_hb<C, G> (grid_hb.hip), whose walking waves stage every other
+    row of a group of G in LDS and sum their own strip's listed cells (column 1 included; no tile workers, no S1
+    vector, no gather pass), in PH launches over bands of blocks -- against stored tables + gather at 1e-12, bit
+    for bit run to run, at the ends of samplea's bracket (A_MIN = 0.01, A_MAX = 0.98, lib/psample.h:89-94), in
+    every strip shape"""
     L = capi.lib()
-    for k, v in (("C", C), ("P", P), ("G", G)):
-        monkeypatch.setenv("STB_HB2_" + k, str(v))
+    monkeypatch.setenv("STB_ATERMS_GRID", "1")
+    for k, v in (("C", C), ("P", P), ("G", G), ("PHASES", PH)):
+        monkeypatch.setenv("STB_GRID_" + k, str(v))
     g, n, t = _edge_pairs(C)
     x = np.array([0.01, 0.11, 0.5, 0.83, 0.98])
     outs = []
@@ -461,10 +467,11 @@ def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G):
         assert orc.close(outs[0][d], want, TOL), (d, outs[0][d], want)
 
 
-def test_fused_aterms_the_spine_sums_log_zero_pairs():
+def test_fused_aterms_the_spine_sums_log_zero_pairs(monkeypatch):
     """a pair outside the table's support has S_S = log 0 (lib/stable.c:948-949): the sum is -inf, as the
     reference's is, in the form that never gathers"""
     L = capi.lib()
+    monkeypatch.setenv("STB_ATERMS_GRID", "1")
     g = synth.groups(20, 30, 300, "wide")
     n, t = g.n.copy(), g.t.copy()
     n[7], t[7] = 5, 9
@@ -479,9 +486,11 @@ def test_fused_aterms_the_spine_sums_log_zero_pairs():
         L.stb_groups_free(h)
 
 
-def test_fused_aterms_the_spine_sums_vs_reference(golden_dir):
-    """... against the reference's own aterms values (golden), small and mid-sized sets"""
+def test_fused_aterms_the_spine_sums_vs_reference(golden_dir, monkeypatch):
+    """... against the reference's own aterms values (golden), small and mid-sized sets (dense ones included:
+    groups of more than 63 listed cells are taken from the lists in CSR form)"""
     L = capi.lib()
+    monkeypatch.setenv("STB_ATERMS_GRID", "1")
     for name in ("small_wide", "small_real", "mid_wide"):
         spec = load(golden_dir, "aterms.json")[name]
         g = groups_of(spec)

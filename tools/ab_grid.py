@@ -2,7 +2,7 @@
 several rounds, medians of wall time and of the summing kernel's device time; every result is compared with the
 first spec's.
 usage: python tools/ab_grid.py NMAX D "hb2,hb2@STB_HB2_C=4,hb,chain,..." [rounds] [profile]     (repo root, GPU box)
-A spec is a form name (hb2 spine sums, hb tile workers sum, chain, twopass) followed by @ENV=VALUE settings."""
+A spec is a form name (auto, hb2 the grid form whose walking waves sum, hb tile workers sum, chain, twopass) followed by @ENV=VALUE settings."""
 import ctypes as C
 import os
 import sys
@@ -16,9 +16,10 @@ import numpy as np
 import orc
 from libstb_amd import capi, synth
 
-FORMS = {"hb2": {},
-         "hb": {"STB_ATERMS_HB2": "0", "STB_ATERMS_HB": "1"},
-         "chain": {"STB_ATERMS_HB2": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "0"},
+FORMS = {"auto": {},
+         "hb2": {"STB_ATERMS_GRID": "1"},
+         "hb": {"STB_ATERMS_GRID": "0", "STB_ATERMS_HB": "1"},
+         "chain": {"STB_ATERMS_GRID": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "0"},
          "twopass": {"STB_ATERMS_FUSED": "0"}}
 Nmax = int(sys.argv[1])
 D = int(sys.argv[2])

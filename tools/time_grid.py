@@ -21,10 +21,10 @@ N = max(int(g.n.max()) + 1, M)
 for D in Ds:
     x = np.ascontiguousarray(synth.discount_grid(64)[:D])
     ref = None
-    for label, env in (("hb2 (spine sums)", {}),
-                       ("hb (halo blocks)", {"STB_ATERMS_HB2": "0", "STB_ATERMS_HB": "1"}),
-                       ("ck (spine + workers)", {"STB_ATERMS_HB2": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "1", "STB_ATERMS_CK_MAX_SPINE": "100000"}),
-                       ("chain", {"STB_ATERMS_HB2": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "0"}),
+    for label, env in (("grid (walking waves sum)", {"STB_ATERMS_GRID": "1"}),
+                       ("hb (halo blocks)", {"STB_ATERMS_GRID": "0", "STB_ATERMS_HB": "1"}),
+                       ("ck (spine + workers)", {"STB_ATERMS_GRID": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "1", "STB_ATERMS_CK_MAX_SPINE": "100000"}),
+                       ("chain", {"STB_ATERMS_GRID": "0", "STB_ATERMS_HB": "0", "STB_ATERMS_CK": "0"}),
                        ("two-pass", {"STB_ATERMS_FUSED": "0"})):
         os.environ.update(env)
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
