@@ -403,6 +403,21 @@ def main():
         fence()
         dt64 = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
         fill_first, fill_last = first_last(per_step)
+        # where a step's time goes: a few more steps with a wait between the fill and the gather
+        f_ms, g_ms = [], []
+        for _ in range(min(10, args.batch_steps)):
+            t1 = time.perf_counter()
+            T64.fill(mine64, capi.FILL_SCALED)
+            pr = T64.tables.index_select(1, pidx).reshape(-1)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            shard.gather_scalars(pr, 64, dist)
+            torch.cuda.synchronize()
+            f_ms.append((t2 - t1) * 1e3)
+            g_ms.append((time.perf_counter() - t2) * 1e3)
+        fence()
+        fill_only_ms = shard.max_over_ranks(float(np.median(f_ms)), dev, dist)
+        fill_gather_ms = shard.max_over_ranks(float(np.median(g_ms)), dev, dist)
         must_be_clean("batch64 fill", fb0)
         L.stb_fill_profile_begin()
         step64()
@@ -422,27 +437,38 @@ def main():
         h = groups_handle(L, g, Ng, Mg, D64)
         post = np.zeros(D64)
         capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))  # set-up + warm-up
+        # the log-posteriors stay on the device: the gather takes device scalars (no copy to the host and back)
+        d_post = torch.empty(D64, dtype=torch.float64, device=dev)
         fence()
-        per_step = []
+        per_step, eval_ms, gather_ms = [], [], []
         t0 = time.perf_counter()
         for _ in range(args.batch_steps):
             t1 = time.perf_counter()
-            capi.check(L.stb_groups_aterms(h, capi.dp(mine64), D64, capi.dp(post)))
-            allpost = shard.gather_scalars(torch.as_tensor(post, device=dev), 64, dist)
+            capi.check(L.stb_groups_aterms_device(h, capi.dp(mine64), D64, d_post.data_ptr(), capi.stream_ptr()))
+            capi.check(L.stb_groups_wait(h))
+            t2 = time.perf_counter()
+            allpost = shard.gather_scalars(d_post, 64, dist)
             torch.cuda.synchronize()
-            per_step.append((time.perf_counter() - t1) * 1e3)
+            t3 = time.perf_counter()
+            per_step.append((t3 - t1) * 1e3)
+            eval_ms.append((t2 - t1) * 1e3)
+            gather_ms.append((t3 - t2) * 1e3)
         fence()
         dtg = shard.max_over_ranks(time.perf_counter() - t0, dev, dist) / args.batch_steps
         grid_first, grid_last = first_last(per_step)
+        grid_eval_ms = shard.max_over_ranks(float(np.median(eval_ms)), dev, dist)
+        grid_gather_ms = shard.max_over_ranks(float(np.median(gather_ms)), dev, dist)
         L.stb_groups_free(h)
         batch64 = {
             "discounts_total": 64, "discounts_per_gpu": D64, "ranks": world, "ranks_seen": ranks_seen,
             "steps": args.batch_steps,
             "fill": {"ms": dt64 * 1e3, "ms_first5_median": fill_first, "ms_last5_median": fill_last,
+                     "ms_fill_median": fill_only_ms, "ms_gather_median": fill_gather_ms,
                      "cells_per_s": cells64 / dt64, "form": FORM_NAMES.get(fT, str(fT)),
                      "kernel_ms_sum": k64, "kernel_span_ms": span64, "launches": n64.value,
                      "frac_of_hbm_peak_per_gpu": (8.0 * cells64 / world / (span64 * 1e-3) / 1e9 / HBM_PEAK_GBS) if span64 > 0 else None},
-            "grid_aterms": {"ms": dtg * 1e3, "ms_first5_median": grid_first, "ms_last5_median": grid_last, "pairs": g.pairs, "N": Ng, "M": Mg, "grid_evals_per_s": 64 * g.pairs / dtg,
+            "grid_aterms": {"ms": dtg * 1e3, "ms_first5_median": grid_first, "ms_last5_median": grid_last,
+                            "ms_evaluation_median": grid_eval_ms, "ms_gather_median": grid_gather_ms, "pairs": g.pairs, "N": Ng, "M": Mg, "grid_evals_per_s": 64 * g.pairs / dtg,
                             "log_posteriors_finite": int(torch.isfinite(allpost).sum().item()),
                             "log_posterior_d0_d63": [float(allpost[0]), float(allpost[63])]},
             "note": "strong scaling: the same 64 tables / 64 x 10^6 grid-evals at every --gpus N; speed-up(N) = ms(1) / ms(N); "

@@ -116,6 +116,9 @@ void S_report(stable_t *sp, FILE *fp);
 int stb_table_sync(stable_t *sp);
 /* how many 128-row blocks of the S and V mirrors have been copied from the device so far */
 void stb_table_mirrored(stable_t *sp, unsigned *s_blocks, unsigned *v_blocks);
+/* bytes this table holds on the device (slabs + fill workspace) and on the host (mirror + vectors); their sum, capped
+ * at 2^32 - 1, is what the memalloced field and S_report show.  An S_FLOAT table's slabs are float slabs only. */
+void stb_table_bytes(stable_t *sp, unsigned long long *device_bytes, unsigned long long *host_bytes);
 
 #ifdef __cplusplus
 }

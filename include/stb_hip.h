@@ -109,9 +109,25 @@ int stb_fill_profile_end(double *kernel_ms_total, int *launches);
 /* device time in ms from the first of those launches' start to the last one's end (large batches of
  * the producer/consumer form run two sub-batches side by side, so the sum counts that time twice) */
 double stb_fill_profile_span(void);
-/* V tables (next row 8f-1): V^n_m for 2<=n<=N, 2<=m<=min(n,M); lib/stable.c:451-482 */
+/* V tables (next row 8f-1): V^n_m = S^n_m / S^n_{m-1} for 2<=n<=N, 2<=m<=min(n,M); lib/stable.c:451-482.  Tables of 512 rows
+ * or more are taken from the S recurrence's block-floating cells (one division per cell off the serial path; within
+ * 1e-10 of the reference); smaller ones, and every table under STB_FILLV_EXACT=1, walk the reference's own V
+ * recurrence, bit for bit. */
 int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
                uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);
+int stb_fill_V_exact(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables,
+                     uint64_t vtable_stride, void *d_ws, size_t ws_bytes, void *stream);
+
+/* the same tables written once as floats (S_FLOAT, reference lib/stable.c:389-449 and :483-537: all arithmetic in
+ * double, only the stored value is a float): D float slabs with the double slabs' element offsets, no double slab
+ * anywhere.  Only the halo-block form narrows before the store: stb_fill_takes_kind(N, M, D, kind) says whether a fill
+ * of kind 1 (log S as float), 2 (V as double, taken from the S recurrence's cells) or 3 (V as float) applies to these
+ * sizes; where it does not, stb_fill_Sf / stb_fill_Vf fail and the caller narrows a double table (stb_table_to_float). */
+int stb_fill_takes_kind(unsigned N, unsigned M, int D, int kind);
+int stb_fill_Sf(const double *a_host, int D, unsigned N, unsigned M, float *d_tables, uint64_t table_stride,
+                double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, void *stream);
+int stb_fill_Vf(const double *a_host, int D, unsigned N, unsigned M, float *d_vtables, uint64_t vtable_stride,
+                void *d_ws, size_t ws_bytes, void *stream);
 
 /* narrow a table slab to float, element for element (S_FLOAT storage, reference lib/stable.h:31-33:
  * "keep final table values in float, but all intermediate calcs done in double") */
@@ -165,6 +181,12 @@ int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_
  * host threads at once -- one per GPU, or several on one GPU; see INTEGRATION.md.) */
 int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, int D, double *out_host, void *stream);
 int stb_groups_wait(stb_groups_t *g);
+/* ... with the D log-posteriors left on the DEVICE, in d_out[0..D) (a device address), for a caller that hands them to a
+ * collective: the discount axis sharded over the GPUs of a node, every rank all-gathers its share.  Queued
+ * like _async; `stream` then waits on the device for the values, so work queued on it afterwards sees them.
+ * stb_groups_wait(g) must still follow, before the values are trusted: it reports a table walk that gave up waiting
+ * for a neighbour, in which case it re-evaluates through stored tables and rewrites d_out. */
+int stb_groups_aterms_device(stb_groups_t *g, const double *x_host, int D, double *d_out, void *stream);
 /* the same values through stored tables and the sorted gather whatever D is (stb_groups_aterms sums
  * inside the fill when D >= 2, which needs a set-up pass over the pairs on first use) */
 int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host);

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     sig("stb_extend_policy", None, [u, u, u, u, i, i, C.POINTER(u), C.POINTER(u)])
     sig("stb_table_sync", i, [vp])
     sig("stb_table_mirrored", None, [vp, C.POINTER(u), C.POINTER(u)])
+    sig("stb_table_bytes", None, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
     # ---- include/yaps.h
     sig("yaps_yapper", None, [vp])
     # ---- include/stb_hip.h
@@ -105,6 +106,13 @@ def lib() -> C.CDLL:
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_profile_span", C.c_double, [])
     sig("stb_fill_V", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
+    sig("stb_fill_V_exact", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
+    sig("stb_fill_Vf", i, [c_double_p, i, u, u, vp, u64, vp, sz, vp])
+    sig("stb_fill_Sf", i, [c_double_p, i, u, u, vp, u64, vp, u64, vp, sz, vp])
+    sig("stb_fill_takes_kind", i, [u, u, i, i])
+    sig("stb_bterms_create", vp, [c_u32_p, i])
+    sig("stb_bterms_eval", i, [vp, c_double_p, i, d, d, d, c_double_p])
+    sig("stb_bterms_free", None, [vp])
     sig("stb_table_to_float", i, [vp, vp, u64, vp])
     sig("stb_lookup_S", i, [vp, vp, u, u, vp, vp, u64, vp, vp])
     sig("stb_sweep_workspace_bytes", sz, [u64, i])
@@ -118,6 +126,7 @@ def lib() -> C.CDLL:
     sig("stb_groups_aterms_tables", i, [vp, c_double_p, i, c_double_p])
     sig("stb_groups_aterms_async", i, [vp, c_double_p, i, c_double_p, vp])
     sig("stb_groups_wait", i, [vp])
+    sig("stb_groups_aterms_device", i, [vp, c_double_p, i, vp, vp])
     sig("stb_groups_update_restaurants", i, [vp, c_u32_p, c_double_p])
     sig("stb_groups_shape", i, [vp, c_int_p, C.POINTER(u64), C.POINTER(u), C.POINTER(u), c_int_p])
     sig("stb_sampler_cache_clear", None, [])
@@ -319,26 +328,55 @@ class DeviceTables:
         return out.cpu().numpy()
 
 
-class DeviceVTables:
+class DeviceFloatTables(DeviceTables):
+    """D log-Stirling tables stored as floats (S_FLOAT), written once by the fill that narrows before the store"""
+
     def __init__(self, N: int, M: int, D: int = 1, device="cuda"):
+        super().__init__(N, M, D, device)
+        torch = _torch()
+        self.tables = torch.empty((D, self.stride), dtype=torch.float32, device=device)
+
+    def fill(self, a, stream=None):
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
+        self.a = a
+        check(self.L.stb_fill_Sf(dp(a), self.D, self.N, self.M, self.tables.data_ptr(), self.stride,
+                                 self.S1.data_ptr(), self.N, self.ws.data_ptr(), self.ws_bytes, stream_ptr(stream)))
+
+    def packed_host(self, d=0):
+        t = self.tables[d].cpu().numpy()
+        out = np.empty(self.cells, dtype=np.float32)
+        pos = 0
+        for n in range(3, self.N + 1):
+            ln = min(n - 2, self.M - 1)
+            o = self.rowoff(n)
+            out[pos:pos + ln] = t[o:o + ln]
+            pos += ln
+        return out
+
+
+class DeviceVTables:
+    def __init__(self, N: int, M: int, D: int = 1, device="cuda", dtype="f64"):
         torch = _torch()
         self.L = lib()
         self.N, self.M, self.D = N, M, D
         self.cells = int(self.L.stb_vcells(N, M))
         self.elems = int(self.L.stb_velems(N, M))
         self.stride = max(32, (self.elems + 31) // 32 * 32)
-        self.tables = torch.empty((D, self.stride), dtype=torch.float64, device=device)
+        self.dtype = dtype
+        self.tables = torch.empty((D, self.stride), dtype=torch.float32 if dtype == "f32" else torch.float64, device=device)
         self.ws_bytes = int(self.L.stb_fill_workspace_bytes(N, M, D))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
 
-    def fill(self, a, stream=None):
+    def fill(self, a, stream=None, exact=False):
+        """exact: the reference's own V recurrence, bit for bit (what tables below 512 rows get anyway)"""
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
-        check(self.L.stb_fill_V(dp(a), self.D, self.N, self.M, self.tables.data_ptr(), self.stride,
-                                self.ws.data_ptr(), self.ws_bytes, stream_ptr(stream)))
+        f = self.L.stb_fill_Vf if self.dtype == "f32" else (self.L.stb_fill_V_exact if exact else self.L.stb_fill_V)
+        check(f(dp(a), self.D, self.N, self.M, self.tables.data_ptr(), self.stride,
+                self.ws.data_ptr(), self.ws_bytes, stream_ptr(stream)))
 
     def packed_host(self, d=0):
         t = self.tables[d].cpu().numpy()
-        out = np.empty(self.cells, dtype=np.float64)
+        out = np.empty(self.cells, dtype=t.dtype)
         pos = 0
         for n in range(2, self.N + 1):
             ln = min(n - 1, self.M - 1)

@@ -9,7 +9,7 @@
 //                                          of 2-24 discounts)
 //   chain   k_fill_chain / k_fillv_chain   one launch per fill (small tables, many short ones, the V table, the fused
 //                                          aterms of more than 24 discounts)
-//   ck      k_fill_ck                      one launch: recurrence-only spine + tile workers (on request)
+//   ck      k_fill_ck                      (ablation build only) one launch: recurrence-only spine + tile workers
 //   pc      k_fill_pc                      launched per 128 rows (many tables; fallback of the one-launch forms)
 //   rows    k_fill_rows                    the reference's own operation order (STB_FILL_LOGDOMAIN)
 //   + the superseded forms of tools/ablation/ablation.hip in the library `make -C tools/ablation` builds
@@ -95,7 +95,7 @@ static size_t ws_head(unsigned M, int D) {  // discounts + frontier
 
 static size_t fill_workspace_need(unsigned N, unsigned M, int D) {
   size_t form = stb_chain_workspace(N, M, D);
-  const size_t ck = stb_ck_workspace(N, M, D);
+  const size_t ck = stb_launch_ck ? stb_ck_workspace(N, M, D) : 0;
   if (ck > form) form = ck;
   const size_t hb = stb_hb_workspace(N, M, D);
   if (hb > form) form = hb;
@@ -153,7 +153,7 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
   // or the variant STB_FILL_CK; what the halo-block form leaves -- very many mid-sized tables -- is the
   // producer/consumer form's: 64 tables of 4000 columns 1.04 against 1.17 ms, 128 of 2000 0.56 against 0.68)
   const int force = stb_env_int("STB_CK", 0);
-  if (force == 0 || g_dot_req_active() || !stb_ck_eligible(N, M, D)) return false;
+  if (force == 0 || g_dot_req_active() || !stb_launch_ck || !stb_ck_eligible(N, M, D)) return false;
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   return cells >= (uint64_t)stb_env_int("STB_CK_MIN_MCELLS", 40) * 1000000ull &&
@@ -189,7 +189,7 @@ static int pick_form(int variant, unsigned N, unsigned M, int D) {
     case STB_FILL_LOGDOMAIN: return FORM_ROWS_LOG;
     case STB_FILL_PC: return (N < (1u << 27)) ? FORM_PC : FORM_ROWS_LOG;
     case STB_FILL_CHAIN: return (N >= 3 && N < (1u << 27)) ? FORM_CHAIN : (N < 3 ? FORM_PC : FORM_ROWS_LOG);
-    case STB_FILL_CK: return stb_ck_eligible(N, M, D) ? FORM_CK : pick_form(STB_FILL_CHAIN, N, M, D);
+    case STB_FILL_CK: return (stb_launch_ck && stb_ck_eligible(N, M, D)) ? FORM_CK : pick_form(STB_FILL_CHAIN, N, M, D);
     case STB_FILL_HB: return stb_hb_eligible(N, M, D) ? FORM_HB : pick_form(STB_FILL_CHAIN, N, M, D);
     case STB_FILL_CHAINX:  // (its converter blocks need a compute unit per 64-column chunk)
       if (D > 2) return pick_form(STB_FILL_CHAIN, N, M, D);
@@ -298,9 +298,24 @@ extern "C" int stb_fill_status(void) {
   return stb_fill_status_of(&g_last);
 }
 
+// The halo-block form also stores floats (S_FLOAT) and V ratios: its tile workers narrow or divide what they hold in
+// double before the store -- the only form that does.  Taken for kinds 1-3 wherever it is taken for log S in double.
+static bool hb_takes_kind(unsigned N, unsigned M, int D, int kind) {
+  if (stb_env_int("STB_HB", -1) == 0 || !stb_hb_eligible_out(N, M, D, kind)) return false;
+  const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
+  if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
+  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 200);
+}
+
+extern "C" int stb_fill_takes_kind(unsigned N, unsigned M, int D, int kind) { return hb_takes_kind(N, M, D, kind) ? 1 : 0; }
+
+static thread_local bool g_fillv_exact = false;  // stb_fill_V_exact: this call walks the reference's own V recurrence
+
+// kind: 0 log S (double), 1 log S (float), 2 V (double), 3 V (float); d_tables is the slab of that type
 static int fill_common(const double *a_host, int D, unsigned N, unsigned M, double *d_tables, uint64_t table_stride,
-                       double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, int variant, bool vtable,
+                       double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, int variant, int kind,
                        hipStream_t st) {
+  const bool vtable = (kind & 2) != 0;
   const char *who = vtable ? "stb_fill_V" : "stb_fill_S";
   g_last.hdr = nullptr;  // whatever this thread filled before is no longer "the last fill"
   g_last.fell_back = false;
@@ -334,6 +349,22 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   if (stb_logtab(&A.lt)) return 1;
   HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
 
+  if (kind != 0 && !(kind == 2 && (g_fillv_exact || stb_env_int("STB_FILLV_EXACT", 0) || !hb_takes_kind(N, M, D, kind)))) {
+    // floats, and the V table from the S recurrence's own cells (one division per cell, off the serial path: 1e-10 of
+    // the reference; STB_FILLV_EXACT=1 keeps the V table on the reference's own recurrence, bit for bit)
+    if (!hb_takes_kind(N, M, D, kind))
+      return stb_fail("%s: no kernel stores %s for N=%u M=%u D=%d (the caller narrows a double table instead)", who,
+                      kind == 1 ? "floats" : (kind == 2 ? "V ratios" : "float V ratios"), N, M, D);
+    unsigned *hdr = nullptr;
+    if (stb_launch_hb(A, D, ws, ws_left, nullptr, &hdr, st, kind)) return 1;
+    g_last.hdr = hdr;
+    g_last.A = A;
+    g_last.D = D;
+    g_last.st = st;
+    g_last.s_table = !vtable;
+    g_last.can_fall_back = false;  // (k_fill_pc stores log S in double only: the caller repeats in another way)
+    return 0;
+  }
   if (vtable) {
     if (stb_env_int("STB_FILLV_CHAIN", 1)) {
       unsigned *hdr = nullptr;
@@ -424,13 +455,42 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
 extern "C" int stb_fill_S(const double *a_host, int D, unsigned N, unsigned M, double *d_tables, uint64_t table_stride,
                           double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, int variant, void *stream) {
   STB_ENTRY;
-  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, variant, false,
+  return fill_common(a_host, D, N, M, d_tables, table_stride, d_S1, s1_stride, d_ws, ws_bytes, variant, 0,
                      (hipStream_t)stream);
+}
+
+// S_FLOAT storage written once, as floats (lib/stable.c:389-449: the recurrence in double, the stored value a float):
+// D float slabs with the double slab's element offsets.  Fails (and says so) where only the double forms apply:
+// stb_fill_takes_kind(N, M, D, 1) tells beforehand.
+extern "C" int stb_fill_Sf(const double *a_host, int D, unsigned N, unsigned M, float *d_tables, uint64_t table_stride,
+                           double *d_S1, uint64_t s1_stride, void *d_ws, size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  return fill_common(a_host, D, N, M, reinterpret_cast<double *>(d_tables), table_stride, d_S1, s1_stride, d_ws, ws_bytes,
+                     STB_FILL_SCALED, 1, (hipStream_t)stream);
+}
+
+extern "C" int stb_fill_Vf(const double *a_host, int D, unsigned N, unsigned M, float *d_vtables, uint64_t vtable_stride,
+                           void *d_ws, size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  return fill_common(a_host, D, N, M, reinterpret_cast<double *>(d_vtables), vtable_stride, nullptr, 0, d_ws, ws_bytes,
+                     STB_FILL_SCALED, 3, (hipStream_t)stream);
 }
 
 extern "C" int stb_fill_V(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables, uint64_t vtable_stride,
                           void *d_ws, size_t ws_bytes, void *stream) {
   STB_ENTRY;
-  return fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes, STB_FILL_SCALED, true,
+  return fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes, STB_FILL_SCALED, 2,
                      (hipStream_t)stream);
+}
+
+// the V table on the reference's own recurrence (k_fillv_chain: two dependent divisions a row, bit for bit the
+// reference's table), whatever the size: what stb_fill_V does by itself below 512 rows and under STB_FILLV_EXACT=1
+extern "C" int stb_fill_V_exact(const double *a_host, int D, unsigned N, unsigned M, double *d_vtables, uint64_t vtable_stride,
+                                void *d_ws, size_t ws_bytes, void *stream) {
+  STB_ENTRY;
+  g_fillv_exact = true;
+  const int rc = fill_common(a_host, D, N, M, d_vtables, vtable_stride, nullptr, 0, d_ws, ws_bytes, STB_FILL_SCALED, 2,
+                             (hipStream_t)stream);
+  g_fillv_exact = false;
+  return rc;
 }

@@ -173,10 +173,17 @@ __device__ __forceinline__ void hb_row(double (&v)[C], double (&coef)[C], double
 // first block of strip j: the state before it has nothing in the strip's own columns (2 + j U C and up)
 __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { return (int)(((long long)j * UC) / R); }
 
-template <int C, int DOT>
+// OUT: what the tile workers store -- 0 log S^n_m as double (S_remake_part, lib/stable.c:321-388), 1 the same narrowed to
+// float (S_FLOAT, lib/stable.c:389-449: all arithmetic in double, only the stored value is a float), 2 the ratio
+// V^n_m = S^n_m / S^n_{m-1} as double (S_UVTABLE, lib/stable.c:451-482: a block-floating cell and its left neighbour are
+// one division away from it), 3 that ratio as float (lib/stable.c:483-537).
+template <int C, int DOT, int OUT = 0>
 __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
-  constexpr int NG = (C == 4 && DOT == 0) ? 2 : 1, CG = C / NG;  // a worker lane's groups of adjacent elements (see the workers)
+  static_assert(OUT == 0 || (DOT == 0 && C >= 2), "only the storing fill of 2 or 4 columns per lane narrows or divides");
+  constexpr bool VT = (OUT & 2) != 0, FL = (OUT & 1) != 0;
+  // a worker lane's groups of adjacent elements (see the workers; a float row of 4 columns per lane is one 16-byte store)
+  constexpr int NG = (C == 4 && DOT == 0 && !FL) ? 2 : 1, CG = C / NG;
   __shared__ double2 lt[128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
   __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
@@ -724,20 +731,56 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         if (lane == 0) X.dotp[(size_t)d * X.n_tiles + ((unsigned)(recO - tab_rec) - (unsigned)NB)] = acc;
       } else {
       double *table = A.tables + (uint64_t)d * A.tstride;
+      float *tablef = reinterpret_cast<float *>(A.tables) + (uint64_t)d * A.tstride;
       const unsigned e0 = (unsigned)(jw * UC);  // first own element of the strip
       // (the lane offset counts from the wave's first halo element: the base may lie before the row)
-      const unsigned voff = (unsigned)(lane * CG) * 8u;
+      const unsigned voff = (unsigned)(lane * CG) * (FL ? 4u : 8u);
       unsigned n = 2u + (unsigned)(b * R);  // the row the next step produces
-      uint64_t roff = stb_row_offset(n, M);
+      // the S table's rows start at n = 3 and hold m = 2 .. min(n - 1, M); the V table's at n = 2, m = 2 .. min(n, M)
+      constexpr unsigned NMIN = VT ? 2u : 3u;
+      auto rlen = [&](unsigned nn) { return VT ? stb_vrow_len(nn, M) : stb_row_len(nn, M); };
+      auto rpitch = [&](unsigned nn) { return VT ? stb_vrow_pitch(nn, M) : stb_row_pitch(nn, M); };
+      uint64_t roff = VT ? stb_vrow_offset(n, M) : stb_row_offset(n, M);
       constexpr int RS = 8 / C;  // rows converted together: eight cells in flight
       int ep8[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) ep8[u] = ep[(NG == 2) ? ((u >> 1) & 1) : 0];
+      // (ratios: what a group's first element takes from its left neighbour in the NEXT row is also the denominator of
+      // its ratio in THIS row: carried from row to row)
+      double tc[NG];
+      if constexpr (VT) {
+        if constexpr (NG == 1) {
+          tc[0] = wave_shr1_zero(v[0][CG - 1]) * s[0];
+        } else {
+          const double ra = wave_ror1(v[0][1]), rb = wave_shr1_zero(v[1][1]);
+          tc[0] = ra * s[0];
+          tc[NG - 1] = fma(ra, z1, rb * s[1]);
+        }
+      }
       for (int r = 0; r < R; r += RS) {
-        double x[8], val[8];
+        double x[8], val[8], xl[VT ? 8 : 1];
 #pragma unroll
         for (int u = 0; u < RS; u++) {
-          if constexpr (NG == 1) {
+          if constexpr (VT) {
+            if constexpr (NG == 1) {
+#pragma unroll
+              for (int i = CG - 1; i >= 1; i--) v[0][i] = fma(coef[0][i], v[0][i], v[0][i - 1]);
+              v[0][0] = fma(coef[0][0], v[0][0], tc[0]);
+              tc[0] = wave_shr1_zero(v[0][CG - 1]) * s[0];
+            } else {
+              v[0][1] = fma(coef[0][1], v[0][1], v[0][0]);
+              v[0][0] = fma(coef[0][0], v[0][0], tc[0]);
+              v[1][1] = fma(coef[1][1], v[1][1], v[1][0]);
+              v[1][0] = fma(coef[1][0], v[1][0], tc[NG - 1]);
+              const double ra = wave_ror1(v[0][1]), rb = wave_shr1_zero(v[1][1]);
+              tc[0] = ra * s[0];
+              tc[NG - 1] = fma(ra, z1, rb * s[1]);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+              for (int i = 0; i < CG; i++) xl[u * C + g * CG + i] = (i == 0) ? tc[g] : v[g][i - 1];
+          } else if constexpr (NG == 1) {
             const double t0 = wave_shr1_zero(v[0][CG - 1]) * s[0];
 #pragma unroll
             for (int i = CG - 1; i >= 1; i--) v[0][i] = fma(coef[0][i], v[0][i], v[0][i - 1]);
@@ -761,14 +804,31 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         }
         // (rows none of whose cells lies in the strip's own columns, and rows outside the table, are only walked)
         const unsigned nl = n + RS - 1;
-        if (nl >= 3 && n <= N && e0 < stb_row_len(min(nl, N), M)) {
-          hb_logs8(x, ep8, lt, one_hi, val);
+        if (nl >= NMIN && n <= N && e0 < rlen(min(nl, N))) {
+          if constexpr (VT) {
+            // V^n_m = S^n_m / S^n_{m-1}: both under the lane's exponent (cells right of the diagonal: 0 / 0 or x / 0 --
+            // they land in the row's slack, which nobody reads)
+#pragma unroll
+            for (int q = 0; q < 8; q++) val[q] = x[q] / xl[q];
+          } else {
+            hb_logs8(x, ep8, lt, one_hi, val);
+          }
 #pragma unroll
           for (int u = 0; u < RS; u++) {
             const unsigned nu = n + u;
-            if (nu >= 3 && nu <= N && e0 < stb_row_len(nu, M)) {
+            if (nu >= NMIN && nu <= N && e0 < rlen(nu)) {
               const double *rp = table + roff + e0 - (size_t)(HL * C);
-              if constexpr ((HB_DIAG & 8) != 0) {
+              if constexpr (FL) {
+                // (the arithmetic was double; the stored value is a float: two or four of them per lane, one store)
+                const float *rpf = tablef + roff + e0 - (size_t)(HL * C);
+                const double p0 = __hiloint2double(__float_as_int((float)val[u * C + 1]), __float_as_int((float)val[u * C]));
+                if constexpr (C == 2) {
+                  if (own[0]) store_sbase(rpf, voff, p0);
+                } else {
+                  const double p1 = __hiloint2double(__float_as_int((float)val[u * C + 3]), __float_as_int((float)val[u * C + 2]));
+                  if (own[0]) hb_store16(rpf, voff, p0, p1);
+                }
+              } else if constexpr ((HB_DIAG & 8) != 0) {
                 asm volatile("" ::"v"(val[u * C]), "v"(val[u * C + C - 1]));
               } else if constexpr (C == 1) {
                 if (own[0]) store_sbase(rp, voff, val[u]);
@@ -779,11 +839,11 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
                 if (own[1]) hb_store16(rp + 128, voff, val[u * 4 + 2], val[u * 4 + 3]);
               }
             }
-            roff += stb_row_pitch(nu, M);
+            roff += rpitch(nu);
           }
         } else {
 #pragma unroll
-          for (int u = 0; u < RS; u++) roff += stb_row_pitch(n + u, M);
+          for (int u = 0; u < RS; u++) roff += rpitch(n + u);
         }
         n += RS;
       }
@@ -816,7 +876,8 @@ int stb_cu_count() {  // compute units of the current device (256 on an MI355X)
   return cus;
 }
 
-static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) {
+// vt: the V table, whose rows include the diagonal (columns up to min(N, M) instead of min(N - 1, M))
+static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false, bool vt = false) {
   hb_geom g;
   memset(&g, 0, sizeof(g));
   g.ok = false;
@@ -827,7 +888,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
   // SIMD.  (MI355X, tools/ab_ck.py: N = M = 10^4, 1 table 0.36 against 0.46-0.50 ms, 2 tables 0.46 against 0.49,
   // 4 tables 0.78 against 0.61; N = M = 4000, 3 tables 0.198 against 0.206, 8 tables 0.31 against 0.25.)
   {
-    const unsigned cmax0 = (M < N - 1) ? M : N - 1;
+    const unsigned cmax0 = vt ? ((M < N) ? M : N) : ((M < N - 1) ? M : N - 1);
     const uint64_t waves2 = (uint64_t)D * ((cmax0 - 1 + 79) / 80);
     g.C = stb_env_int("STB_HB_C", waves2 <= (uint64_t)cus * 5 / 4 ? 2 : 4);  // (320 on 256 compute units)
   }
@@ -845,10 +906,14 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
   R = R / 8 * 8;
   if (R < 8) return g;
   g.R = R;
-  g.HL = R / g.C;
+  // (halo: R columns -- a halo column k from the left is exact for k rows, so the own columns are through all R rows of
+  // a block.  The V table divides an own cell by its left neighbour IN THE SAME ROW, which for a strip's first own
+  // column is the last halo column: one lane more keeps that one exact in the block's last row too.)
+  g.HL = R / g.C + (vt ? 1 : 0);
+  if (g.HL > HB_MAXHL) return g;
   g.U = 64 - g.HL;
   const int UC = g.U * g.C;
-  const unsigned cmax = (M < N - 1) ? M : N - 1;  // columns 2..cmax hold stored cells: elements 0 .. cmax - 2
+  const unsigned cmax = vt ? ((M < N) ? M : N) : ((M < N - 1) ? M : N - 1);  // columns 2..cmax hold stored cells: elements 0 .. cmax - 2
   g.JW = (int)((cmax - 1 + UC - 1) / UC);
   if (g.JW < 1) g.JW = 1;
   // Strips per spine workgroup.  4 -- a spine wave per SIMD -- while the spine decides; once a storing fill's spine
@@ -890,6 +955,10 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false) 
 }
 
 bool stb_hb_eligible(unsigned N, unsigned M, int D) { return hb_geometry(N, M, D).ok; }
+bool stb_hb_eligible_out(unsigned N, unsigned M, int D, int out_kind) {  // ... storing floats or V ratios: 2 or 4 columns per lane
+  const hb_geom g = hb_geometry(N, M, D, false, (out_kind & 2) != 0);
+  return g.ok && (out_kind == 0 || g.C >= 2);
+}
 // spine workgroups a fill of D tables launches (4 strips each, or 7 once there would be more than 100)
 unsigned stb_hb_spine(unsigned N, unsigned M, int D) {
   const hb_geom g = hb_geometry(N, M, D);
@@ -917,8 +986,8 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
     for (int r0 : rows) {
       int R = std::min(std::min(r0, Pc), HB_MAXHL * c) / 8 * 8;
       if (R < 8) continue;
-      const int HL = R / c, U = 64 - HL, UC = U * c;
-      const unsigned cmax = (M < N - 1) ? M : N - 1;
+      const int HL = R / c + 1, U = 64 - HL, UC = U * c;  // (the V table's strips: a halo lane more, see hb_geometry)
+      const unsigned cmax = (M < N) ? M : N;  // (the V table's: one column more than the S table's)
       const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R;
       size_t nrec = NB;
       for (size_t j = 0; j < JW; j++) {
@@ -936,7 +1005,7 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
 struct hb_order_entry {
   int dev;
   unsigned N, M;
-  int C, P, R, NB, JW;
+  int C, P, R, NB, JW, U;
   int r_ns, L_ns, lag_ns;
   unsigned *d_buf;  // [JW + 2] rec_off, then [n_tiles] order
 };
@@ -950,7 +1019,7 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
             lag_ns = stb_env_int("STB_HB_ORDER_LAG", 300);
   std::lock_guard<std::mutex> lock(g_hb_mu);
   for (const hb_order_entry &e : g_hb_orders)
-    if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.R == g.R && e.NB == g.NB && e.JW == g.JW &&
+    if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.R == g.R && e.NB == g.NB && e.JW == g.JW && e.U == g.U &&
         e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
       *rec_off = e.d_buf;
       *order = e.d_buf + g.JW + 2;
@@ -991,6 +1060,7 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   e.R = g.R;
   e.NB = g.NB;
   e.JW = g.JW;
+  e.U = g.U;  // (the V table's strips have a halo lane more than the S table's: other first blocks for the same N, M)
   e.r_ns = r_ns;
   e.L_ns = L_ns;
   e.lag_ns = lag_ns;
@@ -1029,9 +1099,10 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
   return 0;
 }
 
-int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st) {
+int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st, int out_kind) {
   const unsigned N = A.N, M = A.M;
-  const hb_geom g = hb_geometry(N, M, D, dot != nullptr);
+  if (out_kind < 0 || out_kind > 3 || (out_kind && dot)) return stb_fail("stb_fill: output kind %d", out_kind);
+  const hb_geom g = hb_geometry(N, M, D, dot != nullptr, (out_kind & 2) != 0);
   if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
   if (dot && (!dot->item_ptr || dot->col0 != 3))
@@ -1082,7 +1153,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   if (!dot || dot->ws_zero < g.zero_bytes) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
   if (dot) const_cast<dot_request *>(dot)->zero_bytes = g.zero_bytes;
   *hdr_out = X.hdr;
-  if (!(dot && dot->no_s1) && stb_launch_s1(A, D, st)) return 1;
+  if (!(dot && dot->no_s1) && !(out_kind & 2) && stb_launch_s1(A, D, st)) return 1;  // (the V table has no column 1)
   // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
   const int cus = stb_cu_count();
   // A storing fill takes the whole chip: idle workers cost nothing any more (they wait on progress words that have
@@ -1119,10 +1190,17 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     }
   } else {
     const size_t shm = X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
-    switch (g.C) {
-      case 1: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-      case 2: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
-      default: STB_LAUNCH_SHM((k_fill_hb<4, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+    if (out_kind && g.C == 1) return stb_fail("stb_fill: the halo-block form narrows or divides with 2 or 4 columns per lane");
+    switch (g.C * 4 + out_kind) {
+      case 4: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 8: STB_LAUNCH_SHM((k_fill_hb<2, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 9: STB_LAUNCH_SHM((k_fill_hb<2, 0, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 10: STB_LAUNCH_SHM((k_fill_hb<2, 0, 2>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 11: STB_LAUNCH_SHM((k_fill_hb<2, 0, 3>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 16: STB_LAUNCH_SHM((k_fill_hb<4, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 17: STB_LAUNCH_SHM((k_fill_hb<4, 0, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 18: STB_LAUNCH_SHM((k_fill_hb<4, 0, 2>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      default: STB_LAUNCH_SHM((k_fill_hb<4, 0, 3>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
     }
   }
   HIPCHK(hipGetLastError());

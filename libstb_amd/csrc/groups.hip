@@ -55,11 +55,15 @@ struct stb_groups {
   unsigned *d_dense[STB_NLISTS];               // [3], [4]: a word per lane and (tile, group): the list the walk reads
   uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
+  int reused;  // stb_groups_update_restaurants has been called: the same pairs serve call after call
   // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
   double *h_out;  // pinned, [2][Dmax] + 2: what the stream copies the sums to (lean flow: totals, then the fill's error words)
   double *h_out_dev;           // the device's address of it
   size_t ws_zero;              // bytes from the start of d_ws_fill + STB_WS_FORM known to be zero (lean flow)
   int pend_lean;               // the queued evaluation took the lean flow
+  double *pend_user;           // stb_groups_aterms_device: where the totals go on the device (or null)
+  double pend_host[STB_TERMS_DMAX];  // ... and where stb_groups_wait puts them on the host meanwhile
+  hipEvent_t ev_done;
   hipEvent_t ev_dep;
   int pending, pend_D, pend_fuse, pend_v;
   int sel_which;  // the list layout aterms_prepare chose for a fused evaluation in the halo-block form
@@ -137,6 +141,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
   if (g->ev_dep) (void)hipEventDestroy(g->ev_dep);
+  if (g->ev_done) (void)hipEventDestroy(g->ev_done);
   for (auto &e : g->ev)
     if (e) (void)hipEventDestroy(e);
   if (g->st) (void)hipStreamDestroy(g->st);
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void k_dot_reduce(const double *dotp, int part
 // terms' partial sums, each in a fixed order, their total written to pinned host memory together with the fill's
 // error words -- so that the host waits ONCE and copies nothing.
 __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts, int mode, const dd_t *tpart, int nbt, unsigned long long inf,
-                                                   const unsigned *hdr, double *out_dev, double *out_host, int Dmax) {
+                                                   const unsigned *hdr, double *out_dev, double *out_host, int Dmax, double *out_user) {
   __shared__ dd_t red[4];
   __shared__ double ks[4];
   const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts
     out_dev[d] = dots;
     out_dev[Dmax + d] = terms;
     out_host[d] = terms + dots;
+    if (out_user) out_user[d] = terms + dots;  // (stb_groups_aterms_device: the caller's device buffer)
     if (d == 0) {
       out_host[2 * Dmax] = (double)hdr[1];
       out_host[2 * Dmax + 1] = (double)hdr[2];
@@ -264,6 +270,7 @@ static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, 
   GCHK(stb_pool_malloc((void **)&g->h_out, sizeof(double) * (2 * Dmax + 2), 1));
   GCHK(hipHostGetDevicePointer((void **)&g->h_out_dev, g->h_out, 0));
   GCHK(hipEventCreateWithFlags(&g->ev_dep, hipEventDisableTiming));
+  GCHK(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
   g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
   g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
   g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
@@ -593,7 +600,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       // partial sums: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
       // checkpointed one
       g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
-      const size_t ckp = (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax);
+      const size_t ckp = stb_launch_ck ? (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax) : 0;
       if (ckp > g->dotp_elems) g->dotp_elems = ckp;
       hb_dot_info H2;
       if (stb_hb_dot_info(N, M, g->Dmax, &H2) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
@@ -740,7 +747,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
   if (timed) HIPCHK(hipEventRecord(g->ev[1], g->st));
   if (timed) HIPCHK(hipEventRecord(g->ev[2], g->st));
   hipLaunchKernelGGL(k_eval_tail, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, which >= 3 ? 2 : 1, tpart, nbt,
-                     (unsigned long long)g->n_inf, hdr, g->d_out, g->h_out_dev, g->Dmax);
+                     (unsigned long long)g->n_inf, hdr, g->d_out, g->h_out_dev, g->Dmax, g->pend_user);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g->ev[3], g->st));
   // zero for the next evaluation, behind the event the host waits for
@@ -868,10 +875,12 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
 static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_out, int *v_out) {
   if (!g) return stb_fail("stb_groups_aterms: null group set");
   if (D < 1 || D > g->Dmax) return stb_fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
-  if (g->pending) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
+  if (g->pending == 1) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int v = stb_default_variant();
-  // one discount: the gather over a stored table is cheap and needs no set-up; a grid: fused
-  const bool fuse = allow_fuse && g->fused && D >= 2 &&
+  // one discount: the gather over a stored table needs no set-up; a grid: fused -- and so is a single discount once
+  // the set is known to be used again and again (stb_groups_update_restaurants has been called on it: samplea's kept
+  // set), where the one-off set-up is paid back: an evaluation is then three launches and one wait whatever D is
+  const bool fuse = allow_fuse && g->fused && (D >= 2 || g->reused) &&
                     (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK || v == STB_FILL_HB);
   // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
   // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine
@@ -880,7 +889,7 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   // -- the tiles' requests for edges, checkpoints and cell lists stretch the spine's hand-offs between
   // workgroups from 2 to ~17 us, which eats what the lighter spine gains.
   int which = 0;
-  if (fuse && (stb_env_int("STB_ATERMS_CK", 0) || v == STB_FILL_CK) && v != STB_FILL_CHAIN && stb_ck_eligible(g->N, g->M, D) &&
+  if (fuse && stb_launch_ck && (stb_env_int("STB_ATERMS_CK", 0) || v == STB_FILL_CK) && v != STB_FILL_CHAIN && stb_ck_eligible(g->N, g->M, D) &&
       stb_ck_dot_spine(g->N, g->M, D) <= (unsigned)stb_env_int("STB_ATERMS_CK_MAX_SPINE", 208))
     which = 1;
   // ... and in the halo-block form (a spine that walks blocks of rows alone + tile workers that sum their
@@ -962,13 +971,64 @@ extern "C" int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, in
 extern "C" int stb_groups_wait(stb_groups_t *g) {
   STB_ENTRY;
   if (!g) return stb_fail("stb_groups_wait: null group set");
+  if (g->pending == 2) {  // (stb_groups_aterms_device in a flow that finished inside the call)
+    g->pending = 0;
+    return 0;
+  }
   const int prev_dev = stb_device_enter(g->dev);
   double *out = g->pend_out;
   const int D = g->pend_D;
   double x[STB_TERMS_DMAX];
   memcpy(x, g->pend_x, sizeof(x));
+  double *user = g->pend_user;
+  const bool lean = g->pend_lean != 0;
+  g->pend_user = nullptr;
   int rc = aterms_finish(g, nullptr, nullptr, nullptr);
+  const bool redo = rc == 2;
   if (rc == 2) rc = aterms_once(g, x, D, out, false, STB_FILL_PC, nullptr, nullptr, nullptr) ? 1 : 0;
+  // (stb_groups_aterms_device: only the lean flow's last launch writes the caller's device buffer itself)
+  if (!rc && user && (redo || !lean)) {
+    if (hipMemcpyAsync(user, out, sizeof(double) * D, hipMemcpyHostToDevice, g->st) != hipSuccess || hipStreamSynchronize(g->st) != hipSuccess)
+      rc = stb_fail("stb_groups_wait: %s", hipGetErrorString(hipGetLastError()));
+  }
+  stb_device_leave(prev_dev);
+  return rc;
+}
+
+// The same evaluation with the D log-posteriors left on the DEVICE, in d_out[0..D): what a caller that hands them to a
+// collective wants (the discount axis sharded over GPUs: every rank all-gathers its share) -- no copy to
+// the host and back.  Queued on the set's stream behind what `stream` holds now; `stream` in turn waits (on the device)
+// for the values, so work queued on it afterwards sees them.  stb_groups_wait(g) must still be called -- before the
+// values are trusted: it reports a walk that gave up waiting, and then re-evaluates through stored tables and rewrites
+// d_out.
+extern "C" int stb_groups_aterms_device(stb_groups_t *g, const double *x_host, int D, double *d_out, void *stream) {
+  STB_ENTRY;
+  if (!g || !d_out) return stb_fail("stb_groups_aterms_device: null argument");
+  const int prev_dev = stb_device_enter(g->dev);
+  bool fuse = false;
+  int v = 0;
+  int rc = aterms_prepare(g, D, true, &fuse, &v);
+  if (!rc && stream) {
+    if (hipEventRecord(g->ev_dep, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(g->st, g->ev_dep, 0) != hipSuccess)
+      rc = stb_fail("stb_groups_aterms_device: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (!rc) {
+    g->pend_user = d_out;
+    rc = aterms_issue(g, x_host, D, g->pend_host, fuse, v, false);
+    if (rc) g->pend_user = nullptr;
+  }
+  if (!rc && !g->pend_lean) {
+    // (only the lean flow's last launch writes a device buffer: the other flows are finished here and the totals
+    // copied, on the set's stream; the wait that must follow has nothing left to do)
+    g->pend_user = nullptr;
+    rc = aterms_finish(g, nullptr, nullptr, nullptr);
+    if (rc == 2) rc = aterms_once(g, x_host, D, g->pend_host, false, STB_FILL_PC, nullptr, nullptr, nullptr) ? 1 : 0;
+    if (!rc && hipMemcpyAsync(d_out, g->pend_host, sizeof(double) * D, hipMemcpyHostToDevice, g->st) != hipSuccess)
+      rc = stb_fail("stb_groups_aterms_device: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc) g->pending = 2;
+  }
+  if (!rc && (hipEventRecord(g->ev_done, g->st) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g->ev_done, 0) != hipSuccess))
+    rc = stb_fail("stb_groups_aterms_device: %s", hipGetErrorString(hipGetLastError()));
   stb_device_leave(prev_dev);
   return rc;
 }
@@ -998,6 +1058,7 @@ extern "C" int stb_groups_update_restaurants(stb_groups_t *g, const uint32_t *T,
   if (!g) return stb_fail("stb_groups_update_restaurants: null group set");
   const int prev_dev = stb_device_enter(g->dev);
   int rc = 0;
+  g->reused = 1;
   if (g->I > 0) {
     if (hipMemcpyAsync(g->d_T, T, sizeof(uint32_t) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
         hipMemcpyAsync(g->d_bpar, bpar, sizeof(double) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||

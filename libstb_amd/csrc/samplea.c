@@ -27,6 +27,7 @@ typedef struct {
   int maxn, maxt;
   int verbose;
   int keep; /* the device set outlives this call (see `kept`) */
+  int reused; /* ... and came from the previous call: its evaluations sum inside the table walk */
   /* values evaluated ahead of time, served when ARMS asks for exactly these abscissae */
   int npre;
   double xpre[NPRE], ypre[NPRE];
@@ -163,8 +164,10 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
       h = hash_bytes(h, nflat, sizeof(*nflat) * G);
       h = hash_bytes(h, tflat, sizeof(*tflat) * G);
     }
+    ap.reused = 0;
     if (keep && kept.dev && kept.hash == h && kept.I == I && kept.G == G && kept.N == N && kept.M == M) {
       ap.dev = kept.dev;
+      ap.reused = 1;
       if (stb_groups_update_restaurants(ap.dev, T, bpar)) {
         stb_sampler_cache_clear();
         ap.dev = NULL;
@@ -197,7 +200,8 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
        * same expression here, so the same bits): evaluate them in ONE batched device call */
       double x3[NPRE], y3[NPRE];
       for (i = 0; i < NPRE; i++) x3[i] = inita[0] + (i + 1.0) * (inita[2] - inita[0]) / (NPRE + 1.0);
-      if (stb_groups_aterms_tables(ap.dev, x3, NPRE, y3)) {
+      /* (a fresh set: through stored tables, no set-up; a kept one: the fused evaluation, whose cell lists it has) */
+      if (ap.reused ? stb_groups_aterms(ap.dev, x3, NPRE, y3) : stb_groups_aterms_tables(ap.dev, x3, NPRE, y3)) {
         fprintf(stderr, "aterms(): device evaluation failed: %s\n", stb_last_error());
         exit(1);
       }

@@ -93,6 +93,20 @@ static void account(stable_t *sp) {
   sp->memalloced = tot > 0xffffffffull ? 0xffffffffu : (uint32_t)tot;
 }
 
+void stb_table_bytes(stable_t *sp, unsigned long long *device_bytes, unsigned long long *host_bytes) {
+  unsigned long long dv = 0, hs = 0;
+  if (sp && sp->impl) {
+    const stb_impl *im = sp->impl;
+    const mirror *g;
+    dv = im->bytes_dev;
+    hs = im->bytes_host;
+    if (im->cur) hs += im->cur->bytes;
+    for (g = im->retired; g; g = g->next) hs += g->bytes;
+  }
+  if (device_bytes) *device_bytes = dv;
+  if (host_bytes) *host_bytes = hs;
+}
+
 static void lock(stable_t *sp) {
   if (sp->flags & S_THREADS) pthread_mutex_lock(&sp->mutex);
 }
@@ -302,6 +316,16 @@ static int dev_grow(stb_impl *im, double **slot, uint64_t *have, uint64_t want) 
   return 0;
 }
 
+/* S_FLOAT tables are written once, as floats, wherever the fill that narrows before the store applies (the
+ * halo-block form: stb_fill_takes_kind); the double slab then does not exist at all -- half the device memory of a
+ * double table, as the reference's S_FLOAT has half the host memory (lib/stable.h:80-90).  STB_FLOAT_NARROW=1 keeps the
+ * old way: a double slab, narrowed by a second pass. */
+static int float_direct(const stable_t *sp, unsigned N, unsigned M, int vtable) {
+  const char *e = getenv("STB_FLOAT_NARROW");
+  if (!(sp->flags & S_FLOAT) || (e && *e && strcmp(e, "0") != 0)) return 0;
+  return stb_fill_takes_kind(N, M, 1, vtable ? 3 : 1);
+}
+
 /* size the device slabs and scratch for bounds (N,M) */
 static int provision(stable_t *sp, unsigned N, unsigned M) {
   stb_impl *im = sp->impl;
@@ -319,7 +343,7 @@ static int provision(stable_t *sp, unsigned N, unsigned M) {
   if (sp->flags & S_STABLE) {
     uint64_t el = stb_table_elems(N, M);
     if (el < 2) el = 2;
-    if (dev_grow(im, &im->d_S, &im->d_S_elems, el)) return 1;
+    if (!float_direct(sp, N, M, 0) && dev_grow(im, &im->d_S, &im->d_S_elems, el)) return 1;
     if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Sf, &im->d_Sf_elems, el)) return 1;
   }
   if (sp->flags & S_UVTABLE) {
@@ -327,7 +351,7 @@ static int provision(stable_t *sp, unsigned N, unsigned M) {
     if (el < 2) el = 2;
     if (!(sp->flags & S_STABLE) && dev_grow(im, &im->d_S, &im->d_S_elems, stb_table_elems(N, 2) + 2))
       return 1; /* scratch for the S1-only fill */
-    if (dev_grow(im, &im->d_V, &im->d_V_elems, el)) return 1;
+    if (!float_direct(sp, N, M, 1) && dev_grow(im, &im->d_V, &im->d_V_elems, el)) return 1;
     if ((sp->flags & S_FLOAT) && devf_grow(im, &im->d_Vf, &im->d_Vf_elems, el)) return 1;
   }
   return 0;
@@ -337,21 +361,47 @@ static int provision(stable_t *sp, unsigned N, unsigned M) {
 static int build(stable_t *sp, double a, unsigned N, unsigned M) {
   stb_impl *im = sp->impl;
   if (sp->flags & S_STABLE) {
-    if (stb_fill_S(&a, 1, N, M, im->d_S, im->d_S_elems, im->d_S1, N, im->d_ws, im->ws_bytes,
-                   stb_default_variant(), NULL))
-      return 1;
-    /* waits for the fill and, if a one-launch form gave up, repeats it in the other form: only then
-     * may anything read the table (the narrowing below included) */
-    if (stb_fill_status()) return 1;
-    /* all arithmetic was done in double (as lib/stable.c:389-449 does through its frontier
-     * vectors); only the stored values are narrowed, on the device */
-    if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
+    int done = 0;
+    if (float_direct(sp, N, M, 0)) {
+      /* all arithmetic in double (as lib/stable.c:389-449 does through its frontier vectors), the stored value
+       * narrowed by the kernel that computed it: one pass, no double slab.  A fill that gave up waiting cannot be
+       * repeated in this form: the old way below takes over (and only then gets its double slab). */
+      done = !stb_fill_Sf(&a, 1, N, M, im->d_Sf, im->d_Sf_elems, im->d_S1, N, im->d_ws, im->ws_bytes, NULL) && !stb_fill_status();
+      if (!done) {
+        uint64_t el = stb_table_elems(N, M);
+        if (dev_grow(im, &im->d_S, &im->d_S_elems, el < 2 ? 2 : el)) return 1;
+      }
+    }
+    if (!done) {
+      if (stb_fill_S(&a, 1, N, M, im->d_S, im->d_S_elems, im->d_S1, N, im->d_ws, im->ws_bytes,
+                     stb_default_variant(), NULL))
+        return 1;
+      /* waits for the fill and, if a one-launch form gave up, repeats it in the other form: only then
+       * may anything read the table (the narrowing below included) */
+      if (stb_fill_status()) return 1;
+      if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_S, im->d_Sf, stb_table_elems(N, M), NULL)) return 1;
+    }
     if (stb_memcpy_d2h(sp->S1, im->d_S1, sizeof(double) * N, NULL)) return 1;
   }
   if (sp->flags & S_UVTABLE) {
-    if (stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL)) return 1;
-    if (stb_fill_status()) return 1; /* before anything reads it or a later fill reuses the workspace and its header */
-    if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
+    int done = 0;
+    if (float_direct(sp, N, M, 1)) {
+      done = !stb_fill_Vf(&a, 1, N, M, im->d_Vf, im->d_Vf_elems, im->d_ws, im->ws_bytes, NULL) && !stb_fill_status();
+      if (!done) {
+        uint64_t el = stb_vtable_elems(N, M);
+        if (dev_grow(im, &im->d_V, &im->d_V_elems, el < 2 ? 2 : el)) return 1;
+      }
+    }
+    if (!done) {
+      int rc = stb_fill_V(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL);
+      if (!rc) rc = stb_fill_status(); /* before anything reads it or a later fill reuses the workspace and its header */
+      if (rc) {
+        /* (the V table from the S recurrence's cells gave up waiting: the reference's own recurrence, which cannot) */
+        rc = stb_fill_V_exact(&a, 1, N, M, im->d_V, im->d_V_elems, im->d_ws, im->ws_bytes, NULL);
+        if (rc || stb_fill_status()) return 1;
+      }
+      if ((sp->flags & S_FLOAT) && stb_table_to_float(im->d_V, im->d_Vf, stb_vtable_elems(N, M), NULL)) return 1;
+    }
   }
   if (!(sp->flags & S_STABLE)) {
     /* U/V-only tables still keep S1 (lib/stable.c:155, :337-348): take it from a width-2 S fill

@@ -5,7 +5,8 @@
 //   abi.hip          error text, device selection, buffer cache, memory helpers, layout exports
 //   fill.hip         stb_fill_S / stb_fill_V: choice of form, workspace, status, per-launch timing
 //   fill_chain.hip   k_fill_chain (default S fill, also the fused aterms sum), k_fillv_chain (V)
-//   fill_ck.hip      k_fill_ck (spine + tile workers: few tables), k_col1
+//   fill_hb.hip      k_fill_hb (halo-block spine + tile workers: the default fill; floats and V ratios too)
+//   grid_hb.hip      k_grid_hb (the fused grid aterms whose walking waves sum their own strips)
 //   fill_pc.hip      k_fill_pc (launch-per-128-rows form: many tables, and the fallback), k_s1
 //   fill_rows.hip    k_fill_rows: the reference's own operation order (log domain / V ratios)
 //   sweep_terms.hip  k_lookup, k_to_float, k_sweep_partial, k_terms_partial, reductions
@@ -146,21 +147,25 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
                      hipStream_t st);
 int stb_launch_vchain(fill_args &A, int D, char *ws, size_t ws_left, unsigned **hdr_out, hipStream_t st);
 int stb_chain_tuning(unsigned N, unsigned M, int D, int *W_out);  // columns per strip
-// checkpointed form (fill_ck.hip): spine + tile workers, one launch
-bool stb_ck_eligible(unsigned N, unsigned M, int D);
-size_t stb_ck_workspace(unsigned N, unsigned M, int D);
-int stb_ck_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // columns of a wave strip, rows of a tile
-int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
-unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D);  // partial sums per table of the summing form
-unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D);  // spine workgroups it launches for D tables
+// checkpointed form (tools/ablation/fill_ck.hip: spine + tile workers, one launch; superseded by the halo-block form and
+// absent from the default build: weak, like the other ablation entry points -- test stb_launch_ck before any of them)
+bool stb_ck_eligible(unsigned N, unsigned M, int D) __attribute__((weak));
+size_t stb_ck_workspace(unsigned N, unsigned M, int D) __attribute__((weak));
+int stb_ck_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out) __attribute__((weak));  // columns of a wave strip, rows of a tile
+int stb_launch_ck(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st)
+    __attribute__((weak));
+unsigned stb_ck_dot_parts(unsigned N, unsigned M, int D) __attribute__((weak));  // partial sums per table of the summing form
+unsigned stb_ck_dot_spine(unsigned N, unsigned M, int D) __attribute__((weak));  // spine workgroups it launches for D tables
 
 int stb_cu_count();  // compute units of the current device
 // halo-block form (fill_hb.hip): a spine that walks blocks of rows alone + tile workers, one launch
 bool stb_hb_eligible(unsigned N, unsigned M, int D);
+bool stb_hb_eligible_out(unsigned N, unsigned M, int D, int out_kind);
 size_t stb_hb_workspace(unsigned N, unsigned M, int D);
 unsigned stb_hb_spine(unsigned N, unsigned M, int D);  // spine workgroups of a fill of D tables
 int stb_hb_tuning(unsigned N, unsigned M, int D, int *W_out, int *rows_out);  // own columns of a strip, rows of a block
-int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
+// out_kind: 0 log S (double), 1 log S (float), 2 V = S^n_m / S^n_{m-1} (double), 3 V (float); A.tables is the slab of that type
+int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st, int out_kind = 0);
 struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: item = record index * NQ + group of 4 rows)
   int R, UC, HC, NB, JW, NQ;   // rows of a block, own columns of a strip, halo columns, blocks, strips, groups per item base
   int G, C;                    // rows of a group, columns per lane

@@ -21,7 +21,7 @@ def test_library_sees_gpu():
     assert L.stb_device_count() >= 1, capi.last_error()
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_HB])
 def test_small_tables_batched_vs_golden(golden_dir, variant):
     """configs[0] shape (N=200, M=50), five discounts in ONE batched launch sequence."""
     z = np.load(os.path.join(golden_dir, "stable_200x50.npz"))
@@ -36,7 +36,7 @@ def test_small_tables_batched_vs_golden(golden_dir, variant):
         assert orc.close(T.S1[d].cpu().numpy(), z[k + "_S1"], TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_HB])
 @pytest.mark.parametrize("N,M", [(2, 2), (3, 2), (3, 3), (10, 10), (64, 64), (65, 33), (97, 96), (130, 129), (500, 7),
                                  (1000, 1000), (1500, 260)])
 def test_ragged_shapes_vs_oracle(N, M, variant):
@@ -63,7 +63,7 @@ def test_tunings_agree(monkeypatch, C, R):
     assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_LOGDOMAIN, capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_HB])
 @pytest.mark.parametrize("a", [0.5, 0.1, 0.9])
 def test_4000_full_table_vs_oracle(golden_dir, a, variant):
     N = 4000
@@ -97,7 +97,7 @@ def test_10000_config2_vs_golden(golden_dir, a):
         rowsum[n] = np.sum(r)
         absmax[n] = (n - 2) * max(1.0, np.max(np.abs(r)))
     want = z[key + "_rowsum"]
-    # (every cell is also compared at 1e-10 in tests/test_gpu_fill_ck.py::test_10000_full_table_vs_oracle;
+    # (every cell is also compared at 1e-10 in tests/test_gpu_fill_hb.py::test_hb_10000_full_table_vs_oracle;
     # here the bar on a row's sum is 1e-12 of n * max|row|, which a single cell off by 1e-7 relative breaks)
     assert np.all(np.abs(rowsum - want) <= 1e-12 * np.maximum(absmax, 1.0))
     for n in (N // 3, N):
@@ -206,13 +206,76 @@ def test_v_table_bit_exact(golden_dir):
 
 
 def test_v_table_big_vs_oracle():
-    T = capi.DeviceVTables(3000, 1200, D=1)
-    T.fill([0.4])
+    """3000 x 1200: on the reference's own recurrence (two dependent divisions a row) the table is the reference's
+    bit for bit; the default for a table this size takes every V^n_m = S^n_m / S^n_{m-1} from the S recurrence's
+    block-floating cells instead -- one division per cell, off the serial path -- and is within 1e-10"""
     want = orc.fill_V(0.4, 3000, 1200)
+    T = capi.DeviceVTables(3000, 1200, D=1)
+    T.tables.fill_(float("nan"))
+    T.fill([0.4], exact=True)
     assert np.array_equal(T.packed_host(0), want)
+    T.tables.fill_(float("nan"))
+    assert capi.lib().stb_fill_takes_kind(3000, 1200, 1, 2) == 1
+    T.fill([0.4])
+    T.status = capi.DeviceTables.status.__get__(T)
+    T.status()
+    got = T.packed_host(0)
+    assert np.all(np.isfinite(got))
+    assert orc.max_err(got, want) <= TOL, orc.max_err(got, want)
 
 
-@pytest.mark.parametrize("variant", [capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_CK, capi.FILL_HB, capi.FILL_SCALED])
+@pytest.mark.parametrize("N,M,D,a", [(10000, 10000, 1, [0.5]), (4000, 4000, 3, [0.0, 0.01, 0.98]), (2500, 700, 2, [0.3, 0.9]),
+                                     (777, 777, 1, [0.66])])
+def test_v_table_from_the_s_recurrence_vs_oracle(N, M, D, a):
+    """the V table (reference lib/stable.c:451-482) taken from the halo-block fill's cells, every cell against the
+    oracle's V recurrence at 1e-10: config sizes, the ends of samplea's bracket and a = 0, a table wider than tall is
+    not possible (M <= N) but a narrow one is, and the diagonal column V^n_n = 1 / S^n_{n-1} is part of every row"""
+    L = capi.lib()
+    assert L.stb_fill_takes_kind(N, M, D, 2) == 1
+    T = capi.DeviceVTables(N, M, D=D)
+    T.tables.fill_(float("nan"))
+    before = L.stb_fill_fallbacks()
+    T.fill(a)
+    capi.check(L.stb_fill_status())
+    assert L.stb_fill_fallbacks() == before
+    for d in range(D):
+        want = orc.fill_V(float(a[d]), N, M)
+        got = T.packed_host(d)
+        assert np.all(np.isfinite(got)), d
+        assert orc.max_err(got, want) <= TOL, (d, orc.max_err(got, want))
+
+
+@pytest.mark.parametrize("N,M,D,a", [(10000, 10000, 1, [0.5]), (3000, 1200, 2, [0.05, 0.95]), (4000, 4000, 8, None)])
+def test_float_tables_written_once(N, M, D, a):
+    """S_FLOAT (reference lib/stable.c:389-449, :483-537): the recurrence in double, the stored value a float -- here
+    narrowed by the kernel that computed it, no double slab anywhere.  Every cell equals the double table's value
+    rounded to float (S) / is within a float ulp of the oracle's V."""
+    L = capi.lib()
+    a = np.asarray(a if a is not None else synth.discount_grid(64)[:D], dtype=np.float64)
+    assert L.stb_fill_takes_kind(N, M, D, 1) == 1 and L.stb_fill_takes_kind(N, M, D, 3) == 1
+    F = capi.DeviceFloatTables(N, M, D=D)
+    F.tables.fill_(float("nan"))
+    F.fill(a)
+    F.status()
+    T = capi.DeviceTables(N, M, D=D)
+    T.fill(a, capi.FILL_HB)
+    T.status()
+    for d in range(D):
+        got, dbl = F.packed_host(d), T.packed_host(d)
+        assert np.array_equal(got, dbl.astype(np.float32)), d      # the same double, narrowed once
+        assert np.array_equal(F.S1[d].cpu().numpy(), T.S1[d].cpu().numpy())
+    V = capi.DeviceVTables(N, M, D=D, dtype="f32")
+    V.tables.fill_(float("nan"))
+    V.fill(a)
+    capi.check(L.stb_fill_status())
+    for d in (0, D - 1):
+        want = orc.fill_V(float(a[d]), N, M)
+        got = V.packed_host(d)
+        assert np.all(np.isfinite(got))
+        assert np.max(np.abs(got.astype(np.float64) - want) / np.abs(want)) <= 2.0 ** -23, d
+
+
+@pytest.mark.parametrize("variant", [capi.FILL_PC, capi.FILL_CHAIN, capi.FILL_HB, capi.FILL_SCALED])
 @pytest.mark.parametrize("a", [0.0, 0.01, 0.07, 0.5, 0.98])
 def test_growth_next_to_the_diagonal(a, variant, monkeypatch):
     """cells next to the diagonal grow by ~n^2/2 per row (S^n_{n-1} = n(n-1)(1-a)/2): the

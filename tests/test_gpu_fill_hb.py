@@ -1,6 +1,9 @@
 """GPU parity of the halo-block fill form (k_fill_hb: a spine that walks blocks of rows behind a halo,
 alone, + tile workers; libstb_amd/csrc/fill_hb.hip) through the C ABI, against the oracle's table
 (reference recurrence lib/stable.c:380-388).  Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import pytest
 
@@ -152,12 +155,14 @@ def test_hb_gives_up_instead_of_hanging(monkeypatch):
     assert orc.max_err(T.packed_host(0), tab) <= TOL
 
 
-def test_hb_10000_full_table_vs_oracle():
-    """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's"""
+@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_HB])
+def test_hb_10000_full_table_vs_oracle(variant):
+    """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's (reference
+    recurrence lib/stable.c:380-388), in the form stb_fill_S picks by itself and forced into the halo blocks"""
     N, a = 10000, 0.5
     T = capi.DeviceTables(N, N, D=1)
     T.tables.fill_(float("nan"))
-    T.fill([a], capi.FILL_HB)
+    T.fill([a], variant)
     T.status()
     S1, tab = orc.fill_S(a, N, N)
     got = T.packed_host(0)
@@ -181,3 +186,49 @@ def test_hb_discount_zero_and_the_samplers_bounds(monkeypatch, C):
     T.status()
     assert L.stb_fill_fallbacks() == before
     _check_tables(T, a, 4000, 4000)
+
+
+def test_float_table_after_a_fill_that_gave_up(monkeypatch):
+    """S_FLOAT through S_make when the one-launch fill gives up (bound on its waits set to zero): the
+    float slab must be narrowed from the table the producer/consumer form rebuilt, not from what the
+    aborted fill left behind (the narrowing is queued only after the status check)"""
+    L = capi.lib()
+    N, M, a = 1500, 1400, 0.45
+    S1, tab = orc.fill_S(a, N, M)
+    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
+    before = L.stb_fill_fallbacks()
+    t = capi.Table(N, M, N, M, a, capi.S_STABLE | capi.S_FLOAT)
+    assert L.stb_fill_fallbacks() == before + 1          # the chain form did give up and was replaced
+    for n, m in ((3, 2), (100, 57), (700, 699), (1499, 1000), (1500, 1399), (1500, 2)):
+        want = tab[orc.row_offset(n, M) + m - 2]
+        got = t.S(n, m)
+        assert got == float(np.float32(got))             # stored as float
+        assert abs(got - want) <= 2e-7 * max(1.0, abs(want)), (n, m, got, want)
+    t.free()
+
+
+@pytest.mark.parametrize("D", [8, 64])
+def test_10000_batch_every_table_vs_oracle(D):
+    """configs[2]: EVERY table of the 8-per-GPU share (halo-block form, the default there) and of the whole
+    64-discount batch on one GPU (producer/consumer form) against the oracle: the last row, an interior row and
+    the row where the table turns rectangular-free (n = N/3), per-row maximum relative error"""
+    N = 10000
+    grid = synth.discount_grid(64)
+    a = np.ascontiguousarray(grid[:D])
+    T = capi.DeviceTables(N, N, D=D)
+    T.fill(a)
+    T.status()
+    rows = (N, 6311, N // 3)
+
+    def oracle_rows(ad):
+        S1, tab = orc.fill_S(float(ad), N, N)
+        return [tab[orc.row_offset(n, N):orc.row_offset(n, N) + n - 2].copy() for n in rows], S1[-1]
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(oracle_rows, a))
+    for d in range(D):
+        for n, w in zip(rows, want[d][0]):
+            got = T.row(d, n).cpu().numpy()
+            err = np.abs(got - w) / np.maximum(1.0, np.abs(w))
+            assert np.all(np.isfinite(got)) and float(err.max()) <= TOL, (d, n, float(err.max()))
+        assert abs(float(T.S1[d, N - 1]) - want[d][1]) <= TOL * abs(want[d][1])

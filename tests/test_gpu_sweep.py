@@ -255,62 +255,6 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
             L.stb_groups_free(h)
 
 
-def test_fused_aterms_in_the_checkpointed_form(monkeypatch, golden_dir):
-    """STB_ATERMS_CK=1: the summing fill as recurrence-only spine + tile workers (k_fill_ck<.., DOT>, cell lists
-    keyed from column 2).  Same sums as the chain form to rounding -- against the reference's aterms golden values
-    at 1e-10, against the chain form, run to run bit for bit -- with edge pairs, several tables and a set whose
-    chain-form lists are built later on the same object (both layouts live side by side)."""
-    L = capi.lib()
-    monkeypatch.setenv("STB_ATERMS_HB", "0")       # (the halo-block form is the default for a grid: its own test below)
-    spec = load(golden_dir, "aterms.json")["mid_wide"]
-    g = groups_of(spec)
-    N, M = bounds(spec)
-    xs = np.array([fh(v) for v in spec["x"]])
-    want = np.array([fh(v) for v in spec["aterms"]])
-    D = min(len(xs), 8)
-    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
-    assert h, capi.last_error()
-    try:
-        x = np.ascontiguousarray(xs[:D])
-        ck1, ck2, ch = np.zeros(D), np.zeros(D), np.zeros(D)
-        monkeypatch.setenv("STB_ATERMS_CK", "1")
-        fb = L.stb_fill_fallbacks()
-        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ck1)))
-        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ck2)))
-        assert L.stb_fill_fallbacks() == fb
-        monkeypatch.setenv("STB_ATERMS_CK", "0")
-        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ch)))      # the other layout, same object
-        assert np.array_equal(ck1, ck2)
-        assert orc.close(ck1, want[:D], 1e-10), orc.max_err(ck1, want[:D])
-        assert orc.close(ck1, ch, 1e-12), (ck1, ch)
-    finally:
-        L.stb_groups_free(h)
-    # edge pairs (t = 1, t = n, n = 1, many pairs on one cell, next to the diagonal), 3 tables of 900 x 900
-    g = synth.groups(80, 60, 900, "wide")
-    n, t = g.n.copy(), g.t.copy()
-    n[0], t[0] = 1, 1
-    n[1], t[1] = 77, 77
-    n[2], t[2] = 500, 1
-    n[3], t[3] = 3, 2
-    n[4], t[4] = 900, 2
-    n[5], t[5] = 900, 899
-    n[6:40], t[6:40] = 400, 123
-    x = np.array([0.11, 0.5, 0.83])
-    outs = []
-    monkeypatch.setenv("STB_ATERMS_GRID", "0")
-    for ck in ("1", "0"):
-        monkeypatch.setenv("STB_ATERMS_CK", ck)
-        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
-        assert h, capi.last_error()
-        try:
-            out = np.zeros(3)
-            capi.check(L.stb_groups_aterms(h, capi.dp(x), 3, capi.dp(out)))
-            outs.append(out)
-        finally:
-            L.stb_groups_free(h)
-    assert np.all(np.isfinite(outs[0])) and orc.close(outs[0], outs[1], 1e-12), outs
-
-
 def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
     """the default for a grid of discounts: the summing fill as k_fill_hb<4, DOT> (a spine that walks blocks of rows
     alone + tile workers that sum their tiles' listed cells; cell lists keyed by (tile, group of 4 rows)).  Same

@@ -102,3 +102,32 @@ def test_async_then_wait_equals_the_blocking_call():
         assert np.array_equal(o, w)
     for h in hs:
         L.stb_groups_free(h)
+
+
+def test_device_resident_result_equals_the_blocking_call():
+    """stb_groups_aterms_device leaves the D log-posteriors in device memory (what an all-gather over the GPUs of a
+    node takes): the same bits as the blocking call, in the lean flow (a grid) and through stored tables (one
+    discount), with the caller's stream ordered behind the values"""
+    import torch
+    L = capi.lib()
+    g = synth.groups(200, 100, 1500, "wide")
+    M = max(int(g.t.max()) + 1, 10)
+    N = max(int(g.n.max()) + 1, M)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, 8)
+    assert h, capi.last_error()
+    try:
+        for D in (8, 1):
+            x = np.ascontiguousarray(synth.discount_grid(64)[:D])
+            want = np.zeros(D)
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(want)))
+            d_out = torch.full((D,), float("nan"), dtype=torch.float64, device="cuda")
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                capi.check(L.stb_groups_aterms_device(h, capi.dp(x), D, d_out.data_ptr(), capi.stream_ptr(side)))
+                doubled = d_out * 2.0            # queued on the caller's stream: must see the values
+            capi.check(L.stb_groups_wait(h))
+            side.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), want), D
+            assert np.array_equal(doubled.cpu().numpy(), 2.0 * want), D
+    finally:
+        L.stb_groups_free(h)

@@ -107,10 +107,16 @@ def _gpu_worker(rank, world, port, q):
         h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
                                 Ng, Mg, len(mine))
         assert h, capi.last_error()
+        # the log-posteriors stay on the device: what the gather takes (no copy to the host and back)
         out = np.zeros(len(mine))
         capi.check(L.stb_groups_aterms(h, capi.dp(mine), len(mine), capi.dp(out)))
+        d_post = torch.full((len(mine),), float("nan"), dtype=torch.float64, device=dev)
+        capi.check(L.stb_groups_aterms_device(h, capi.dp(mine), len(mine), d_post.data_ptr(), capi.stream_ptr()))
+        capi.check(L.stb_groups_wait(h))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_post.cpu().numpy(), out)
         L.stb_groups_free(h)
-        full_post = shard.gather_scalars(torch.as_tensor(out, device=dev), D, dist)
+        full_post = shard.gather_scalars(d_post, D, dist)
         q.put((rank, full_probe.cpu().numpy().tolist(), full_post.cpu().numpy().tolist()))
     finally:
         dist.destroy_process_group()

@@ -1,9 +1,19 @@
-"""GPU parity of the checkpointed fill form (k_fill_ck: recurrence-only spine + tile workers,
-libstb_amd/csrc/fill_ck.hip) through the C ABI, and the full-size cell-by-cell checks of the table
-fill (reference lib/stable.c:380-388) whatever form stb_fill_S picks.
+"""GPU parity of the checkpointed fill form (k_fill_ck: recurrence-only spine + tile workers, tools/ablation/fill_ck.hip;
+round 3's first design, superseded by the halo-block form and no longer in the product library) through the C ABI.
+Build and run on a GPU box from the repo root:
+
+    make -C tools/ablation
+    STB_LIB_PATH=$PWD/libstb_amd/lib/libstb_amd_ablation.so python -m pytest tools/ablation/test_fill_ck.py -q
+
 Parity metric |x-y| <= 1e-10*max(1,|y|)."""
+import json
 import os
-from concurrent.futures import ThreadPoolExecutor
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p_ in (ROOT, os.path.join(ROOT, "tests")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
 
 import numpy as np
 import pytest
@@ -11,7 +21,27 @@ import pytest
 import orc
 from libstb_amd import capi, synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not capi.lib().stb_has_ablation(), reason="load libstb_amd_ablation.so through STB_LIB_PATH")]
+fh = float.fromhex
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+def groups_of(spec):
+    return synth.groups(spec["I"], spec["K"], spec["n_max"], spec["profile"])
+
+
+def bounds(spec):
+    M = max(spec["maxt"], 10)
+    return max(spec["maxn"], M), M
 TOL = 1e-10
 
 
@@ -122,26 +152,7 @@ def test_ck_gives_up_instead_of_hanging(monkeypatch):
     assert orc.max_err(T.packed_host(0), tab) <= TOL
 
 
-def test_float_table_after_a_fill_that_gave_up(monkeypatch):
-    """S_FLOAT through S_make when the one-launch fill gives up (bound on its waits set to zero): the
-    float slab must be narrowed from the table the producer/consumer form rebuilt, not from what the
-    aborted fill left behind (the narrowing is queued only after the status check)"""
-    L = capi.lib()
-    N, M, a = 1500, 1400, 0.45
-    S1, tab = orc.fill_S(a, N, M)
-    monkeypatch.setenv("STB_CHAIN_TIMEOUT_MS", "0")
-    before = L.stb_fill_fallbacks()
-    t = capi.Table(N, M, N, M, a, capi.S_STABLE | capi.S_FLOAT)
-    assert L.stb_fill_fallbacks() == before + 1          # the chain form did give up and was replaced
-    for n, m in ((3, 2), (100, 57), (700, 699), (1499, 1000), (1500, 1399), (1500, 2)):
-        want = tab[orc.row_offset(n, M) + m - 2]
-        got = t.S(n, m)
-        assert got == float(np.float32(got))             # stored as float
-        assert abs(got - want) <= 2e-7 * max(1.0, abs(want)), (n, m, got, want)
-    t.free()
-
-
-@pytest.mark.parametrize("variant", [capi.FILL_SCALED, capi.FILL_CK])
+@pytest.mark.parametrize("variant", [capi.FILL_CK])
 def test_10000_full_table_vs_oracle(variant):
     """configs[1] cell by cell: all 49 985 001 cells of the N=M=10000, a=0.5 table against the oracle's
     (reference recurrence lib/stable.c:380-388), in the form stb_fill_S picks (halo blocks) and in the checkpointed one"""
@@ -159,28 +170,61 @@ def test_10000_full_table_vs_oracle(variant):
     assert orc.close(T.S1[0].cpu().numpy(), S1, TOL)
 
 
-@pytest.mark.parametrize("D", [8, 64])
-def test_10000_batch_every_table_vs_oracle(D):
-    """configs[2]: EVERY table of the 8-per-GPU share (halo-block form, the default there) and of the whole
-    64-discount batch on one GPU (producer/consumer form) against the oracle: the last row, an interior row and
-    the row where the table turns rectangular-free (n = N/3), per-row maximum relative error"""
-    N = 10000
-    grid = synth.discount_grid(64)
-    a = np.ascontiguousarray(grid[:D])
-    T = capi.DeviceTables(N, N, D=D)
-    T.fill(a)
-    T.status()
-    rows = (N, 6311, N // 3)
 
-    def oracle_rows(ad):
-        S1, tab = orc.fill_S(float(ad), N, N)
-        return [tab[orc.row_offset(n, N):orc.row_offset(n, N) + n - 2].copy() for n in rows], S1[-1]
 
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        want = list(ex.map(oracle_rows, a))
-    for d in range(D):
-        for n, w in zip(rows, want[d][0]):
-            got = T.row(d, n).cpu().numpy()
-            err = np.abs(got - w) / np.maximum(1.0, np.abs(w))
-            assert np.all(np.isfinite(got)) and float(err.max()) <= TOL, (d, n, float(err.max()))
-        assert abs(float(T.S1[d, N - 1]) - want[d][1]) <= TOL * abs(want[d][1])
+def test_fused_aterms_in_the_checkpointed_form(monkeypatch, golden_dir):
+    """STB_ATERMS_CK=1: the summing fill as recurrence-only spine + tile workers (k_fill_ck<.., DOT>, cell lists
+    keyed from column 2).  Same sums as the chain form to rounding -- against the reference's aterms golden values
+    at 1e-10, against the chain form, run to run bit for bit -- with edge pairs, several tables and a set whose
+    chain-form lists are built later on the same object (both layouts live side by side)."""
+    L = capi.lib()
+    monkeypatch.setenv("STB_ATERMS_HB", "0")       # (the halo-block form is the default for a grid: its own test below)
+    spec = load(golden_dir, "aterms.json")["mid_wide"]
+    g = groups_of(spec)
+    N, M = bounds(spec)
+    xs = np.array([fh(v) for v in spec["x"]])
+    want = np.array([fh(v) for v in spec["aterms"]])
+    D = min(len(xs), 8)
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), N, M, D)
+    assert h, capi.last_error()
+    try:
+        x = np.ascontiguousarray(xs[:D])
+        ck1, ck2, ch = np.zeros(D), np.zeros(D), np.zeros(D)
+        monkeypatch.setenv("STB_ATERMS_CK", "1")
+        fb = L.stb_fill_fallbacks()
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ck1)))
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ck2)))
+        assert L.stb_fill_fallbacks() == fb
+        monkeypatch.setenv("STB_ATERMS_CK", "0")
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(ch)))      # the other layout, same object
+        assert np.array_equal(ck1, ck2)
+        assert orc.close(ck1, want[:D], 1e-10), orc.max_err(ck1, want[:D])
+        assert orc.close(ck1, ch, 1e-12), (ck1, ch)
+    finally:
+        L.stb_groups_free(h)
+    # edge pairs (t = 1, t = n, n = 1, many pairs on one cell, next to the diagonal), 3 tables of 900 x 900
+    g = synth.groups(80, 60, 900, "wide")
+    n, t = g.n.copy(), g.t.copy()
+    n[0], t[0] = 1, 1
+    n[1], t[1] = 77, 77
+    n[2], t[2] = 500, 1
+    n[3], t[3] = 3, 2
+    n[4], t[4] = 900, 2
+    n[5], t[5] = 900, 899
+    n[6:40], t[6:40] = 400, 123
+    x = np.array([0.11, 0.5, 0.83])
+    outs = []
+    monkeypatch.setenv("STB_ATERMS_GRID", "0")
+    for ck in ("1", "0"):
+        monkeypatch.setenv("STB_ATERMS_CK", ck)
+        h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 3)
+        assert h, capi.last_error()
+        try:
+            out = np.zeros(3)
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), 3, capi.dp(out)))
+            outs.append(out)
+        finally:
+            L.stb_groups_free(h)
+    assert np.all(np.isfinite(outs[0])) and orc.close(outs[0], outs[1], 1e-12), outs
+
+
