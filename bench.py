@@ -248,11 +248,14 @@ def sampler_calls(g):
         ta = time.perf_counter() - t0
         best = ta if best is None else min(best, ta)
     evals = L.stb_sampler_trace_count()
-    orc.seed_libc(777, 12345)
-    t0 = time.perf_counter()
-    b_new = L.sampleb(10.0, g.I, g.shape, g.scale, g.N.ctypes.data_as(capi.c_u32_p), g.T.ctypes.data_as(capi.c_u32_p),
-                      0.5, None, 1, 0)
-    tb = time.perf_counter() - t0
+    tb = None
+    for _ in range(3):  # (best of three calls, like samplea: the first one makes the thread's device context)
+        orc.seed_libc(777, 12345)
+        t0 = time.perf_counter()
+        b_new = L.sampleb(10.0, g.I, g.shape, g.scale, g.N.ctypes.data_as(capi.c_u32_p), g.T.ctypes.data_as(capi.c_u32_p),
+                          0.5, None, 1, 0)
+        t1 = time.perf_counter() - t0
+        tb = t1 if tb is None else min(tb, t1)
     out["samplea"] = {"seconds": best, "aterms_evaluations": evals, "a": a_new, "grid_evals_per_s": evals * g.pairs / best}
     out["sampleb"] = {"seconds": tb, "bterms_evaluations": L.stb_sampler_trace_count(), "b": b_new}
     if orc.have_ref():

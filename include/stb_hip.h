@@ -160,6 +160,7 @@ int stb_bterms(const double *x_host, int J, double Q, double shape, double apar,
  * values arriving in pinned host memory without a copy call */
 typedef struct stb_bctx stb_bctx_t;
 stb_bctx_t *stb_bterms_create(const uint32_t *T, int I);
+int stb_bterms_update(stb_bctx_t *c, const uint32_t *T, int I); /* new totals, I <= the I it was created with; else non-zero */
 int stb_bterms_eval(stb_bctx_t *c, const double *x_host, int J, double Q, double shape, double apar, double *out_host);
 void stb_bterms_free(stb_bctx_t *c);
 

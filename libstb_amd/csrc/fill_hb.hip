@@ -65,6 +65,12 @@
 #else
 #define HB_STAMP() ((unsigned long long)wall_clock64())
 #endif
+#ifndef HB_LTX
+#define HB_LTX 0           // 1: the storing kernels hold the log table 16 times in LDS (no bank conflicts), 0: once.  Measured
+                           // (MI355X, tools/ab_lib.py, N = M = 10^4, medians): 8 tables 0.772 / 0.813 ms with either, 16 tables
+                           // 1.446 against 1.444, one table 0.332 against 0.325 (32 KB more to set up per workgroup): the
+                           // storing workers wait for their stores, not for LDS -- left off
+#endif
 #ifndef HB_DIAG
 #define HB_DIAG 0          // diagnostic builds: 1 the spine stores no records, 2 it stores every record twice, 8 the workers store nothing, 16 summing workers look nothing up, 32 ... and stage nothing (results wrong)
 #endif
@@ -121,11 +127,19 @@ __device__ __forceinline__ void hb_store_wt16(unsigned long long *p, unsigned lo
 }
 
 // ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
+// (LTX: the table is held 16 times, entry e of copy c at lt[e * 16 + c], and a lane reads copy lane & 15: the sixteen lanes
+// a 16-byte LDS read serves per cycle then sit on sixteen different slots whatever their entries -- no bank conflicts,
+// where 64 random entries of ONE 2 KB table cost a storing worker 56 % of its LDS cycles, profiles/r03_sq_counters_fill8.txt)
+template <bool LTX>
 __device__ __forceinline__ void hb_logs8(const double (&x)[8], const int (&ep8)[8], const double2 *lt, int one_hi, double (&val)[8]) {
   double z[8], kf[8], r[8], pl[8];
   double2 tt[8];
+  const int l15 = LTX ? (int)(threadIdx.x & 15) : 0;
 #pragma unroll
-  for (int u = 0; u < 8; u++) tt[u] = lt[(__double2hiint(x[u]) >> 13) & 127];
+  for (int u = 0; u < 8; u++) {
+    const int e = (__double2hiint(x[u]) >> 13) & 127;
+    tt[u] = lt[LTX ? (e << 4) | l15 : e];
+  }
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const int hi = __double2hiint(x[u]);
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   constexpr bool VT = (OUT & 2) != 0, FL = (OUT & 1) != 0;
   // a worker lane's groups of adjacent elements (see the workers; a float row of 4 columns per lane is one 16-byte store)
   constexpr int NG = (C == 4 && DOT == 0 && !FL) ? 2 : 1, CG = C / NG;
-  __shared__ double2 lt[128];
+  constexpr bool LTX = (DOT == 0) && (HB_LTX != 0);  // the storing kernels hold the log table 16 times (see hb_logs8)
+  __shared__ double2 lt[LTX ? 128 * 16 : 128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
   __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
   __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
@@ -203,7 +218,11 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.hdr, 1u);
-  if (tid < 128) lt[tid] = A.lt[tid];
+  if constexpr (LTX) {
+    for (int i = tid; i < 128 * 16; i += blockDim.x) lt[i] = A.lt[i >> 4];
+  } else {
+    if (tid < 128) lt[tid] = A.lt[tid];
+  }
   const bool order_in_lds = X.order_lds != 0;
   if (order_in_lds)
     for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
@@ -811,7 +830,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
 #pragma unroll
             for (int q = 0; q < 8; q++) val[q] = x[q] / xl[q];
           } else {
-            hb_logs8(x, ep8, lt, one_hi, val);
+            hb_logs8<LTX>(x, ep8, lt, one_hi, val);
           }
 #pragma unroll
           for (int u = 0; u < RS; u++) {
@@ -1135,7 +1154,9 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", dot ? 6 : (g.C == 4 ? 4 : 3));
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
-  X.doze = stb_env_int("STB_HB_DOZE", 1);
+  // (measured, MI355X, N = M = 10^4: one table 0.365 ms with it against 0.321 without -- a late start is never made up,
+  // and every strip's is up to 512 cycles late; 8 tables 0.74-0.80 against 0.80: off unless asked for)
+  X.doze = stb_env_int("STB_HB_DOZE", 0);
   if (dot) {
     X.item_ptr = dot->item_ptr;
     X.ent_pos = dot->ent_pos;

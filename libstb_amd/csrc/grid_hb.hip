@@ -33,6 +33,9 @@
 #define GH_WRITTEN 0x8000000000000000ull
 #define GH_SPIN 48
 #define GH_MAXPH 16           // phases at most
+#ifndef GH_NOSTORE
+#define GH_NOSTORE 0          // diagnostic build: 1 nothing is staged (results wrong)
+#endif
 
 struct gh_args {
   const double *a;             // [D] discounts
@@ -44,9 +47,10 @@ struct gh_args {
   double *state_v;             // [D][JW][64 * C]  a strip's significands between two phases
   int *state_e;                // [D][JW][64]      ... and lane exponents
   const unsigned *tile_off;    // [JW + 2], entry j + 1: tiles of the strips before strip j (a strip's tiles are its blocks from its first one on)
-  const unsigned *dense;       // [n_tiles * NQ][64] the listed cells of every (tile, group of G rows), a word per lane:
-                               // (row in group << 8 | element of the wave, halo included) | count << 13, 0 for none;
-                               // 0xffffffff in lane 63: more than 63 cells, or a large count -- see the three lists below
+  const unsigned *tinfo;       // [n_tiles] first word / 64 << 6 | NW: where a tile's listed cells start in `dense` and how many
+                               // words per lane each of its NQ groups of G rows has (63: taken from the three lists below)
+  const unsigned *dense;       // a listed cell is a word: (row in group << 8 | element of the wave, halo included) | count << 13,
+                               // 0 for none; group q of a tile: words [first + q NW, first + (q + 1) NW) x 64 lanes
   const unsigned *item_ptr;    // [n_tiles * NQ + 1] first list entry of every (tile, group)
   const unsigned short *ent_pos;  // row in group << 8 | element of the wave
   const unsigned *ent_cnt;     // occurrence count
@@ -92,26 +96,46 @@ __device__ __forceinline__ void gh_row(double (&v)[C], double (&coef)[C], double
 
 __host__ __device__ static inline int gh_first_block(int j, int UC, int R) { return (int)(((long long)j * UC) / R); }
 
-// One look-up pass: every lane with `valid` takes one listed cell of the group just walked.  Rows 0, 2, 4, .. of
-// the group are staged (row r at stage + (r / 2) WS); a cell of an odd row is one step of the recurrence away from
-// the staged row above it -- the very operations the walking wave itself performs for that cell.
-template <int C>
+// One look-up pass: every lane with `valid` takes one listed cell of the group just walked.  Every K-th row of the
+// group is staged (rows 0, K, 2K, ..: row r at stage + (r / K) WS); a cell of a row in between is one to K - 1 steps
+// of the recurrence away from the staged row above it -- the very operations the walking wave itself performs for that
+// cell, on the K cells of the staged row it depends on (they lie in the cell's own lane and, at most, the lane to its
+// left: K <= C).
+template <int C, int K>
 __device__ __forceinline__ void gh_lookup(bool valid, unsigned pos, unsigned cnt, const double *stage, const int *se,
                                           const double2 *lt, double a, int mE0, int nrow0, int one_hi, long long &accK, double &accF) {
+  static_assert(K == 2 || (K == 4 && C == 4), "rows between two staged ones");
   constexpr int WS = 64 * C;
   if (valid) {
     const int cw = (int)(pos & 255u), r = (int)(pos >> 8) & 31;
-    const double *row = stage + (r >> 1) * WS;
-    const double A = row[cw];
-    const double Bq = row[cw - 1 < 0 ? 0 : cw - 1];
+    const int j = r & (K - 1);  // steps below the staged row
+    const double *row = stage + (r / K) * WS;
     const int ln = cw / C;
     const int e = se[ln];
-    // (the element to the left lives in the lane to the left, under that lane's exponent: the factor the walk uses)
+    // (what lives in the lane to the left is under that lane's exponent: the factor the walk uses)
     const int dl = (ln > 0 ? se[ln - 1] : e) - e;
-    const double sfac = ((cw & (C - 1)) == 0) ? ldexp(1.0, min(max(dl, -1100), 220)) : 1.0;
-    // coefficient of row n = nrow0 + r at column m = mE0 + cw: n - 1 - m a
-    const double coef = fma(-(double)(mE0 + cw), a, (double)(nrow0 + r - 1));
-    const double x = (r & 1) ? fma(coef, A, Bq * sfac) : A;
+    const double sfac = ldexp(1.0, min(max(dl, -1100), 220));
+    const int ci = cw & (C - 1);  // the cell's place in its lane
+    // coefficient n' - 1 - m' a of row n0 + 1 (n0: the staged row) at the cell's column m = mE0 + cw; a column to the
+    // left adds a, a row down adds 1
+    const double c10 = fma(-(double)(mE0 + cw), a, (double)(nrow0 + r - j));
+    double x;
+    if constexpr (K == 2) {
+      const double v0 = row[cw];
+      const double v1 = row[cw - 1 < 0 ? 0 : cw - 1] * (ci < 1 ? sfac : 1.0);
+      x = j ? fma(c10, v0, v1) : v0;
+    } else {
+      const double v0 = row[cw];
+      const double v1 = row[cw - 1 < 0 ? 0 : cw - 1] * (ci < 1 ? sfac : 1.0);
+      const double v2 = row[cw - 2 < 0 ? 0 : cw - 2] * (ci < 2 ? sfac : 1.0);
+      const double v3 = row[cw - 3 < 0 ? 0 : cw - 3] * (ci < 3 ? sfac : 1.0);
+      const double a2 = a + a;
+      const double w0 = fma(c10, v0, v1), w1 = fma(c10 + a, v1, v2), w2 = fma(c10 + a2, v2, v3);  // row n0 + 1: columns m, m - 1, m - 2
+      const double c20 = c10 + 1.0;
+      const double u0 = fma(c20, w0, w1), u1 = fma(c20 + a, w1, w2);                               // row n0 + 2: columns m, m - 1
+      const double t0 = fma(c20 + 1.0, u0, u1);                                                    // row n0 + 3
+      x = (j == 0) ? v0 : ((j == 1) ? w0 : ((j == 2) ? u0 : t0));
+    }
     const int hi = __double2hiint(x);
     const double2 t = lt[(hi >> 13) & 127];
     const double z = __hiloint2double(mantissa_of_one(hi, one_hi), __double2loint(x));
@@ -126,11 +150,12 @@ __device__ __forceinline__ void gh_lookup(bool valid, unsigned pos, unsigned cnt
   }
 }
 
-template <int C, int G>
+// K: every K-th row of a group is staged (2, or 4 with 4 columns per lane)
+template <int C, int G, int K>
 __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
   static_assert(C == 2 || C == 4, "columns per lane");
-  static_assert(G % 2 == 0 && G >= 2 && G <= 32, "rows per group");
-  constexpr int WS = 64 * C, SR = G / 2;  // doubles of a staged row, staged rows of a group
+  static_assert(G % K == 0 && G >= K && G <= 32, "rows per group");
+  constexpr int WS = 64 * C, SR = G / K;  // doubles of a staged row, staged rows of a group
   constexpr int MHL = GH_MAXR / C;
   constexpr int SL = GH_SL, SLH = SL / 2, FSL = GH_FSL;
   __shared__ double2 lt[128];
@@ -225,19 +250,21 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
     double *stage = gh_dyn + (size_t)w * (size_t)(SR * WS);
     int *se = &w_se[w][0];
     const int NQ = R / G;
-    // the strip's listed cells, group after group in (block, group of G rows) order: a word per lane, asked for a
-    // group ahead (the address needs no look-up)
-    const size_t item0 = (size_t)X.tile_off[jw + 1] * (size_t)NQ;  // items of tile (jw, b00)
-    const unsigned *dns = X.dense + (item0 + (size_t)(b0 - b00) * NQ) * 64 + lane;  // the next group's word
-    unsigned wcur = (b0 < bE) ? *dns : 0u;
-    dns += 64;
+    // the strip's listed cells, group after group in (block, group of G rows) order: NW words per lane, the first of
+    // them asked for a group ahead and the tile's entry a block ahead (no address depends on a load just made)
+    const unsigned tile0 = X.tile_off[jw + 1];  // tile (jw, b00)
+    const size_t item0 = (size_t)tile0 * (size_t)NQ;
+    unsigned ti = (b0 < bE) ? X.tinfo[tile0 + (unsigned)(b0 - b00)] : 0u;
+    ti = (unsigned)__builtin_amdgcn_readfirstlane((int)ti);
+    unsigned wcur = 0;
+    if ((ti & 63u) != 0 && (ti & 63u) != 63u) wcur = X.dense[(size_t)(ti >> 6) * 64 + lane];
     long long accK = 0;
     double accF = 0.0;
     // Everything is set up before the wave dozes until its first halo is about to arrive: a strip never makes up
     // for a late start, and a wave that spins takes issue slots from the walking wave it shares a SIMD with.
     while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
     if (w > 0)
-      while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
+      while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_s_setprio(3);
     if (dbg) dbg[0] = wall_clock64();
     for (int b = b0; b < bE; b++) {
@@ -300,21 +327,28 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
 #pragma unroll
       for (int i = 0; i < C; i++) coef[i] = (double)(1 + b * R) - (double)(m0 + i) * a;
       se[lane] = ep;
+      const unsigned nw = ti & 63u;
+      const unsigned *tw = X.dense + (size_t)(ti >> 6) * 64 + lane;  // this tile's words, this lane's
+      unsigned tin = (b + 1 < bE) ? X.tinfo[tile0 + (unsigned)(b + 1 - b00)] : 0u;  // the next tile's entry
       for (int q = 0; q < NQ; q++) {
         // (this group's list is looked at BEFORE the next one is asked for: the compiler waits for every load under
         // way where a loaded register is first read inside a loop, the one just issued included)
-        const bool listed = __ballot(wcur != 0) != 0;
+        const bool listed = (nw == 63u) || __ballot(wcur != 0) != 0;
         asm volatile("" ::: "memory");
-        // the next group's list is asked for now: it arrives while this group is walked
+        // the next group's first word is asked for now: it arrives while this group is walked
         unsigned wnext = 0;
-        if (q + 1 < NQ || b + 1 < bE) wnext = *dns;
-        dns += 64;
+        if (q + 1 < NQ) {
+          if (nw != 0 && nw != 63u) wnext = tw[(size_t)(q + 1) * nw * 64];
+        } else {
+          tin = (unsigned)__builtin_amdgcn_readfirstlane((int)tin);
+          if ((tin & 63u) != 0 && (tin & 63u) != 63u) wnext = X.dense[(size_t)(tin >> 6) * 64 + lane];
+        }
         if (listed && !(X.diag & 8)) {
 #pragma unroll
           for (int r = 0; r < G; r++) {
             gh_row<C>(v, coef, s);
-            if ((r & 1) == 0) {
-              double *dst = stage + (r >> 1) * WS + lane * C;
+            if ((r % K) == 0 && !GH_NOSTORE) {
+              double *dst = stage + (r / K) * WS + lane * C;
               if constexpr (C == 4) {
                 *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
                 *reinterpret_cast<gh_double2 *>(dst + 2) = gh_double2{v[2], v[3]};
@@ -324,10 +358,22 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
             }
           }
           const int nrow0 = 2 + b * R + q * G;  // the row the group's first step produces
-          if ((unsigned)__builtin_amdgcn_readlane((int)wcur, 63) != 0xffffffffu) {
-            if (!(X.diag & 4)) gh_lookup<C>(wcur != 0, wcur & 0x1fffu, wcur >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+          if (X.diag & 4) {
+          } else if (nw != 63u) {
+            // word after word, the next one asked for before this one is worked on; a group's words are filled from
+            // the front: the first empty one ends it
+            const unsigned *gw = tw + (size_t)q * nw * 64;
+            unsigned w = wcur;
+            for (unsigned k = 0; k < nw; k++) {
+              if (k > 0 && __ballot(w != 0) == 0) break;  // (looked at before the next load is issued: see above)
+              asm volatile("" ::: "memory");
+              unsigned wn = 0;
+              if (k + 1 < nw) wn = gw[(size_t)(k + 1) * 64];
+              gh_lookup<C, K>(w != 0, w & 0x1fffu, w >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+              w = wn;
+            }
           } else {
-            // (more than 63 listed cells in the group, or a count of 2^19 or more: rare; the lists in CSR form)
+            // (a count of 2^19 or more in the tile, or more words than the layout takes: the lists in CSR form)
             const size_t item = item0 + (size_t)(b - b00) * NQ + q;
             const unsigned e0 = X.item_ptr[item], e1 = X.item_ptr[item + 1];
             for (unsigned kk = e0; kk < e1; kk += 64) {
@@ -336,7 +382,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
                 pos = X.ent_pos[kk + lane];
                 cnt = X.ent_cnt[kk + lane];
               }
-              gh_lookup<C>(kk + lane < e1, pos, cnt, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+              gh_lookup<C, K>(kk + lane < e1, pos, cnt, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
             }
           }
         } else {
@@ -346,6 +392,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
         }
         wcur = wnext;
       }
+      ti = tin;
     }
     // the strip's two sums, over the wave in a fixed tree: the same bits on every run.  (The exponent sum is an
     // integer well below 2^53: exact in a double, whatever the order.)
@@ -491,7 +538,9 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
   {
     // (4 columns per lane, 64 discounts as above: groups of 8 rows 1.85, 12: 1.73, 16: 1.97)
     const bool two_per_cu = (int64_t)g.B * D > cus;
-    int Gd = (g.C == 2) ? 24 : ((g.P > 4 && two_per_cu) ? 8 : 12);
+    // (... with the dense lists: 12 rows 1.57, 16: 1.46, 24: 1.39)
+    int Gd = (g.C == 2) ? 24 : ((g.P > 4 && two_per_cu) ? 8 : 24);
+    g.K = (g.C == 4) ? (stb_env_int("STB_GRID_K", 4) == 2 ? 2 : 4) : 2;  // every K-th row of a group is staged
     Gd = stb_env_int("STB_GRID_G", Gd);
     while (Gd > 2 && (R % Gd != 0 || (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24))) Gd -= 2;
     if (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24) Gd = 8;
@@ -569,19 +618,19 @@ void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off) {
   off[0] = o;  // (the total, for whoever wants to check)
 }
 
-template <int C>
+template <int C, int K>
 static int gh_launch(const gh_args &X, int G, unsigned grid, int P, hipStream_t st) {
-  const size_t shm = (size_t)P * (size_t)(G / 2) * 64 * C * sizeof(double);
+  const size_t shm = (size_t)P * (size_t)(G / K) * 64 * C * sizeof(double);  // (every K-th row of a group is staged)
   size_t ask = shm;
   // While there are no more workgroups than compute units each should have a unit to itself (two walking waves on
   // one SIMD share its issue, and every strip moves at the pace of the slowest): ask for more than half of a unit's LDS.
   if ((int)grid <= stb_cu_count() && ask < 84 * 1024 && stb_env_int("STB_GRID_ALONE", 1)) ask = 84 * 1024;
   const dim3 block(64 * (P + 1));
   switch (G) {
-    case 8: STB_LAUNCH_SHM((k_grid_hb<C, 8>), dim3(grid), block, ask, st, X); break;
-    case 12: STB_LAUNCH_SHM((k_grid_hb<C, 12>), dim3(grid), block, ask, st, X); break;
-    case 16: STB_LAUNCH_SHM((k_grid_hb<C, 16>), dim3(grid), block, ask, st, X); break;
-    case 24: STB_LAUNCH_SHM((k_grid_hb<C, 24>), dim3(grid), block, ask, st, X); break;
+    case 8: STB_LAUNCH_SHM((k_grid_hb<C, 8, K>), dim3(grid), block, ask, st, X); break;
+    case 12: STB_LAUNCH_SHM((k_grid_hb<C, 12, K>), dim3(grid), block, ask, st, X); break;
+    case 16: STB_LAUNCH_SHM((k_grid_hb<C, 16, K>), dim3(grid), block, ask, st, X); break;
+    case 24: STB_LAUNCH_SHM((k_grid_hb<C, 24, K>), dim3(grid), block, ask, st, X); break;
     default: return stb_fail("stb_groups_aterms: no grid kernel for groups of %d rows", G);
   }
   return 0;
@@ -592,7 +641,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   grid_geom g;
   if (stb_grid_geometry(N, M, D, &g)) return stb_fail("stb_groups_aterms: the grid form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_groups_aterms: workspace too small for the grid form (%zu > %zu)", g.bytes, ws_left);
-  if (!dot || !dot->item_ptr || !dot->tile_off || !dot->dense || dot->col0 != 4)
+  if (!dot || !dot->item_ptr || !dot->tile_off || !dot->dense || !dot->tinfo || dot->col0 != 4)
     return stb_fail("stb_groups_aterms: the grid form sums over cell lists built for its strips");
   if (dot->geom_C != g.C || dot->geom_R != g.R || dot->geom_G != g.G)
     return stb_fail("stb_groups_aterms: cell lists built for %d columns a lane, blocks of %d rows, groups of %d; the walk is %d, %d, %d",
@@ -608,6 +657,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   X.state_v = (double *)(ws + g.off_state_v);
   X.tile_off = dot->tile_off;
   X.dense = dot->dense;
+  X.tinfo = dot->tinfo;
   X.item_ptr = dot->item_ptr;
   X.ent_pos = dot->ent_pos;
   X.ent_cnt = dot->ent_cnt;
@@ -646,7 +696,9 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
     X.JWa = jwa;
     X.ticket = X.hdr + 64 + 16 * ph;
     const unsigned grid = (unsigned)((jwa + g.P - 1) / g.P) * (unsigned)D;
-    if (g.C == 2 ? gh_launch<2>(X, g.G, grid, g.P, st) : gh_launch<4>(X, g.G, grid, g.P, st)) return 1;
+    const int rc = (g.C == 2) ? gh_launch<2, 2>(X, g.G, grid, g.P, st)
+                              : (g.K == 4 ? gh_launch<4, 4>(X, g.G, grid, g.P, st) : gh_launch<4, 2>(X, g.G, grid, g.P, st));
+    if (rc) return 1;
   }
   HIPCHK(hipGetLastError());
   if (X.dbg) {

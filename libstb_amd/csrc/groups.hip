@@ -3,6 +3,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <vector>
 
@@ -52,7 +53,8 @@ struct stb_groups {
   int lists_ready[STB_NLISTS];
   int list_R[STB_NLISTS], list_G[STB_NLISTS];  // [3], [4]: the block and group length the list was built for
   unsigned *d_tile_off[STB_NLISTS];            // [3], [4]: first tile of every strip (grid_hb.hip)
-  unsigned *d_dense[STB_NLISTS];               // [3], [4]: a word per lane and (tile, group): the list the walk reads
+  unsigned *d_dense[STB_NLISTS];               // [3], [4]: the listed cells as words per lane, group after group: what the walk reads
+  unsigned *d_tinfo[STB_NLISTS];               // [3], [4]: per tile, where its words start and how many a group has
   uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
   int reused;  // stb_groups_update_restaurants has been called: the same pairs serve call after call
@@ -136,7 +138,8 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                   g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
                   g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
                   g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
-                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4]};
+                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4],
+                  g->d_tinfo[3], g->d_tinfo[4]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -419,25 +422,43 @@ __global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigne
   }
 }
 
-// The grid form's dense layout: a word per lane and (tile, group) -- position | count << 13 of the lane's listed cell, 0
-// for none -- so that a group's list is ONE coalesced load at an address that needs no look-up (the walking wave asks
-// for it a group ahead).  A group with more than 63 cells, or a count of 2^19 or more, keeps only a marker in lane 63
-// and is taken from the CSR lists instead.
-#define STB_DENSE_MARK 0xffffffffu
-__global__ void k_dense_words(const unsigned *item_ptr, const unsigned short *pos, const unsigned *cnt, unsigned nitems, unsigned *dense) {
+// The grid form's dense layout.  A listed cell is one word, position | count << 13; a (tile, group of rows) holds its
+// cells in NW words per lane -- NW the same for the NQ groups of a tile: the most any of them needs -- at an address that
+// needs no look-up beyond the tile's own entry of `tinfo` (first word / 64 << 6 | NW), which the walking wave asks for a
+// block ahead: a group's cells are coalesced loads issued ahead of their use, whether it holds 20 cells or 2000 (the
+// pairs of a 10^4 x 10^4 table thin out like 1 / n: its first 4000 rows hold more than 63 cells per group of 12 x 208).
+// NW = 63 marks a tile taken from the CSR lists instead (a count of 2^19 or more, or more words than STB_DENSE_NWMAX).
+#define STB_DENSE_NWMAX 40
+#define STB_DENSE_CSR 63u
+__global__ void k_tile_words(const unsigned *item_ptr, const unsigned *cnt, unsigned n_tiles, unsigned NQ, unsigned *tnw, unsigned *twords) {
+  const unsigned t = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (t >= n_tiles) return;
+  const unsigned e0 = item_ptr[(size_t)t * NQ], e1 = item_ptr[(size_t)t * NQ + NQ];
+  unsigned nw = 0;
+  for (unsigned q = 0; q < NQ; q++) {
+    const unsigned c = item_ptr[(size_t)t * NQ + q + 1] - item_ptr[(size_t)t * NQ + q];
+    nw = max(nw, (c + 63) / 64);
+  }
+  bool big = false;
+  for (unsigned e = e0 + lane; e < e1; e += 64) big = big || cnt[e] >= (1u << 19);
+  if (__any(big) || nw > STB_DENSE_NWMAX) nw = STB_DENSE_CSR;
+  if (lane == 0) {
+    tnw[t] = nw;
+    twords[t] = (nw == STB_DENSE_CSR) ? 0u : nw * NQ;
+  }
+}
+
+__global__ void k_dense_fill(const unsigned *item_ptr, const unsigned short *pos, const unsigned *cnt, unsigned nitems, unsigned NQ,
+                             const unsigned *tnw, const unsigned *toff, unsigned *dense, unsigned *tinfo) {
   const unsigned i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
   if (i >= nitems) return;
-  const unsigned b0 = item_ptr[i], b1 = item_ptr[i + 1], n = b1 - b0;
-  bool big = n > 63;
-  unsigned w = 0;
-  if (!big && lane < n) {
-    const unsigned c = cnt[b0 + lane];
-    if (c >= (1u << 19)) big = true;
-    w = (unsigned)pos[b0 + lane] | (c << 13);
-  }
-  big = __any(big);
-  if (big) w = (lane == 63) ? STB_DENSE_MARK : 0u;
-  dense[(size_t)i * 64 + lane] = w;
+  const unsigned t = i / NQ, q = i - t * NQ;
+  const unsigned nw = tnw[t];
+  if (q == 0 && lane == 0) tinfo[t] = (toff[t] << 6) | nw;
+  if (nw == STB_DENSE_CSR) return;
+  const unsigned e0 = item_ptr[i], e1 = item_ptr[i + 1];
+  unsigned *dst = dense + ((size_t)toff[t] + (size_t)q * nw) * 64;
+  for (unsigned k = lane; k < nw * 64; k += 64) dst[k] = (e0 + k < e1) ? ((unsigned)pos[e0 + k] | (cnt[e0 + k] << 13)) : 0u;
 }
 
 // item_ptr[i] = first run whose item index is >= i
@@ -483,7 +504,9 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       stb_pool_free(g->d_ent_cnt[which]);
       stb_pool_free(g->d_tile_off[which]);
       stb_pool_free(g->d_dense[which]);
+      stb_pool_free(g->d_tinfo[which]);
       g->d_dense[which] = nullptr;
+      g->d_tinfo[which] = nullptr;
       g->d_item_ptr[which] = nullptr;
       g->d_ent_pos[which] = nullptr;
       g->d_ent_cnt[which] = nullptr;
@@ -588,13 +611,41 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
     if (which >= 3) {
-      if (stb_pool_malloc((void **)&g->d_dense[which], 4 * 64 * (size_t)(nitems ? nitems : 1)) != hipSuccess) {
-        stb_fail("stb_groups_aterms: out of device memory");
+      // the dense layout the walk reads: words per tile, their prefix sum, the words
+      const unsigned n_tiles = H.n_tiles, NQ = (unsigned)H.NQ;
+      unsigned *tnw = nullptr, *twords = nullptr, *toff = nullptr;
+      void *tmp2 = nullptr;
+      size_t b3 = 0;
+      bool ok = stb_pool_malloc((void **)&tnw, 4 * (size_t)(n_tiles + 1)) == hipSuccess &&
+                stb_pool_malloc((void **)&twords, 4 * (size_t)(n_tiles + 1)) == hipSuccess &&
+                stb_pool_malloc((void **)&toff, 4 * (size_t)(n_tiles + 1)) == hipSuccess &&
+                stb_pool_malloc((void **)&g->d_tinfo[which], 4 * (size_t)(n_tiles + 1)) == hipSuccess;
+      unsigned h_last[2] = {0, 0};
+      if (ok && n_tiles) {
+        hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ,
+                           tnw, twords);
+        ok = rocprim::exclusive_scan(nullptr, b3, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st) == hipSuccess &&
+             stb_pool_malloc(&tmp2, b3 ? b3 : 1) == hipSuccess &&
+             rocprim::exclusive_scan(tmp2, b3, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st) == hipSuccess &&
+             hipMemcpyAsync(&h_last[0], toff + (n_tiles - 1), 4, hipMemcpyDeviceToHost, g->st) == hipSuccess &&
+             hipMemcpyAsync(&h_last[1], twords + (n_tiles - 1), 4, hipMemcpyDeviceToHost, g->st) == hipSuccess &&
+             hipStreamSynchronize(g->st) == hipSuccess;
+      }
+      const size_t words = (size_t)h_last[0] + h_last[1];  // in units of 64 dwords
+      ok = ok && words < (1u << 26);                       // (a tile's first word / 64 goes into 26 bits of its entry)
+      ok = ok && stb_pool_malloc((void **)&g->d_dense[which], 256 * (words ? words : 1)) == hipSuccess;
+      if (ok && nitems)
+        hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which],
+                           g->d_ent_cnt[which], nitems, NQ, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
+      if (ok) ok = hipStreamSynchronize(g->st) == hipSuccess;
+      stb_pool_free(tnw);
+      stb_pool_free(twords);
+      stb_pool_free(toff);
+      stb_pool_free(tmp2);
+      if (!ok) {
+        stb_fail("stb_groups_aterms: out of device memory (or a dense list beyond 2^32 bytes)");
         break;
       }
-      if (nitems)
-        hipLaunchKernelGGL(k_dense_words, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which],
-                           g->d_ent_cnt[which], nitems, g->d_dense[which]);
     }
     if (!g->d_dotp) {
       // partial sums: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
@@ -726,6 +777,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
     req.geom_G = g->list_G[which];
     req.tile_off = g->d_tile_off[which];
     req.dense = g->d_dense[which];
+    req.tinfo = g->d_tinfo[which];
   }
   req.dotp = g->d_dotp;
   req.ws_zero = g->ws_zero;

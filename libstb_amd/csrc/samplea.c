@@ -67,9 +67,12 @@ static _Thread_local struct { /* (one per calling thread: samplers of different 
   unsigned N, M;
 } kept;
 
+void stb_sampleb_cache_clear(void); /* sampleb.c */
+
 void stb_sampler_cache_clear(void) {
   if (kept.dev) stb_groups_free(kept.dev);
   memset(&kept, 0, sizeof(kept));
+  stb_sampleb_cache_clear();
 }
 
 static uint64_t mix64(uint64_t h, uint64_t v) {
@@ -97,6 +100,20 @@ static uint64_t hash_bytes(uint64_t h, const void *p, size_t bytes) {
   return mix64(mix64(mix64(mix64(h, lanes[0]), lanes[1]), lanes[2]), lanes[3] ^ bytes);
 }
 
+/* largest entry of an array (0 for an empty one); loops the compiler turns into vector code */
+__attribute__((optimize("O3"))) static unsigned max_u32(const scnt_int *p, size_t n) {
+  unsigned m = 0;
+  size_t i;
+  for (i = 0; i < n; i++) m = p[i] > m ? p[i] : m;
+  return m;
+}
+__attribute__((optimize("O3"))) static unsigned max_u16(const stcnt_int *p, size_t n) {
+  unsigned m = 0;
+  size_t i;
+  for (i = 0; i < n; i++) m = p[i] > m ? p[i] : m;
+  return m;
+}
+
 /* environment switch for the sampler family, so both can be exercised from one build:
  * STB_SAMPLER=slice selects SliceSimple, anything else the compile-time default */
 static int use_slice(void) {
@@ -117,6 +134,7 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
   stcnt_int *tflat;
   size_t G = 0, g = 0;
   unsigned N, M;
+  uint64_t pairs_hash = 0;
   int i, k;
 
   /* lib/samplea.c:161-177: start point nudged off the ends, move limited to +-SQUEEZEA */
@@ -128,29 +146,41 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
   if (inita[1] + SQUEEZEA < A_MAX) inita[2] = inita[1] + SQUEEZEA;
 #endif
 
-  /* flatten the pairs and find the bounds: maxn = max n + 1, maxt = max t + 1, both at least 1
-   * (lib/samplea.c:184-208) */
+  /* the bounds: maxn = max n + 1, maxt = max t + 1, both at least 1 (lib/samplea.c:184-208), and a hash of the
+   * pairs, in ONE pass over the caller's arrays; they are flattened (copied) only when the device does not hold
+   * them already -- a Gibbs sampler resamples a over counts that change slowly or not at all, and the copy costs as
+   * much as three posterior evaluations */
   for (i = 0; i < I; i++) G += (size_t)(K[i] > 0 ? K[i] : 0);
-  nflat = malloc(sizeof(*nflat) * (G ? G : 1));
-  tflat = malloc(sizeof(*tflat) * (G ? G : 1));
-  if (!nflat || !tflat) {
-    fprintf(stderr, "Out of memory for S table\n");
-    exit(1);
-  }
+  nflat = NULL;
+  tflat = NULL;
   ap.maxt = 1;
   ap.maxn = 1;
   ap.verbose = verbose;
-  for (i = 0; i < I; i++)
-    for (k = 0; k < K[i]; k++, g++) {
-      if (getval)
-        getval(&nflat[g], &tflat[g], i, k);
-      else {
-        nflat[g] = n[i][k];
-        tflat[g] = t[i][k];
-      }
-      if ((int)tflat[g] >= ap.maxt) ap.maxt = tflat[g] + 1;
-      if (nflat[g] >= (scnt_int)ap.maxn) ap.maxn = nflat[g] + 1;
+  if (getval) { /* (a callback has to be asked pair by pair: flattened first, then as arrays) */
+    nflat = malloc(sizeof(*nflat) * (G ? G : 1));
+    tflat = malloc(sizeof(*tflat) * (G ? G : 1));
+    if (!nflat || !tflat) {
+      fprintf(stderr, "Out of memory for S table\n");
+      exit(1);
     }
+    for (i = 0; i < I; i++)
+      for (k = 0; k < K[i]; k++, g++) getval(&nflat[g], &tflat[g], i, k);
+  }
+  {
+    uint64_t hh = hash_bytes(0x5eedull, K, sizeof(int) * (size_t)(I > 0 ? I : 0));
+    size_t off = 0;
+    for (i = 0; i < I; i++) {
+      const size_t Ki = (size_t)(K[i] > 0 ? K[i] : 0);
+      const scnt_int *ni = getval ? nflat + off : n[i];
+      const stcnt_int *ti = getval ? tflat + off : t[i];
+      const unsigned mn = max_u32(ni, Ki), mt = max_u16(ti, Ki);
+      if ((int)mt >= ap.maxt) ap.maxt = (int)mt + 1;
+      if (Ki && mn >= (unsigned)ap.maxn) ap.maxn = (int)mn + 1;
+      hh = mix64(hash_bytes(hh, ni, sizeof(*ni) * Ki), hash_bytes(hh, ti, sizeof(*ti) * Ki));
+      off += Ki;
+    }
+    pairs_hash = hh;
+  }
   /* the table aterms builds is S_make(maxn,maxt,maxn,maxt) (lib/samplea.c:60) after S_make's
    * clamps (lib/stable.c:118-129): M = max(maxt,10), N = max(maxn,M) */
   M = ap.maxt < 10 ? 10u : (unsigned)ap.maxt;
@@ -158,12 +188,7 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
   {
     const char *ce = getenv("STB_SAMPLEA_CACHE");
     const int keep = !(ce && strcmp(ce, "0") == 0);
-    uint64_t h = 0;
-    if (keep) {
-      h = hash_bytes(0x5eedull, K, sizeof(int) * (size_t)(I > 0 ? I : 0));
-      h = hash_bytes(h, nflat, sizeof(*nflat) * G);
-      h = hash_bytes(h, tflat, sizeof(*tflat) * G);
-    }
+    const uint64_t h = pairs_hash;
     ap.reused = 0;
     if (keep && kept.dev && kept.hash == h && kept.I == I && kept.G == G && kept.N == N && kept.M == M) {
       ap.dev = kept.dev;
@@ -176,7 +201,24 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
       stb_sampler_cache_clear();
       ap.dev = NULL;
     }
-    if (!ap.dev) ap.dev = stb_groups_create(I, K, T, nflat, tflat, bpar, N, M, NPRE);
+    if (!ap.dev) {
+      if (!getval) { /* not on the device yet: now the pairs are copied, restaurant after restaurant */
+        size_t off = 0;
+        nflat = malloc(sizeof(*nflat) * (G ? G : 1));
+        tflat = malloc(sizeof(*tflat) * (G ? G : 1));
+        if (!nflat || !tflat) {
+          fprintf(stderr, "Out of memory for S table\n");
+          exit(1);
+        }
+        for (i = 0; i < I; i++) {
+          const size_t Ki = (size_t)(K[i] > 0 ? K[i] : 0);
+          memcpy(nflat + off, n[i], sizeof(*nflat) * Ki);
+          memcpy(tflat + off, t[i], sizeof(*tflat) * Ki);
+          off += Ki;
+        }
+      }
+      ap.dev = stb_groups_create(I, K, T, nflat, tflat, bpar, N, M, NPRE);
+    }
     if (ap.dev && keep) {
       kept.dev = ap.dev;
       kept.hash = h;

@@ -46,6 +46,13 @@ static double bterms(double x, void *vp) {
   return val;
 }
 
+static _Thread_local stb_bctx_t *kept_b; /* one per calling thread, like samplea's kept pairs */
+
+void stb_sampleb_cache_clear(void) {
+  if (kept_b) stb_bterms_free(kept_b);
+  kept_b = NULL;
+}
+
 static int use_slice(void) {
   const char *s = getenv("STB_SAMPLER");
 #ifdef PSAMPLE_ARS
@@ -100,7 +107,14 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
     bp.apar = apar;
     bp.shape = shape;
     bp.npre = 0;
-    bp.dev = stb_bterms_create(T, I);
+    /* the device context of the previous call on this thread, when it is large enough: T[] is copied anew (it changes
+     * from call to call), the stream, the pinned result buffer and the device memory are kept */
+    if (kept_b && stb_bterms_update(kept_b, T, I) == 0)
+      bp.dev = kept_b;
+    else {
+      if (kept_b) stb_bterms_free(kept_b);
+      kept_b = bp.dev = stb_bterms_create(T, I);
+    }
     if (!bp.dev) {
       fprintf(stderr, "sampleb(): no device memory for T[] (%s)\n", stb_last_error());
       exit(1);
@@ -143,7 +157,7 @@ double sampleb(double b_in, int I, double shape, double scale, scnt_int *N, scnt
         exit(1);
       }
     }
-    stb_bterms_free(bp.dev);
+    /* (bp.dev stays: kept_b; stb_sampler_cache_clear drops it) */
     if (verbose > 1) fprintf(stderr, "Sample b ~ G(%lg) = %lf\n", Q, myb);
   }
   return myb;

@@ -134,7 +134,8 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
                                            //         4: k_fill_hb's strips (the spine sums), lists built for geom_*
   int geom_C = 0, geom_R = 0, geom_G = 0;  //         col0 = 4: columns per lane, rows per block, rows per group of the lists
   const unsigned *tile_off = nullptr;      //         col0 = 4: first tile of every strip (device, stb_grid_tile_offsets)
-  const unsigned *dense = nullptr;         //         col0 = 4: a word per lane and (tile, group): position | count << 13
+  const unsigned *dense = nullptr;         //         col0 = 4: the listed cells as words per lane (position | count << 13), group after group
+  const unsigned *tinfo = nullptr;         //         col0 = 4: per tile, first word / 64 << 6 | words per group (63: the CSR lists)
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
   size_t ws_zero = 0;                      // in: bytes at the start of the workspace the caller knows to be zero (no memset then)
@@ -178,6 +179,7 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out);
 struct grid_geom {
   int C, P, B, JW, NB, R, HL, U;  // columns per lane, strips per workgroup, workgroups per table, strips, blocks, rows per block, halo / own lanes
   int G, NQ, phases;              // rows per group, groups per block, launches
+  int K;                          // every K-th row of a group is staged in LDS
   unsigned n_tiles;               // (strip, block) pairs of a table
   size_t off_cke, off_ckv, off_state_e, off_state_v, zero_bytes, bytes;
   int ok;

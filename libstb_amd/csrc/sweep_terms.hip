@@ -309,7 +309,7 @@ int stb_restaurant_partials(const double *x_host, int D, const uint32_t *d_T, co
 // ---- bterms for sampleb: T[] resident, an evaluation = two launches and one wait ----
 struct stb_bctx {
   int dev;
-  uint64_t I;
+  uint64_t I, cap;  // restaurants now, and at most
   uint32_t *d_T;
   double *d_out, *h_out, *h_out_dev;
   void *d_ws;
@@ -321,12 +321,11 @@ extern "C" void stb_bterms_free(stb_bctx_t *c) {
   STB_ENTRY;
   if (!c) return;
   const int prev = stb_device_enter(c->dev);
-  if (c->st) (void)hipStreamSynchronize(c->st);
+  (void)hipStreamSynchronize(c->st);
   stb_pool_free(c->d_T);
   stb_pool_free(c->d_out);
   stb_pool_free(c->d_ws);
   stb_pool_free(c->h_out);
-  if (c->st) (void)hipStreamDestroy(c->st);
   stb_device_leave(prev);
   free(c);
 }
@@ -342,8 +341,11 @@ extern "C" stb_bctx_t *stb_bterms_create(const uint32_t *T, int I) {
   const int prev = stb_device_enter(stb_get_device());
   bool ok = hipGetDevice(&c->dev) == hipSuccess;
   c->I = (uint64_t)(I > 0 ? I : 0);
+  c->cap = c->I;
   c->ws_bytes = stb_terms_workspace_bytes(c->I, STB_TERMS_DMAX);
-  ok = ok && hipStreamCreate(&c->st) == hipSuccess;
+  // (the null stream, as the reference-shaped host samplers always used here: making a stream costs milliseconds, a
+  // sampleb call a fraction of one)
+  c->st = nullptr;
   ok = ok && stb_pool_malloc((void **)&c->d_T, sizeof(uint32_t) * (c->I ? c->I : 1)) == hipSuccess;
   ok = ok && stb_pool_malloc((void **)&c->d_out, sizeof(double) * STB_TERMS_DMAX) == hipSuccess;
   ok = ok && stb_pool_malloc(&c->d_ws, c->ws_bytes) == hipSuccess;
@@ -360,6 +362,22 @@ extern "C" stb_bctx_t *stb_bterms_create(const uint32_t *T, int I) {
   }
   stb_device_leave(prev);
   return c;
+}
+
+// new totals for a context made for at least as many restaurants (a sampler keeps one context from call to call: a
+// stream, pinned memory and device buffers cost more to make than twenty evaluations take); non-zero when I does not fit
+extern "C" int stb_bterms_update(stb_bctx_t *c, const uint32_t *T, int I) {
+  STB_ENTRY;
+  if (!c) return stb_fail("stb_bterms_update: null context");
+  if (I < 0 || (uint64_t)I > c->cap) return 1;
+  const int prev = stb_device_enter(c->dev);
+  int rc = 0;
+  c->I = (uint64_t)I;
+  if (I > 0 && (hipMemcpyAsync(c->d_T, T, sizeof(uint32_t) * (size_t)I, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+                hipStreamSynchronize(c->st) != hipSuccess))
+    rc = stb_fail("stb_bterms_update: %s", hipGetErrorString(hipGetLastError()));
+  stb_device_leave(prev);
+  return rc;
 }
 
 // out_host[j] = bterms(x_j) (lib/sampleb.c:33-41), j < J <= 64; blocks until the values are there
