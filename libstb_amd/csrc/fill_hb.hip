@@ -48,7 +48,10 @@
 #define HB_MAXHL 32      // halo lanes at most
 #define HB_EOFF32 (1u << 30)
 #define HB_WRITTEN 0x8000000000000000ull  // a record's significands (never negative) travel with the sign bit set
-#define HB_DOT_NQ 12       // groups of 4 rows in a block at most (summing form)
+#define HB_DOT_GR 8        // rows of a group of the summing form: its listed cells are looked up together, one per lane and pass
+                           // (4 rows: 12 passes a tile, each with its LDS round trips exposed -- a worker wave has one
+                           // partner on its SIMD -- and a quarter of the lanes at work; 8 rows: 6 fuller passes)
+#define HB_DOT_NQ 6        // groups in a block at most (48 rows)
 #define HB_MAXCNT 64        // ticket counters at most
 #define HB_CNT0 64          // word of the header the ticket counters start at (one per 32 words)
 #define HB_HDR_BYTES (256 + HB_MAXCNT * 128)
@@ -96,7 +99,7 @@ struct hb_args {
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
   int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
-  // per item = (record index of the tile) * HB_DOT_NQ + (group of 4 rows of the block), and where the sums go
+  // per item = (record index of the tile) * HB_DOT_NQ + (group of HB_DOT_GR rows of the block), and where the sums go
   const unsigned *item_ptr;        // [n_rec * HB_DOT_NQ + 1] first entry of every item
   const unsigned short *ent_pos;   // row-in-group << 8 | element of the wave (halo included) of each occurring cell
   const unsigned *ent_cnt;         // its occurrence count
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       unsigned short pp[DOT ? HB_DOT_NQ : 1];
       unsigned cc[DOT ? HB_DOT_NQ : 1];
       if constexpr (DOT != 0) {
-        const int NQ = R / 4;
+        const int NQ = R / HB_DOT_GR;
         const unsigned tix = (unsigned)(recO - tab_rec);
         if (lane <= NQ) ip = X.item_ptr[(size_t)tix * HB_DOT_NQ + lane];
         const unsigned ipn = (unsigned)__shfl_down((int)ip, 1);
@@ -681,9 +684,11 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         if (lane == 0) z1 = ldexp(1.0, min(max(e63 - ep[1], -1100), 220));
       }
       if constexpr (DOT != 0) {
-        // ---- the tile as a sum: no logs but those of the cells that occur, nothing stored.  Four rows at a
-        // time go to LDS (this wave's own area), then every lane looks one occurring cell up; the first 64
-        // cells of every group's list were asked for when the tile was taken. ----
+        // ---- the tile as a sum: no logs but those of the cells that occur, nothing stored.  Of every group of eight
+        // rows every other one goes to LDS (this wave's own area; eight waves staging every row keep a compute unit's
+        // LDS store path busy twice as long as its SIMDs take to walk), then every lane looks one occurring cell up
+        // -- a cell of a row in between is one step of the recurrence away from the staged row above it; the
+        // first 64 cells of every group's list were asked for when the tile was taken. ----
         constexpr int WS = 64 * C;
         double *stage = hb_dyn + (size_t)wave * (4 * WS);
         int *se = &w_se[DOT ? wave : 0][0];
@@ -707,21 +712,21 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           if (q < qe) {
             const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)ip, q), b1 = (unsigned)__builtin_amdgcn_readlane((int)ip, q + 1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < HB_DOT_GR; u++) {
               const double t0 = wave_shr1_zero(v[0][C - 1]) * s[0];
 #pragma unroll
               for (int i = C - 1; i >= 1; i--) v[0][i] = fma(coef[0][i], v[0][i], v[0][i - 1]);
               v[0][0] = fma(coef[0][0], v[0][0], t0);
 #pragma unroll
               for (int i = 0; i < C; i++) coef[0][i] += 1.0;
-              if (b0 != b1 && !(HB_DIAG & 32)) {  // (a group none of whose cells occurs is only walked)
+              if ((u & 1) == 0 && b0 != b1 && !(HB_DIAG & 32)) {  // (a group none of whose cells occurs is only walked)
                 if constexpr (C == 4) {
-                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4) = hb_double2{v[0][0], v[0][1]};
-                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 4 + 2) = hb_double2{v[0][2], v[0][3]};
+                  *reinterpret_cast<hb_double2 *>(stage + (u >> 1) * WS + lane * 4) = hb_double2{v[0][0], v[0][1]};
+                  *reinterpret_cast<hb_double2 *>(stage + (u >> 1) * WS + lane * 4 + 2) = hb_double2{v[0][2], v[0][3]};
                 } else if constexpr (C == 2) {
-                  *reinterpret_cast<hb_double2 *>(stage + u * WS + lane * 2) = hb_double2{v[0][0], v[0][1]};
+                  *reinterpret_cast<hb_double2 *>(stage + (u >> 1) * WS + lane * 2) = hb_double2{v[0][0], v[0][1]};
                 } else {
-                  stage[u * WS + lane] = v[0][0];
+                  stage[(u >> 1) * WS + lane] = v[0][0];
                 }
               }
             }
@@ -729,8 +734,18 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
               unsigned kk = b0 + lane, pos = pp[q], cnt = cc[q];
               for (;;) {
                 if (kk < b1) {
-                  const int cw = (int)(pos & 255u);
-                  const double val = bfp_log(stage[(pos >> 8) * WS + cw], se[cw / C], lt);
+                  const int cw = (int)(pos & 255u), r = (int)(pos >> 8);
+                  const double *row = stage + (r >> 1) * WS;
+                  const int ln = cw / C;
+                  const int e = se[ln];
+                  double x = row[cw];
+                  // (rows 1 and 3 of the group: n - 1 - m a times the cell above, plus the cell above and to the left
+                  // -- under the left lane's exponent where that is another lane: the walk's own operations)
+                  const int dl = (ln > 0 ? se[ln - 1] : e) - e;
+                  const double xl = row[cw - 1 < 0 ? 0 : cw - 1] * (((cw & (C - 1)) == 0) ? ldexp(1.0, min(max(dl, -1100), 220)) : 1.0);
+                  const double c1 = fma(-(double)(mE0 + cw), a, (double)(1 + b * R + q * HB_DOT_GR + r));
+                  if (r & 1) x = fma(c1, x, xl);
+                  const double val = bfp_log(x, e, lt);
                   acc += (double)cnt * val;
                 }
                 if (kk - lane + 64 >= b1) break;  // (wave-uniform)
@@ -1100,7 +1115,7 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
 // records start (device array of JW + 2 words; a tile's record index is its item base)
 int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
   const hb_geom g = hb_geometry(N, M, D, true);
-  if (!g.ok || g.R / 4 > HB_DOT_NQ) return 1;
+  if (!g.ok || g.R % HB_DOT_GR != 0 || g.R / HB_DOT_GR > HB_DOT_NQ) return 1;
   const unsigned *rec_off = nullptr, *order = nullptr;
   if (hb_order_list(g, N, M, &rec_off, &order)) return 1;
   out->R = g.R;
@@ -1109,7 +1124,7 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
   out->NB = g.NB;
   out->JW = g.JW;
   out->NQ = HB_DOT_NQ;
-  out->G = 4;
+  out->G = HB_DOT_GR;
   out->C = g.C;
   out->n_tiles = g.n_tiles;
   out->n_rec = g.n_rec;
@@ -1126,7 +1141,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
   if (dot && (!dot->item_ptr || dot->col0 != 3))
     return stb_fail("stb_fill_S: the halo-block form sums over cell lists built for its tiles");
-  if (dot && g.R / 4 > HB_DOT_NQ) return stb_fail("stb_fill_S: blocks of %d rows are too long for the summing form", g.R);
+  if (dot && (g.R % HB_DOT_GR != 0 || g.R / HB_DOT_GR > HB_DOT_NQ)) return stb_fail("stb_fill_S: blocks of %d rows do not suit the summing form", g.R);
   hb_args X;
   memset(&X, 0, sizeof(X));
   X.hdr = (unsigned *)ws;

@@ -328,8 +328,8 @@ __global__ void k_item_keys(const uint32_t *n, const uint16_t *t, uint64_t G, un
   payload[g] = (uint32_t)g;
 }
 
-// the same for the tiles of k_fill_hb: key = (item << 10) | (row in group << 8) | element of the wave (halo included),
-// item = (record index of tile (strip, block)) * NQ + group of 4 rows; row n belongs to block (n - 2) / R
+// the same for the tiles of k_fill_hb: key = (item << 11) | (row in group << 8) | element of the wave (halo included),
+// item = (record index of tile (strip, block)) * NQ + group of H.G rows; row n belongs to block (n - 2) / R
 __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, hb_dot_info H,
                                uint64_t *key, uint32_t *payload) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,7 +350,8 @@ __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G,
     const unsigned b = (nn - 2) / (unsigned)H.R, r = (nn - 2) - b * (unsigned)H.R;
     const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
     const unsigned rec = H.rec_off[j + 1] + (b - b0);  // (b >= b0: the cell lies on or below the diagonal)
-    k = ((((uint64_t)rec * (unsigned)H.NQ) + (r >> 2)) << 10) | ((uint64_t)(r & 3u) << 8) | cw;
+    const unsigned q = r / (unsigned)H.G;
+    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << 11) | ((uint64_t)(r - q * (unsigned)H.G) << 8) | cw;
   }
   key[g] = k;
   payload[g] = (uint32_t)g;
@@ -606,7 +607,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     }
     if (h_runs) {
       hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item,
-                         which >= 3 ? 13 : (which == 2 ? 10 : 9));
+                         which >= 3 ? 13 : (which == 2 ? 11 : 9));
       if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
