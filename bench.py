@@ -44,7 +44,10 @@ import torch
 from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-TRAFFIC_DB = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+TRAFFIC_DB = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (4, 3)) if os.path.exists(p)),
+                  os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
+N_SIMD = 1024           # 256 compute units x 4 SIMDs (MI355X)
+NOMINAL_CLOCK_HZ = 2.4e9
 FORM_NAMES = {2: "pc", 3: "chain", 4: "ck", 6: "hb"}
 
 
@@ -164,6 +167,40 @@ def traffic_lookup(key: str, kernel_prefix: str):
         if kname.startswith(kernel_prefix):
             return rec["hbm_bytes_per_launch"], f"profiles/{os.path.basename(TRAFFIC_DB)}[{key}][{kname}]"
     return None, None
+
+
+def valu_busy(workload: str, kernel_prefix: str):
+    """fraction of the chip's vector-issue slots a kernel uses (SURVEY 8d asks for it beside the HBM fraction), from the
+    COMMITTED profiles of the same workload: SQ_INSTS_VALU wave-instructions (profiles/r04_sq_counters_<workload>.txt)
+    x 4 cycles / (1024 SIMDs x the kernel's average duration (profiles/r04_<workload>_kernel_stats.csv) x 2.4 GHz);
+    also SALU per VALU instruction and the share of LDS cycles lost to bank conflicts"""
+    import csv
+    cpath = os.path.join(ROOT, "profiles", f"r04_sq_counters_{workload}.txt")
+    spath = os.path.join(ROOT, "profiles", f"r04_{workload}_kernel_stats.csv")
+    if not (os.path.exists(cpath) and os.path.exists(spath)):
+        return None
+    vals, on = {}, False
+    for line in open(cpath):
+        if not line.startswith(" "):
+            on = kernel_prefix in line
+            continue
+        if on:
+            parts = line.split()
+            vals.setdefault(parts[0], float(parts[1]))
+    dur_ns = None
+    for r in csv.DictReader(open(spath)):
+        if kernel_prefix in r["Name"]:
+            dur_ns = float(r["AverageNs"])
+            break
+    if not vals.get("SQ_INSTS_VALU") or not dur_ns:
+        return None
+    out = {"valu_busy_frac": vals["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * dur_ns * 1e-9 * NOMINAL_CLOCK_HZ),
+           "valu_busy_source": f"profiles/r04_sq_counters_{workload}.txt, profiles/r04_{workload}_kernel_stats.csv ({kernel_prefix}, {dur_ns / 1e3:.1f} us)"}
+    if vals.get("SQ_INSTS_SALU"):
+        out["salu_per_valu"] = vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"]
+    if vals.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_frac"] = vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / vals["SQ_LDS_IDX_ACTIVE"]
+    return out
 
 
 def groups_handle(L, g, N, M, Dmax):
@@ -527,9 +564,14 @@ def main():
                 "avg_launch_us": avg_launch_ms * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_per_step": kms.value / args.steps,
-                "note": "one table per GPU is bound by the N serial row steps of the recurrence (10^4 rows x 25 ns in k_fill_hb) plus the hand-overs between the spine's workgroups, not by HBM; see DESIGN.md",
+                "note": f"one table per GPU is bound by the N serial row steps of the recurrence -- this run: {N} rows x "
+                        f"{avg_launch_ms * 1e6 / max(N, 1):.1f} ns of kernel time per row (the spine's walk + the hand-overs between its "
+                        "workgroups + the last tiles) -- not by HBM; see DESIGN.md",
             },
         }
+        vb = valu_busy("fill1" if Dl == 1 else "fill8", "k_fill_hb") if fname == "hb" else None
+        if vb:
+            out["roofline"].update(vb)
         extra = {}
         if batch64 is not None:
             out["scale_job"] = batch64
@@ -542,17 +584,21 @@ def main():
                 fu = s10k["D64"]["fused"]
                 alg = fu["grid_evals"] * (8 + 6.0 / 64)
                 dev_ms = fu["fill_ms"] + fu["sweep_ms"] + fu["terms_ms"]
-                tr, tr_src = traffic_lookup("grid_N10000_D64", "k_fill_chain")
+                tr, tr_src = traffic_lookup("grid_N10000_D64", "k_grid_hb")
+                vbg = valu_busy("grid64", "k_grid_hb")
                 out["roofline_sweep"] = {
                     "metric": "sampler grid-evals/s", "bound": "hbm",
-                    "kernel": "k_fill_chain<...,DOT>: the chain fill of 64 discounts at N=M=10000 summing count * log S over the "
-                              "occurring cells itself (no table stored), + the restaurant terms; what stb_groups_aterms runs for D >= 2",
+                    "kernel": "k_grid_hb<4,24,4>: the table walk of 64 discounts at N=M=10000 whose walking waves sum count * log S over "
+                              "their own strips' listed cells (no table stored, no tile workers, every 4th row staged in LDS), + the "
+                              "restaurant terms; what stb_groups_aterms runs for a grid beyond the tile-worker form's range",
                     "grid_evals": fu["grid_evals"], "device_ms": dev_ms, "fill_ms": fu["fill_ms"],
                     "value": fu["grid_evals"] / (dev_ms * 1e-3), "unit": "grid-evals/s",
                     "algorithmic_bytes": alg, "achieved": alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "frac": alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
-                    "note": "not an HBM-bound kernel: its time is the recurrence's serial row chain (N rows x row time + one hand-off "
-                            "per column strip) and its traffic the edge streams and the cell lists, not the tables; see DESIGN.md",
+                    "note": "not an HBM-bound kernel (its traffic is the cell lists and the records between workgroups, not tables): at 64 "
+                            "discounts it is bound by vector instruction issue -- 3.1 walking waves per SIMD, every table's strips in "
+                            "lockstep, the look-ups' recompute -- see valu_busy_frac and DESIGN.md",
+                    **(vbg or {}),
                     "end_to_end": {"fused_grid_evals_per_s": fu["grid_evals_per_s_end_to_end"], "fused_wall_ms": fu["wall_ms"],
                                    "two_pass_grid_evals_per_s": tp["grid_evals_per_s_end_to_end"], "two_pass_wall_ms": tp["wall_ms"]},
                 }

@@ -162,7 +162,7 @@ static bool ck_wins(unsigned N, unsigned M, int D) {
 
 // The halo-block form (a spine that walks blocks of rows alone behind a halo + tile workers) is the fast one
 // wherever the ROW CHAIN, not the chip's throughput, decides.  Chosen for tables of >= 512 rows while the batch's
-// spine workgroups leave the tile workers room (200 at most: 24 tables of 10^4 columns, 64 of 4000) and the batch
+// spine workgroups leave the tile workers room (25/32 of the compute units at most, 200 of an MI355X's 256: 24 tables of 10^4 columns, 64 of 4000) and the batch
 // stays below 1.25 x 10^9 cells.  (MI355X, tools/ab_ck.py, ms: N = M = 10^4: 1 table 0.32-0.33 against 0.70 chain /
 // 0.71 checkpointed, 2 tables 0.365 against 0.72, 4 tables 0.48-0.50 against 0.76, 8 tables 0.73-0.75 against
 // 0.90-0.93, 16 tables 1.34-1.50 against 1.51-1.65, 24 tables 2.13 against 2.37 pc, 32 tables 4.3 against 2.9 pc;
@@ -179,7 +179,7 @@ static bool hb_wins(unsigned N, unsigned M, int D) {
   if (force > 0) return true;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
-  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 200);
+  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", stb_cu_count() * 25 / 32);
 }
 
 enum { FORM_ROWS_LOG, FORM_PC, FORM_CHAIN, FORM_ABLATION, FORM_CK, FORM_HB };
@@ -304,7 +304,7 @@ static bool hb_takes_kind(unsigned N, unsigned M, int D, int kind) {
   if (stb_env_int("STB_HB", -1) == 0 || !stb_hb_eligible_out(N, M, D, kind)) return false;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
-  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", 200);
+  return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", stb_cu_count() * 25 / 32);
 }
 
 extern "C" int stb_fill_takes_kind(unsigned N, unsigned M, int D, int kind) { return hb_takes_kind(N, M, D, kind) ? 1 : 0; }

@@ -924,6 +924,14 @@ static int aterms_once(stb_groups_t *g, const double *x_host, int D, double *out
   return aterms_finish(g, ms_fill, ms_sweep, ms_terms);
 }
 
+// The summing halo-block form (tile workers sum) holds while its spine workgroups leave the workers a quarter of the
+// chip: 25/32 of the compute units (200 of an MI355X's 256: 28 discounts of 10^4 columns at 7 strips a workgroup;
+// measured 28 discounts 0.99 ms against the grid form's 1.21, 30: 1.55, 32: 2.03 against 1.23).  STB_ATERMS_HB_MAX_SPINE overrides.
+static unsigned hb_max_spine() {
+  const int e = stb_env_int("STB_ATERMS_HB_MAX_SPINE", 0);
+  return e > 0 ? (unsigned)e : (unsigned)(stb_cu_count() * 25 / 32);
+}
+
 // which form an evaluation of D discounts takes, with the one-off set-up of the fused form done
 static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_out, int *v_out) {
   if (!g) return stb_fail("stb_groups_aterms: null group set");
@@ -963,17 +971,14 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
     grid_geom gg;
     if (force != 0 && stb_grid_geometry(g->N, g->M, D, &gg) == 0) {
       hb_dot_info H;
-      const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H) == 0 &&
-                            (unsigned)H.JW * (unsigned)D <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_WAVES", 1200);
+      const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= hb_max_spine();
       const bool sparse_pairs = (double)g->G <= 0.04 * (double)stb_table_cells(g->N, g->M);
       if (force > 0 || (!hb_range && sparse_pairs && stb_env_int("STB_ATERMS_HB", 1))) which = (gg.C == 2) ? 3 : 4;
     }
   }
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
     hb_dot_info H;
-    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 &&
-        (unsigned)H.JW * (unsigned)D <= (unsigned)stb_env_int("STB_ATERMS_HB_MAX_WAVES", 1200))
-      which = 2;
+    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= hb_max_spine()) which = 2;
   }
   if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which, D)) return 1;
   if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;

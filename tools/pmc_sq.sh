@@ -26,7 +26,7 @@ for f in glob.glob(f"{out}/{w}_g*/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/{w}.txt", "w") as fo:
     for k, cs in acc.items():
-        if "k_fill" not in k and "k_sweep" not in k:
+        if "k_fill" not in k and "k_sweep" not in k and "k_grid" not in k:
             continue
         print(k, file=fo)
         for c, v in sorted(cs.items()):

@@ -6,11 +6,15 @@
 The interpreter itself follows `--` (no env / shell hop: the profiler's library has initialised the
 GPU by then).  WHAT:
     fill1 fill8 fill64   stb_fill_S of 1 / 8 / 64 tables, N = M = 10000 (k_fill_hb / k_fill_hb / k_fill_pc)
-    fill1ck fill8ck      the same 1 / 8 tables in the checkpointed form (k_fill_ck)
+    fill1ck fill8ck      the same 1 / 8 tables in the checkpointed form (k_fill_ck; needs the ablation library)
     fill1chain fill8chain  ... and in the chain form (what round 2 ran)
-    vfill                stb_fill_V, N = M = 10000                      (k_fillv_chain)
-    grid64 grid8         the fused 64- / 8-discount aterms over 10^6 pairs, n < 10000 (k_fill_chain DOT / k_fill_hb DOT)
-    grid8chain           the 8-discount grid in the chain form
+    ffill8               8 tables stored as floats (S_FLOAT written once)  (k_fill_hb<4,0,1>)
+    vfill vfillx         stb_fill_V, N = M = 10000: from the S recurrence's cells (k_fill_hb<2,0,2>) / the reference's own
+                         V recurrence, bit for bit (k_fillv_chain)
+    grid64 grid8         the fused 64- / 8-discount aterms over 10^6 pairs, n < 10000 (k_grid_hb: walking waves sum /
+                         k_fill_hb<4,1>: tile workers sum)
+    grid64chain grid8chain  the same grids in the chain form (what rounds 2-3 ran at 64 discounts)
+    eval1f               one-discount aterms on a set that is used again and again (fused, as samplea's kept set)
     sweep64              the same grid through stored tables             (k_fill_pc, k_sweep_partial)
     eval1                one-discount aterms, 10^6 pairs, n < 4000       (k_fill_chain, k_sweep_partial, k_terms_partial)
     bterms               stb_bterms, 10^6 restaurants x 20 abscissae     (k_terms_partial)
@@ -55,16 +59,25 @@ if what in ("fill1", "fill8", "fill64", "fill1chain", "fill8chain", "fill1ck", "
         T.fill(a)
     torch.cuda.synchronize()
     T.status()
-elif what == "vfill":
+elif what in ("vfill", "vfillx"):
     T = capi.DeviceVTables(N, N, D=1)
     for _ in range(reps):
-        T.fill(np.array([0.5]))
+        T.fill(np.array([0.5]), exact=(what == "vfillx"))
     torch.cuda.synchronize()
-elif what in ("grid64", "grid8", "grid8chain", "sweep64"):
+    capi.check(L.stb_fill_status())
+elif what == "ffill8":
+    T = capi.DeviceFloatTables(N, N, D=8)
+    a = synth.discount_grid(64)[:8]
+    for _ in range(reps):
+        T.fill(a)
+    torch.cuda.synchronize()
+    T.status()
+elif what in ("grid64", "grid8", "grid8chain", "grid64chain", "sweep64"):
     if what == "sweep64":
         os.environ["STB_ATERMS_FUSED"] = "0"
-    if what == "grid8chain":
+    if what.endswith("chain"):
         os.environ["STB_ATERMS_HB"] = "0"
+        os.environ["STB_ATERMS_GRID"] = "0"
     Dg = 8 if what.startswith("grid8") else 64
     g = synth.groups(1000, 1000, N, "wide")
     h = groups_handle(g, Dg)
@@ -73,10 +86,12 @@ elif what in ("grid64", "grid8", "grid8chain", "sweep64"):
     for _ in range(reps):
         capi.check(L.stb_groups_aterms(h, capi.dp(x), Dg, capi.dp(out)))
     L.stb_groups_free(h)
-elif what == "eval1":
+elif what in ("eval1", "eval1f"):
     g = synth.groups(1000, 1000, 4000, "wide")
     h = groups_handle(g, 1)
     x, out = np.array([0.45]), np.zeros(1)
+    if what == "eval1f":  # (a set whose restaurants have been refreshed is a kept set: its evaluations are fused)
+        capi.check(L.stb_groups_update_restaurants(h, g.T.ctypes.data_as(capi.c_u32_p), capi.dp(g.bpar)))
     for _ in range(reps):
         capi.check(L.stb_groups_aterms(h, capi.dp(x), 1, capi.dp(out)))
     L.stb_groups_free(h)
