@@ -29,13 +29,9 @@ f64=$(find $OUT/fill64 -name "*kernel_trace.csv" | tail -1)
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_fill_pc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# fills are separated by gaps much longer than a launch: split where the start jumps by > 0.5 ms
-fills, cur = [], [rows[0]]
-for a, b in zip(rows, rows[1:]):
-    if int(b["Start_Timestamp"]) - int(a["End_Timestamp"]) > 500000:
-        fills.append(cur); cur = []
-    cur.append(b)
-fills.append(cur)
+# five fills of equally many launches, one after the other (a fill's two sub-batches overlap each other, not the next fill)
+per = len(rows) // 5
+fills = [rows[i * per:(i + 1) * per] for i in range(5)]
 print("# k_fill_pc launches of the 64-table fill (two sub-batches on two streams), from the rocprofv3 kernel trace:")
 print("# fill, launches, span first start -> last end (ms), sum of launch durations (ms), streams")
 for i, f in enumerate(fills):
