@@ -194,6 +194,11 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 // float (S_FLOAT, lib/stable.c:389-449: all arithmetic in double, only the stored value is a float), 2 the ratio
 // V^n_m = S^n_m / S^n_{m-1} as double (S_UVTABLE, lib/stable.c:451-482: a block-floating cell and its left neighbour are
 // one division away from it), 3 that ratio as float (lib/stable.c:483-537).
+#define HB_LIKELY(x) __builtin_expect(!!(x), 1)
+#define HB_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#ifndef HB_ABL
+#define HB_ABL 0  // timing-only builds (results wrong): the spine leaves out 1 the halo read, 2 the ring store, 4 the renormalisation, 8 the record, 16 the progress word
+#endif
 template <int C, int DOT, int OUT = 0>
 __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
@@ -321,13 +326,22 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_s_setprio(3);
         if (dbg) dbg[0] = HB_STAMP();
+#ifdef HB_TL_FINE
+        unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_tiles * 4 + (size_t)jw * NB * 8 : nullptr;
+#define HB_FINE(k) if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP()
+#else
+#define HB_FINE(k)
+#endif
         for (int b = b0; b < NB; b++) {
-          if (b > b0) hb_renorm<C>(v, ep);
+          HB_FINE(0);
+          if (HB_LIKELY(b > b0) && !(HB_ABL & 4)) hb_renorm<C>(v, ep);
+          HB_FINE(1);
           // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
-          if (has_next) {
+          if (has_next && (HB_ABL & 2)) lds_post(&posted[w], b + 1);
+          if (HB_LIKELY(has_next) && !(HB_ABL & 2)) {
             // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
             // but the last 4, which covers this block and the next three)
-            if ((b & 3) == 0 || b == b0) wait_ge(&taken[w + 1], b - 4, 0x400u);
+            if (HB_UNLIKELY((b & 3) == 0 || b == b0)) wait_ge(&taken[w + 1], b - 4, 0x400u);
             if (lane >= U) {
               double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
 #pragma unroll
@@ -336,11 +350,12 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             }
             lds_post(&posted[w], b + 1);
           }
+          HB_FINE(2);
           // ---- the record of the block: the own lanes as they stand before it (the halo lanes of strip 0 are
           // exact: they go to strip index 0 at the place a left neighbour's rightmost lanes would have).
           // (A publisher wave that takes the row from LDS and stores it in the spine's stead was tried: the spine
           // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
-          if ((own || jw == 0) && !(HB_DIAG & 1)) {
+          if (HB_LIKELY(own || jw == 0) && !(HB_DIAG & 1) && !(HB_ABL & 8)) {
             unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
             if constexpr (C == 1) {
               __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
@@ -353,24 +368,31 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             }
             __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0 && !(HB_ABL & 16)) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          HB_FINE(3);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
-          if (jw > 0) {
+          if (jw > 0 && (HB_ABL & 1)) lds_post(&taken[w], b + 1);
+          if (HB_LIKELY(jw > 0) && !(HB_ABL & 1)) {
             // (the counter and the data are asked for together -- LDS serves a wave's requests in order, so data
             // read after a counter that says "there" is there -- and only if the counter says "not yet" is it
-            // waited for and the data read again: one LDS round trip instead of two)
+            // waited for and the data read again: one LDS round trip instead of two.  Asking at the top of the block,
+            // so that the round trip passes behind the hand-over and the record above, gains nothing: measured 0.316 ms
+            // either way for one table -- the round trip is not what a block waits for)
             double hv[C];
             int he = 0;
             const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
             const int *srce = left_e + (b & left_mask) * HB_MAXHL + lane;
             const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
+#ifdef HB_TL_FINE
+            if (fdbg) fdbg[(size_t)b * 8 + 7] = (unsigned long long)(unsigned)(seen - b + 100);
+#endif
             asm volatile("" ::: "memory");
             if (lane < HL) {
 #pragma unroll
               for (int i = 0; i < C; i++) hv[i] = src[i];
               he = *srce;
             }
-            if (seen < b + 1) {
+            if (HB_UNLIKELY(seen < b + 1)) {
               wait_ge(left_cnt, b + 1, 0x100u);
               if (lane < HL) {
 #pragma unroll
@@ -387,15 +409,25 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             lds_post(&taken[w], b + 1);
           }
           if (dbg) dbg[1 + b] = HB_STAMP();
+          HB_FINE(4);
           // ---- R rows alone ----
           {
             const int dl = wave_shr1(ep, ep) - ep;
             s = ldexp(1.0, min(max(dl, -1100), 220));
           }
-          for (int r = 0; r < R; r += 8) {
+          HB_FINE(5);
+          // (a taken branch costs a lone wave ~28 cycles, most of a row: tools/ubench/rowvar.hip, 35.5 cycles a row in a
+          // loop of 8 rows, 31.0 with the 48 rows of a block in line)
+          if (HB_LIKELY(R == 48)) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) hb_row<C>(v, coef, s);
+            for (int u = 0; u < 48; u++) hb_row<C>(v, coef, s);
+          } else {
+            for (int r = 0; r < R; r += 8) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) hb_row<C>(v, coef, s);
+            }
           }
+          HB_FINE(6);
         }
         if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[NB + 1] = HB_STAMP();
@@ -457,8 +489,9 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           idle = 0;
           continue;
         }
-        for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
-        if (!woke) __builtin_amdgcn_s_sleep(4);  // (the left strip may be a long way from this one's first block)
+for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
+        if (!woke) __builtin_amdgcn_s_sleep(4);  // (the left strip may be a long way from this one's first block; polling
+                                                 // without a pause until the first record has come: measured no gain)
         if ((++idle & 31) != 0 && X.timeout != 0) continue;
         if (!timing) {
           timing = true;
@@ -1181,7 +1214,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   }
   if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");
+#ifdef HB_TL_FINE
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4 + (size_t)g.JW * g.NB * 8;
+#else
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4;
+#endif
   if (tl_file && *tl_file) {
     HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
     HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));

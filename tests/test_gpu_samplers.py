@@ -159,6 +159,18 @@ def test_samplea_keeps_the_pairs_between_calls(monkeypatch):
     monkeypatch.setenv("STB_SAMPLEA_CACHE", "0")
     orc.seed_libc(777, 12345)
     assert a2 == L.samplea(0.5, g2.I, orc.i32p(g2.K), orc.u32p(g2.T), n2, t2, None, orc.dp(g2.bpar), None, 1, 0)
+    monkeypatch.delenv("STB_SAMPLEA_CACHE")
+    # ONE count changed, all shapes the same: the evaluations queued on the guess that the kept set still holds (they
+    # are, before the pairs are read) must be thrown away
+    L.stb_sampler_cache_clear()
+    first = draw(0.5, b10)
+    g3 = synth.groups(100, 100, 1000, "wide")
+    g3.n[int(np.argmin(g3.n))] += 1                            # (table bounds unchanged: only the hash can tell)
+    n3, t3 = ragged(g3)
+    changed = draw(0.5, b10, nn=n3, tt=t3)
+    monkeypatch.setenv("STB_SAMPLEA_CACHE", "0")
+    assert changed == draw(0.5, b10, nn=n3, tt=t3)
+    assert first == draw(0.5, b10)
     L.stb_sampler_cache_clear()
 
 
