@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the fused grid aterms (summing halo-block / chain fills): the same evaluation over and over must give
+"""Soak test of the fused grid aterms (summing halo-block fills, tile workers or walking waves summing, and chain fills): the same evaluation over and over must give
 the same bits and never fall back.   usage: python tools/soak_grid.py [seconds]      (repo root, GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ import orc
 from libstb_amd import capi, synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 L = capi.lib()
-cases = [(10000, 8), (10000, 24), (10000, 3), (4000, 32), (1500, 5), (10000, 64)]
+cases = [(10000, 8), (10000, 24), (10000, 3), (4000, 32), (1500, 5), (10000, 64), (10000, 32), (10000, 48), (10000, 1)]
 total = 0
 for Nmax, D in cases:
     g = synth.groups(1000, 1000, Nmax, "wide")
