@@ -33,6 +33,9 @@
 #define GH_WRITTEN 0x8000000000000000ull
 #define GH_SPIN 48
 #define GH_MAXPH 16           // phases at most
+#define GH_JOB_MB 192          // room for the records of helper jobs
+#define GH_JOBS 1000           // jobs of a table at most
+#define GH_JQ 64               // strips (from the left) whose tiles can be jobs: a queue each
 #ifndef GH_NOSTORE
 #define GH_NOSTORE 0          // diagnostic build: 1 nothing is staged (results wrong)
 #endif
@@ -54,7 +57,15 @@ struct gh_args {
   const unsigned *item_ptr;    // [n_tiles * NQ + 1] first list entry of every (tile, group)
   const unsigned short *ent_pos;  // row in group << 8 | element of the wave
   const unsigned *ent_cnt;     // occurrence count
-  double *dotp;                // [D][JW][2]: sum of count x binary exponent (an integer), sum of count x log of the mantissa part
+  double *dotp;                // [D][JW + n_jobs][2]: sum of count x binary exponent (an integer), sum of count x log of the mantissa part; a strip's, then a job's
+  const unsigned *jobs;        // [n_jobs] tiles left to helper waves: strip | block << 16, strip after strip, a strip's by block;
+                               // then [GH_JQ + 1] the first job of every strip (a queue per strip)
+  const unsigned *tjob;        // [n_tiles] a tile's place in `jobs`, or 0xffffffff
+  unsigned n_jobs;
+  unsigned *jticket;           // [GH_JQ] x 16 words: per strip the next (job, table) to hand out, on a line of its own
+  unsigned *jflag;             // [D][n_jobs] non-zero: the record is written
+  int *jrec_e;                 // [D][n_jobs][64]      a job's record: the lane exponents of the tile's own wave before the block
+  double *jrec_v;              // [D][n_jobs][64 * C]  ... and its significands
   unsigned N, M;
   int D, B, JW, NB;            // tables, workgroups per table (all phases), strips per table, blocks
   int P, R, HL, U;             // spine waves per workgroup, rows per block, halo lanes, own lanes
@@ -166,12 +177,14 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
   __shared__ int posted[GH_NWMAX], taken[GH_NWMAX], fetched, s_abort, s_awake;
   __shared__ unsigned s_ticket;
   __shared__ int w_se[GH_PMAX][64];
+  __shared__ unsigned s_jq[GH_JQ + 1];  // first job of every strip's queue
   extern __shared__ __attribute__((aligned(16))) double gh_dyn[];  // per spine wave SR staged rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.ticket, 1u);
   if (tid < 128) lt[tid] = X.lt[tid];
+  if (X.n_jobs && tid <= GH_JQ) s_jq[tid] = X.jobs[X.n_jobs + tid];
   __syncthreads();
   const unsigned ticket = s_ticket;
   const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
@@ -215,24 +228,19 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
     };
     const int b00 = gh_first_block(jw, UC, R);  // the strip's own first block
     const int b0 = max(b00, bB);                // ... and its first one in this phase
-    const double a = X.a[d];
-    const int mE0 = 2 + (jw * U - HL) * C;      // column of the wave's first element (halo included; <= 0 in strip 0's halo)
-    const int m0 = mE0 + lane * C;
-    const size_t strip = (size_t)d * X.JW + jw;
+    // what the group loop below works on: the strip's own wave, or (after the strip has ended) a tile of another strip, of
+    // any table, taken as a job
+    double a = X.a[d];
+    int mE0 = 2 + (jw * U - HL) * C;            // column of the wave's first element (halo included; <= 0 in strip 0's halo)
+    int m0 = mE0 + lane * C;
+    const size_t strip = ((size_t)d * (size_t)(X.JW + (int)X.n_jobs) + jw);  // the strip's pair of sums
     double v[C], coef[C];
     int ep = 1 + PC_BIAS;
-    if (b00 < bB) {
-      // (the state the previous phase left: plain loads, another launch wrote it)
 #pragma unroll
-      for (int i = 0; i < C; i++) v[i] = X.state_v[(strip * 64 + lane) * C + i];
-      ep = X.state_e[strip * 64 + lane];
-    } else {
-#pragma unroll
-      for (int i = 0; i < C; i++) v[i] = 0.0;
-      if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
+    for (int i = 0; i < C; i++) {
+      v[i] = 0.0;
+      coef[i] = 0.0;
     }
-#pragma unroll
-    for (int i = 0; i < C; i++) coef[i] = 0.0;
     int one_hi = 0x3ff00000;
     asm volatile("" : "+v"(one_hi));
     const bool has_next = (w + 1 < P) && (jw + 1 < X.JWa);
@@ -250,18 +258,217 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
     double *stage = gh_dyn + (size_t)w * (size_t)(SR * WS);
     int *se = &w_se[w][0];
     const int NQ = R / G;
+    long long accK = 0;
+    double accF = 0.0;
+    // ---- a block's rows: the groups of G rows walked, every K-th row staged, the listed cells looked up.  `ti` is the
+    // tile's entry, `wcur` the first word of its first group (asked for a group ago), `tin` the NEXT tile's entry (asked
+    // for a block ago; 0: none), whose first word is asked for during the last group and left in `wcur`.  `only_walk`:
+    // the tile's cells are somebody else's (a helper's). ----
+    auto block_rows = [&](int b, unsigned ti, unsigned &wcur, unsigned tin, size_t item_blk, bool only_walk) {
+      {
+        const int dl = wave_shr1(ep, ep) - ep;
+        s = ldexp(1.0, min(max(dl, -1100), 220));
+      }
+      // (the coefficient n - 1 - m a of the next row, from its closed form at every block: + 1 a row drifts)
+#pragma unroll
+      for (int i = 0; i < C; i++) coef[i] = (double)(1 + b * R) - (double)(m0 + i) * a;
+      se[lane] = ep;
+      const unsigned nw = ti & 63u;
+      const unsigned *tw = X.dense + (size_t)(ti >> 6) * 64 + lane;  // this tile's words, this lane's
+      for (int q = 0; q < NQ; q++) {
+        // (this group's list is looked at BEFORE the next one is asked for: the compiler waits for every load under
+        // way where a loaded register is first read inside a loop, the one just issued included)
+        const bool listed = !only_walk && ((nw == 63u) || __ballot(wcur != 0) != 0);
+        asm volatile("" ::: "memory");
+        // the next group's first word is asked for now: it arrives while this group is walked
+        unsigned wnext = 0;
+        if (q + 1 < NQ) {
+          if (nw != 0 && nw != 63u) wnext = tw[(size_t)(q + 1) * nw * 64];
+        } else {
+          tin = (unsigned)__builtin_amdgcn_readfirstlane((int)tin);
+          if ((tin & 63u) != 0 && (tin & 63u) != 63u) wnext = X.dense[(size_t)(tin >> 6) * 64 + lane];
+        }
+        if (listed && !(X.diag & 8)) {
+#pragma unroll
+          for (int r = 0; r < G; r++) {
+            gh_row<C>(v, coef, s);
+            if ((r % K) == 0 && !GH_NOSTORE) {
+              double *dst = stage + (r / K) * WS + lane * C;
+              if constexpr (C == 4) {
+                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
+                *reinterpret_cast<gh_double2 *>(dst + 2) = gh_double2{v[2], v[3]};
+              } else {
+                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
+              }
+            }
+          }
+          const int nrow0 = 2 + b * R + q * G;  // the row the group's first step produces
+          if (X.diag & 4) {
+          } else if (nw != 63u) {
+            // word after word, the next one asked for before this one is worked on; a group's words are filled from
+            // the front: the first empty one ends it
+            const unsigned *gw = tw + (size_t)q * nw * 64;
+            unsigned wd = wcur;
+            for (unsigned k = 0; k < nw; k++) {
+              if (k > 0 && __ballot(wd != 0) == 0) break;  // (looked at before the next load is issued: see above)
+              asm volatile("" ::: "memory");
+              unsigned wn = 0;
+              if (k + 1 < nw) wn = gw[(size_t)(k + 1) * 64];
+              gh_lookup<C, K>(wd != 0, wd & 0x1fffu, wd >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+              wd = wn;
+            }
+          } else {
+            // (a count of 2^19 or more in the tile, or more words than the layout takes: the lists in CSR form)
+            const size_t item = item_blk + q;
+            const unsigned e0 = X.item_ptr[item], e1 = X.item_ptr[item + 1];
+            for (unsigned kk = e0; kk < e1; kk += 64) {
+              unsigned pos = 0, cnt = 0;
+              if (kk + lane < e1) {
+                pos = X.ent_pos[kk + lane];
+                cnt = X.ent_cnt[kk + lane];
+              }
+              gh_lookup<C, K>(kk + lane < e1, pos, cnt, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+            }
+          }
+        } else {
+          // (a group none of whose cells occurs, or whose cells are a helper's, is only walked)
+#pragma unroll
+          for (int r = 0; r < G; r++) gh_row<C>(v, coef, s);
+        }
+        wcur = wnext;
+      }
+    };
+    // the two sums of what has been looked up, over the wave in a fixed tree: the same bits on every run.  (The exponent
+    // sum is an integer well below 2^53: exact in a double, whatever the order.)
+    auto sums_out = [&](double *out, bool add) {
+      double kd = (double)accK;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        kd += __shfl_xor(kd, o);
+        accF += __shfl_xor(accF, o);
+      }
+      if (lane == 0) {
+        if (add) {  // (what the earlier phases summed: this wave is the strip's only writer in this launch)
+          kd += out[0];
+          accF = out[1] + accF;
+        }
+        out[0] = kd;
+        out[1] = accF;
+      }
+      accK = 0;
+      accF = 0.0;
+    };
+    // ---- helper jobs: a tile (strip jj, block jb, table dd) whose own wave only walked it, leaving the state of the
+    // wave before the block; tickets go through the jobs in the order the tiles become ready, table after table.
+    // Returns false when there is none left (or the launch is being given up). ----
+    const unsigned n_jobs = X.n_jobs;
+    bool jobs_left = n_jobs != 0 && b00 >= bB && !(X.diag & 32);
+    unsigned long long q_off = 0;  // queues this wave has found exhausted, or too late for it
+    int q_next = (int)((ticket * 4u + (unsigned)w) % GH_JQ);
+    // A queue per strip, a strip's jobs by block; a wave starts at a queue of its own and moves on when one is exhausted.
+    // (Jobs are taken only by waves whose own strip has ENDED.  Taken before its start -- by waves the diagonal has not
+    // reached yet, from the strips to their left -- they cost more than they bring: a wave that is inside a job when its
+    // first halo arrives starts late, and everything to its right with it.  MI355X, 32 discounts, kernel ms: no jobs 1.23;
+    // jobs up to 4 blocks before the wave's own first one 1.19, 12: 1.09, 24: 1.04, 48: 0.98; after the strip only: 0.93.)
+    auto run_job = [&]() -> bool {
+      unsigned job = 0;
+      int dd = 0;
+      bool got = false;
+      for (int tries = 0; tries < GH_JQ && !got; tries++) {
+        const int q = q_next;
+        if ((q_off >> q) & 1ull) {
+          q_next = (q_next + 1 == GH_JQ) ? 0 : q_next + 1;
+          continue;
+        }
+        const unsigned j0 = s_jq[q], nq = s_jq[q + 1] - j0;
+        const unsigned long long all = (unsigned long long)nq * (unsigned long long)X.D;
+        unsigned t = 0;
+        if (nq != 0 && lane == 0) t = atomicAdd(X.jticket + 16 * q, 1u);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (nq == 0 || (unsigned long long)t >= all) {
+          q_off |= 1ull << q;
+          q_next = (q_next + 1 == GH_JQ) ? 0 : q_next + 1;
+          continue;
+        }
+        job = j0 + t / (unsigned)X.D;
+        dd = (int)(t % (unsigned)X.D);
+        got = true;
+      }
+      if (!got) return false;
+      const unsigned jd = X.jobs[job];
+      const int jj = (int)(jd & 0xffffu), jb = (int)(jd >> 16);
+      const size_t slot = (size_t)dd * n_jobs + job;
+      const unsigned tile = X.tile_off[jj + 1] + (unsigned)(jb - gh_first_block(jj, UC, R));
+      unsigned ti = X.tinfo[tile];
+      // the record: written a block after the tile's own wave walked past it
+      {
+        unsigned long long t_begin = 0;
+        bool timing = false;
+        unsigned idle = 0;
+        while (__hip_atomic_load(X.jflag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(8);
+          if ((++idle & 31) != 0) continue;
+          if (!timing) {
+            timing = true;
+            t_begin = wall_clock64();
+          }
+          const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (err != 0 || (X.timeout != 0 && (unsigned long long)wall_clock64() - t_begin >= X.timeout)) {
+            if (err == 0 && lane == 0) {
+              __hip_atomic_store(X.hdr + 2, (unsigned)(jj | (dd << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return false;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(X.jrec_v) + (slot * 64 + lane) * C;
+#pragma unroll
+        for (int i = 0; i < C; i++) v[i] = __longlong_as_double((long long)__hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        ep = __hip_atomic_load(X.jrec_e + slot * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ti = (unsigned)__builtin_amdgcn_readfirstlane((int)ti);
+      unsigned wcur = 0;
+      if ((ti & 63u) != 0 && (ti & 63u) != 63u) wcur = X.dense[(size_t)(ti >> 6) * 64 + lane];
+      a = X.a[dd];
+      mE0 = 2 + (jj * U - HL) * C;
+      m0 = mE0 + lane * C;
+      accK = 0;
+      accF = 0.0;
+      block_rows(jb, ti, wcur, 0u, (size_t)tile * (size_t)NQ, false);
+      sums_out(X.dotp + ((size_t)dd * (size_t)(X.JW + (int)n_jobs) + (size_t)X.JW + job) * 2, false);
+      return true;
+    };
+    // ---- the strip's own walk ----
+    a = X.a[d];
+    mE0 = 2 + (jw * U - HL) * C;
+    m0 = mE0 + lane * C;
+    ep = 1 + PC_BIAS;
+    if (b00 < bB) {
+      // (the state the previous phase left: plain loads, another launch wrote it)
+#pragma unroll
+      for (int i = 0; i < C; i++) v[i] = X.state_v[(((size_t)d * X.JW + jw) * 64 + lane) * C + i];
+      ep = X.state_e[((size_t)d * X.JW + jw) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < C; i++) v[i] = 0.0;
+      if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
+    }
+    accK = 0;
+    accF = 0.0;
     // the strip's listed cells, group after group in (block, group of G rows) order: NW words per lane, the first of
     // them asked for a group ahead and the tile's entry a block ahead (no address depends on a load just made)
     const unsigned tile0 = X.tile_off[jw + 1];  // tile (jw, b00)
     const size_t item0 = (size_t)tile0 * (size_t)NQ;
     unsigned ti = (b0 < bE) ? X.tinfo[tile0 + (unsigned)(b0 - b00)] : 0u;
+    unsigned tj = (n_jobs && b0 < bE) ? X.tjob[tile0 + (unsigned)(b0 - b00)] : 0xffffffffu;  // the tile's place among the jobs, if it is one
     ti = (unsigned)__builtin_amdgcn_readfirstlane((int)ti);
+    tj = (unsigned)__builtin_amdgcn_readfirstlane((int)tj);
     unsigned wcur = 0;
     if ((ti & 63u) != 0 && (ti & 63u) != 63u) wcur = X.dense[(size_t)(ti >> 6) * 64 + lane];
-    long long accK = 0;
-    double accF = 0.0;
-    // Everything is set up before the wave dozes until its first halo is about to arrive: a strip never makes up
-    // for a late start, and a wave that spins takes issue slots from the walking wave it shares a SIMD with.
+    unsigned pend = 0xffffffffu;  // a job whose record has been stored and whose "written" word is still to be set
     while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
     if (w > 0)
       while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
@@ -319,105 +526,47 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
         lds_post(&taken[w], b + 1);
       }
       if (dbg) dbg[1 + b] = wall_clock64();
-      {
-        const int dl = wave_shr1(ep, ep) - ep;
-        s = ldexp(1.0, min(max(dl, -1100), 220));
+      // ---- a tile that is a job: the wave as it stands goes to the job's record.  Its "written" word follows a block
+      // later, when the stores have long been through (waiting for them here would cost a round trip to memory). ----
+      if (pend != 0xffffffffu) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(X.jflag + (size_t)d * n_jobs + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend = 0xffffffffu;
       }
-      // (the coefficient n - 1 - m a of the next row, from its closed form at every block: + 1 a row drifts)
+      const bool is_job = tj != 0xffffffffu;
+      if (is_job) {
+        const size_t slot = (size_t)d * n_jobs + tj;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(X.jrec_v) + (slot * 64 + lane) * C;
 #pragma unroll
-      for (int i = 0; i < C; i++) coef[i] = (double)(1 + b * R) - (double)(m0 + i) * a;
-      se[lane] = ep;
-      const unsigned nw = ti & 63u;
-      const unsigned *tw = X.dense + (size_t)(ti >> 6) * 64 + lane;  // this tile's words, this lane's
-      unsigned tin = (b + 1 < bE) ? X.tinfo[tile0 + (unsigned)(b + 1 - b00)] : 0u;  // the next tile's entry
-      for (int q = 0; q < NQ; q++) {
-        // (this group's list is looked at BEFORE the next one is asked for: the compiler waits for every load under
-        // way where a loaded register is first read inside a loop, the one just issued included)
-        const bool listed = (nw == 63u) || __ballot(wcur != 0) != 0;
-        asm volatile("" ::: "memory");
-        // the next group's first word is asked for now: it arrives while this group is walked
-        unsigned wnext = 0;
-        if (q + 1 < NQ) {
-          if (nw != 0 && nw != 63u) wnext = tw[(size_t)(q + 1) * nw * 64];
-        } else {
-          tin = (unsigned)__builtin_amdgcn_readfirstlane((int)tin);
-          if ((tin & 63u) != 0 && (tin & 63u) != 63u) wnext = X.dense[(size_t)(tin >> 6) * 64 + lane];
-        }
-        if (listed && !(X.diag & 8)) {
-#pragma unroll
-          for (int r = 0; r < G; r++) {
-            gh_row<C>(v, coef, s);
-            if ((r % K) == 0 && !GH_NOSTORE) {
-              double *dst = stage + (r / K) * WS + lane * C;
-              if constexpr (C == 4) {
-                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
-                *reinterpret_cast<gh_double2 *>(dst + 2) = gh_double2{v[2], v[3]};
-              } else {
-                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
-              }
-            }
-          }
-          const int nrow0 = 2 + b * R + q * G;  // the row the group's first step produces
-          if (X.diag & 4) {
-          } else if (nw != 63u) {
-            // word after word, the next one asked for before this one is worked on; a group's words are filled from
-            // the front: the first empty one ends it
-            const unsigned *gw = tw + (size_t)q * nw * 64;
-            unsigned w = wcur;
-            for (unsigned k = 0; k < nw; k++) {
-              if (k > 0 && __ballot(w != 0) == 0) break;  // (looked at before the next load is issued: see above)
-              asm volatile("" ::: "memory");
-              unsigned wn = 0;
-              if (k + 1 < nw) wn = gw[(size_t)(k + 1) * 64];
-              gh_lookup<C, K>(w != 0, w & 0x1fffu, w >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
-              w = wn;
-            }
-          } else {
-            // (a count of 2^19 or more in the tile, or more words than the layout takes: the lists in CSR form)
-            const size_t item = item0 + (size_t)(b - b00) * NQ + q;
-            const unsigned e0 = X.item_ptr[item], e1 = X.item_ptr[item + 1];
-            for (unsigned kk = e0; kk < e1; kk += 64) {
-              unsigned pos = 0, cnt = 0;
-              if (kk + lane < e1) {
-                pos = X.ent_pos[kk + lane];
-                cnt = X.ent_cnt[kk + lane];
-              }
-              gh_lookup<C, K>(kk + lane < e1, pos, cnt, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
-            }
-          }
-        } else {
-          // (a group none of whose cells occurs is only walked)
-#pragma unroll
-          for (int r = 0; r < G; r++) gh_row<C>(v, coef, s);
-        }
-        wcur = wnext;
+        for (int i = 0; i < C; i += 2)
+          gh_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]), (unsigned long long)__double_as_longlong(v[i + 1]));
+        __hip_atomic_store(X.jrec_e + slot * 64 + lane, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend = tj;
       }
-      ti = tin;
-    }
-    // the strip's two sums, over the wave in a fixed tree: the same bits on every run.  (The exponent sum is an
-    // integer well below 2^53: exact in a double, whatever the order.)
-    double kd = (double)accK;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      kd += __shfl_xor(kd, o);
-      accF += __shfl_xor(accF, o);
-    }
-    if (lane == 0) {
-      double *out = X.dotp + strip * 2;
-      if (b00 < bB) {  // (what the earlier phases summed: this wave is the strip's only writer in this launch)
-        kd += out[0];
-        accF = out[1] + accF;
+      unsigned tin = 0, tjn = 0xffffffffu;
+      if (b + 1 < bE) {
+        tin = X.tinfo[tile0 + (unsigned)(b + 1 - b00)];  // the next tile's entry
+        if (n_jobs) tjn = X.tjob[tile0 + (unsigned)(b + 1 - b00)];
       }
-      out[0] = kd;
-      out[1] = accF;
+      block_rows(b, ti, wcur, tin, item0 + (size_t)(b - b00) * NQ, is_job);
+      ti = (unsigned)__builtin_amdgcn_readfirstlane((int)tin);
+      tj = (unsigned)__builtin_amdgcn_readfirstlane((int)tjn);
     }
+    if (pend != 0xffffffffu) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(X.jflag + (size_t)d * n_jobs + pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sums_out(X.dotp + strip * 2, b00 < bB);
     if (bE < NB) {
 #pragma unroll
-      for (int i = 0; i < C; i++) X.state_v[(strip * 64 + lane) * C + i] = v[i];
-      X.state_e[strip * 64 + lane] = ep;
+      for (int i = 0; i < C; i++) X.state_v[(((size_t)d * X.JW + jw) * 64 + lane) * C + i] = v[i];
+      X.state_e[((size_t)d * X.JW + jw) * 64 + lane] = ep;
     }
     if (dbg) dbg[NB + 1] = wall_clock64();
     __builtin_amdgcn_s_setprio(0);
+    // ---- ... and after it: the jobs that are left ----
+    while (jobs_left && !lds_peek(&s_abort))
+      if (!run_job()) jobs_left = false;
   } else if (wave == P && j > 0 && jw0 < X.JWa) {
     // ================= fetcher: the left workgroup's last strip's records -> LDS, for spine wave 0 =================
     const int gl = (HL <= 16) ? 16 : 32;
@@ -494,6 +643,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
 // ------------------------------------------------------------------------------------------------
 // host side
 
+unsigned stb_grid_job_cap(int C, int D, unsigned n_tiles, int phases);
 int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
   grid_geom g;
   memset(&g, 0, sizeof(g));
@@ -569,21 +719,40 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
     if (ph > g.NB) ph = g.NB;
     g.phases = ph;
   }
-  size_t o = 256 + 64 * GH_MAXPH;  // header: error words, then a ticket word per phase on a line of its own
+  // Helper jobs (one launch only): tiles whose listed cells the strip's own wave leaves to waves that have nothing to
+  // do yet.  A job's record is the whole wave before the block, 64 (4 + 8 C) bytes: at most GH_JOB_MB of them per launch.
+  g.job_cap = stb_grid_job_cap(g.C, D, g.n_tiles, g.phases);
+  size_t o = 256 + 64 * (GH_MAXPH + GH_JQ);  // header: error words, then a ticket word per phase -- and one per job queue -- on a line of its own
   o = stb_align_up(o, 256);
   g.off_cke = o;
   o += stb_align_up((size_t)D * g.B * g.NB * g.HL * sizeof(unsigned), 256);
   g.off_ckv = o;
   o += stb_align_up((size_t)D * g.B * g.NB * g.HL * g.C * 8, 256);
+  g.off_jflag = o;
+  o += stb_align_up((size_t)D * g.job_cap * sizeof(unsigned), 256);
   g.zero_bytes = o;
   g.off_state_e = o;
   o += stb_align_up((size_t)D * g.JW * 64 * sizeof(int), 256);
   g.off_state_v = o;
   o += stb_align_up((size_t)D * g.JW * 64 * g.C * 8, 256);
+  g.off_jrec_e = o;
+  o += stb_align_up((size_t)D * g.job_cap * 64 * sizeof(int), 256);
+  g.off_jrec_v = o;
+  o += stb_align_up((size_t)D * g.job_cap * 64 * g.C * 8, 256);
   g.bytes = o;
   g.ok = 1;
   *out = g;
   return 0;
+}
+
+unsigned stb_grid_job_cap(int C, int D, unsigned n_tiles, int phases) {
+  if (phases != 1 || D < 1 || !stb_env_int("STB_GRID_HELP", 1)) return 0;
+  uint64_t rec = 64ull * (4 + 8 * C), room = ((uint64_t)stb_env_int("STB_GRID_JOB_MB", GH_JOB_MB) << 20) / ((uint64_t)D * rec);
+  // (... and what is taken off every table's critical path comes back as a tail in which all waves work side by side: a
+  // job is ~7 us of a wave, a table has ~50 of them)
+  const uint64_t most = (uint64_t)stb_env_int("STB_GRID_JOBS", GH_JOBS);
+  if (room > most) room = most;
+  return (unsigned)(room < n_tiles ? room : n_tiles);
 }
 
 size_t stb_grid_workspace(unsigned N, unsigned M, int D) {
@@ -600,7 +769,9 @@ size_t stb_grid_workspace(unsigned N, unsigned M, int D) {
   for (int c : cs) {
     const int HL = R / c, U = 64 - HL, UC = U * c;
     const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R, B = (JW + 3) / 4;
-    const size_t b = 4096 + (size_t)D * B * NB * HL * (4 + 8 * c) + (size_t)D * JW * 64 * (4 + 8 * c) + 2048;
+    const size_t jobs = stb_grid_job_cap(c, D, (unsigned)(JW * NB), 1);  // (records and "written" words of the helper jobs)
+    const size_t b = 4096 + 64 * (GH_MAXPH + GH_JQ) + (size_t)D * B * NB * HL * (4 + 8 * c) + (size_t)D * JW * 64 * (4 + 8 * c) + 2048 +
+                     (size_t)D * jobs * (64 * (4 + 8 * c) + 4) + 1024;
     if (b > need) need = b;
   }
   return need + 256;
@@ -676,7 +847,16 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
   if (X.poll_nap < 1) X.poll_nap = 1;
   X.diag = stb_env_int("STB_GRID_DIAG", 0);
-  const_cast<dot_request *>(dot)->parts_per_table = g.JW;
+  if (dot->n_jobs > g.job_cap || (dot->n_jobs && (!dot->jobs || !dot->tjob)))
+    return stb_fail("stb_groups_aterms: %u helper jobs in the cell lists, room for %u in the workspace", dot->n_jobs, g.job_cap);
+  X.jobs = dot->jobs;
+  X.tjob = dot->tjob;
+  X.n_jobs = dot->n_jobs;
+  X.jticket = X.hdr + 64 + 16 * GH_MAXPH;  // (GH_JQ lines)
+  X.jflag = (unsigned *)(ws + g.off_jflag);
+  X.jrec_e = (int *)(ws + g.off_jrec_e);
+  X.jrec_v = (double *)(ws + g.off_jrec_v);
+  const_cast<dot_request *>(dot)->parts_per_table = g.JW + (int)dot->n_jobs;
   const char *tl_file = getenv("STB_HB_TIMELINE");
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2);
   if (tl_file && *tl_file) {

@@ -5,6 +5,7 @@
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "stb_common.h"
@@ -55,6 +56,9 @@ struct stb_groups {
   unsigned *d_tile_off[STB_NLISTS];            // [3], [4]: first tile of every strip (grid_hb.hip)
   unsigned *d_dense[STB_NLISTS];               // [3], [4]: the listed cells as words per lane, group after group: what the walk reads
   unsigned *d_tinfo[STB_NLISTS];               // [3], [4]: per tile, where its words start and how many a group has
+  unsigned *d_jobs[STB_NLISTS];                // [3], [4]: the tiles whose cells are left to helper waves, in the order they become ready
+  unsigned *d_tjob[STB_NLISTS];                // [3], [4]: per tile its place in d_jobs, or 0xffffffff
+  unsigned n_jobs[STB_NLISTS];
   uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
   int reused;  // stb_groups_update_restaurants has been called: the same pairs serve call after call
@@ -139,7 +143,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                   g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
                   g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
                   g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4],
-                  g->d_tinfo[3], g->d_tinfo[4]};
+                  g->d_tinfo[3], g->d_tinfo[4], g->d_jobs[3], g->d_jobs[4], g->d_tjob[3], g->d_tjob[4]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -483,9 +487,10 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
   hb_dot_info H;
   memset(&H, 0, sizeof(H));
   if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
+  grid_geom gg;
+  memset(&gg, 0, sizeof(gg));
   if (which >= 3) {
     // (the strip shape of the grid form depends on the number of discounts: a list per shape)
-    grid_geom gg;
     if (stb_grid_geometry(N, M, D, &gg)) return stb_fail("stb_groups_aterms: no grid geometry for N=%u M=%u", N, M);
     which = (gg.C == 2) ? 3 : 4;
     H.R = gg.R;
@@ -506,6 +511,11 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       stb_pool_free(g->d_tile_off[which]);
       stb_pool_free(g->d_dense[which]);
       stb_pool_free(g->d_tinfo[which]);
+      stb_pool_free(g->d_jobs[which]);
+      stb_pool_free(g->d_tjob[which]);
+      g->d_jobs[which] = nullptr;
+      g->d_tjob[which] = nullptr;
+      g->n_jobs[which] = 0;
       g->d_dense[which] = nullptr;
       g->d_tinfo[which] = nullptr;
       g->d_item_ptr[which] = nullptr;
@@ -639,6 +649,64 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
         hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which],
                            g->d_ent_cnt[which], nitems, NQ, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
       if (ok) ok = hipStreamSynchronize(g->st) == hipSuccess;
+      // The tiles whose listed cells the strip's own wave does not look up: every strip of a table moves at the pace of
+      // the strips to its left, and those hold most of the pairs (t uniform below n: columns like log) -- several
+      // passes a group where the average strip has one.  Such a tile is only walked by its strip, which leaves the
+      // state of its wave before the block as a record; waves whose strips the diagonal has not reached yet take the
+      // tiles as jobs, in the order they become ready (blocks, then strips).  Which: all tiles of NWH passes a group and
+      // more (the lists in CSR form among them), NWH the smallest number from 2 for which the records fit (grid_geom::job_cap
+      // at Dmax discounts).
+      g->n_jobs[which] = 0;
+      if (ok && n_tiles) {
+        std::vector<unsigned> h_nw(n_tiles), off;
+        const unsigned cap = stb_grid_job_cap(gg.C, g->Dmax, n_tiles, gg.phases);
+        ok = hipMemcpy(h_nw.data(), tnw, 4 * (size_t)n_tiles, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && cap) {
+          unsigned hist[65] = {0};  // (an upper bound: the tiles of all strips)
+          for (unsigned t = 0; t < n_tiles; t++) hist[h_nw[t] > 63 ? 63 : h_nw[t]]++;
+          unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 2);
+          if (nwh < 1) nwh = 1;
+          for (; nwh <= 63; nwh++) {
+            unsigned c = 0;
+            for (unsigned k = nwh; k <= 63; k++) c += hist[k];
+            if (c <= cap) break;
+          }
+          std::vector<unsigned> jobs, tjob(n_tiles, 0xffffffffu);
+          stb_grid_tile_offsets(gg, off);
+          const int UCg = gg.U * gg.C;
+          // (only tiles of strips whose workgroups are on the chip from the launch's first moment -- one workgroup per
+          // compute unit at the least, handed the lowest tickets -- so that whoever waits for a record waits for a wave
+          // that is running or through: Dmax tables x jlim / P workgroups <= compute units)
+          int jlim = (stb_cu_count() / (g->Dmax > 0 ? g->Dmax : 1)) * gg.P;
+          if (jlim > 64) jlim = 64;  // (GH_JQ of grid_hb.hip: a queue of jobs per strip)
+          std::vector<unsigned> qoff(64 + 1, 0u);
+          if (nwh <= 63) {
+            // strip after strip, a strip's tiles by block: a queue per strip
+            for (int j = 0; j < gg.JW && j < jlim; j++) {
+              const int b00 = (int)(((long long)j * UCg) / gg.R);
+              qoff[j] = (unsigned)jobs.size();
+              for (int b = b00; b < gg.NB; b++)
+                if (h_nw[off[j + 1] + (unsigned)(b - b00)] >= nwh) {
+                  tjob[off[j + 1] + (unsigned)(b - b00)] = (unsigned)jobs.size();
+                  jobs.push_back((unsigned)j | ((unsigned)b << 16));
+                }
+            }
+            for (int j = (gg.JW < jlim ? gg.JW : jlim); j <= 64; j++) qoff[j] = (unsigned)jobs.size();
+            if (jobs.size() > cap) {  // (the bound above counted every strip's tiles: cannot happen)
+              jobs.clear();
+              std::fill(tjob.begin(), tjob.end(), 0xffffffffu);
+              std::fill(qoff.begin(), qoff.end(), 0u);
+            }
+          }
+          const size_t nj = jobs.size();
+          jobs.insert(jobs.end(), qoff.begin(), qoff.end());  // (behind the jobs: the first job of every strip)
+          ok = stb_pool_malloc((void **)&g->d_jobs[which], 4 * (jobs.size() + 1)) == hipSuccess &&
+               stb_pool_malloc((void **)&g->d_tjob[which], 4 * (size_t)(n_tiles + 1)) == hipSuccess &&
+               hipMemcpy(g->d_tjob[which], tjob.data(), 4 * (size_t)n_tiles, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemcpy(g->d_jobs[which], jobs.data(), 4 * jobs.size(), hipMemcpyHostToDevice) == hipSuccess;
+          if (ok) g->n_jobs[which] = (unsigned)nj;
+        }
+      }
       stb_pool_free(tnw);
       stb_pool_free(twords);
       stb_pool_free(toff);
@@ -658,7 +726,14 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       if (stb_hb_dot_info(N, M, g->Dmax, &H2) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
         g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
       // (the self-summing form: two sums per strip, strips of 80 columns at the narrowest)
-      const size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
+      size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
+      {
+        // (... and two per tile left to helper waves: at most grid_geom::job_cap of them)
+        grid_geom gj;
+        for (int dd : {1, g->Dmax})
+          if (stb_grid_geometry(N, M, dd, &gj) == 0 && (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2 > hb2)
+            hb2 = (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2;
+      }
       if (hb2 > g->dotp_elems) g->dotp_elems = hb2;
       if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
         stb_fail("stb_groups_aterms: out of device memory");
@@ -779,6 +854,9 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
     req.tile_off = g->d_tile_off[which];
     req.dense = g->d_dense[which];
     req.tinfo = g->d_tinfo[which];
+    req.jobs = g->d_jobs[which];
+    req.tjob = g->d_tjob[which];
+    req.n_jobs = g->n_jobs[which];
   }
   req.dotp = g->d_dotp;
   req.ws_zero = g->ws_zero;

@@ -136,6 +136,9 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   const unsigned *tile_off = nullptr;      //         col0 = 4: first tile of every strip (device, stb_grid_tile_offsets)
   const unsigned *dense = nullptr;         //         col0 = 4: the listed cells as words per lane (position | count << 13), group after group
   const unsigned *tinfo = nullptr;         //         col0 = 4: per tile, first word / 64 << 6 | words per group (63: the CSR lists)
+  const unsigned *jobs = nullptr;          //         col0 = 4: tiles left to helper waves, strip | block << 16, in the order they become ready
+  const unsigned *tjob = nullptr;          //         col0 = 4: per tile its place in `jobs`, or 0xffffffff
+  unsigned n_jobs = 0;
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
   size_t ws_zero = 0;                      // in: bytes at the start of the workspace the caller knows to be zero (no memset then)
@@ -181,11 +184,14 @@ struct grid_geom {
   int G, NQ, phases;              // rows per group, groups per block, launches
   int K;                          // every K-th row of a group is staged in LDS
   unsigned n_tiles;               // (strip, block) pairs of a table
+  unsigned job_cap;               // tiles of a table at most whose listed cells are left to waves with nothing to do yet (0: none)
   size_t off_cke, off_ckv, off_state_e, off_state_v, zero_bytes, bytes;
+  size_t off_jflag, off_jrec_e, off_jrec_v;  // [D][job_cap] "written" words (zeroed), [D][job_cap][64] exponents, [D][job_cap][64 C] significands
   int ok;
 };
 int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out);
 size_t stb_grid_workspace(unsigned N, unsigned M, int D);
+unsigned stb_grid_job_cap(int C, int D, unsigned n_tiles, int phases);
 int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st);
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);

@@ -373,17 +373,27 @@ def _edge_pairs(C):
     return g, n, t
 
 
-@pytest.mark.parametrize("C,P,G,PH", [(2, 4, 24, 1), (2, 7, 12, 3), (2, 2, 8, 1), (4, 4, 12, 1), (4, 7, 8, 4), (4, 3, 16, 2), (4, 4, 24, 5)])
-def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G, PH):
+HELP_ALL = {"STB_GRID_HELP_NW": "1"}                           # every tile with a listed cell is a helper job
+HELP_FEW = {"STB_GRID_HELP_NW": "1", "STB_GRID_JOBS": "3"}     # ... but room for three: the threshold moves up
+HELP_OFF = {"STB_GRID_HELP": "0"}
+
+
+@pytest.mark.parametrize("C,P,G,PH,env", [(2, 4, 24, 1, {}), (2, 7, 12, 3, {}), (2, 2, 8, 1, {}), (4, 4, 12, 1, {}), (4, 7, 8, 4, {}),
+                                          (4, 3, 16, 2, {}), (4, 4, 24, 5, {}), (2, 4, 24, 1, HELP_ALL), (4, 4, 24, 1, HELP_ALL),
+                                          (4, 3, 12, 1, HELP_ALL), (4, 4, 24, 1, HELP_FEW), (4, 4, 24, 1, HELP_OFF), (4, 4, 8, 3, HELP_ALL)])
+def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G, PH, env):
     """the default for a grid since round 4: k_grid_hb<C, G> (grid_hb.hip), whose walking waves stage every other
     row of a group of G in LDS and sum their own strip's listed cells (column 1 included; no tile workers, no S1
     vector, no gather pass), in PH launches over bands of blocks -- against stored tables + gather at 1e-12, bit
     for bit run to run, at the ends of samplea's bracket (A_MIN = 0.01, A_MAX = 0.98, lib/psample.h:89-94), in
-    every strip shape"""
+    every strip shape; and with tiles left to helper waves (a strip's own wave only walks them and leaves a record;
+    waves whose strips have ended sum them): all tiles, a few, none"""
     L = capi.lib()
     monkeypatch.setenv("STB_ATERMS_GRID", "1")
     for k, v in (("C", C), ("P", P), ("G", G), ("PHASES", PH)):
         monkeypatch.setenv("STB_GRID_" + k, str(v))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     g, n, t = _edge_pairs(C)
     x = np.array([0.01, 0.11, 0.5, 0.83, 0.98])
     outs = []
