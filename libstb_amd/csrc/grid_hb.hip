@@ -34,7 +34,7 @@
 #define GH_SPIN 48
 #define GH_MAXPH 16           // phases at most
 #define GH_JOB_MB 192          // room for the records of helper jobs
-#define GH_JOBS 1000           // jobs of a table at most
+#define GH_JOBS 1500           // jobs of a table at most
 #define GH_JQ 64               // strips (from the left) whose tiles can be jobs: a queue each
 #ifndef GH_NOSTORE
 #define GH_NOSTORE 0          // diagnostic build: 1 nothing is staged (results wrong)

@@ -653,9 +653,8 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       // the strips to its left, and those hold most of the pairs (t uniform below n: columns like log) -- several
       // passes a group where the average strip has one.  Such a tile is only walked by its strip, which leaves the
       // state of its wave before the block as a record; waves whose strips the diagonal has not reached yet take the
-      // tiles as jobs, in the order they become ready (blocks, then strips).  Which: all tiles of NWH passes a group and
-      // more (the lists in CSR form among them), NWH the smallest number from 2 for which the records fit (grid_geom::job_cap
-      // at Dmax discounts).
+      // tiles as jobs once their own strips have ended.  Which: all tiles of NWH passes a group and more (the lists in CSR
+      // form among them), NWH chosen below and raised until the records fit (grid_geom::job_cap at Dmax discounts).
       g->n_jobs[which] = 0;
       if (ok && n_tiles) {
         std::vector<unsigned> h_nw(n_tiles), off;
@@ -664,8 +663,15 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
         if (ok && cap) {
           unsigned hist[65] = {0};  // (an upper bound: the tiles of all strips)
           for (unsigned t = 0; t < n_tiles; t++) hist[h_nw[t] > 63 ? 63 : h_nw[t]]++;
-          unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 2);
-          if (nwh < 1) nwh = 1;
+          // NWH at the least: what a job takes off the critical path it adds to the chip's work (the tile is walked twice),
+          // which the fuller chip can afford less (MI355X, 10^6 pairs, N = 10^4, kernel ms without jobs / NWH = 3 / 4 / 6 /
+          // 8 / 12: 32 discounts 1.21 / 1.00 / 0.96 / 1.01 / 1.04 / 1.09, 40: 1.26 / 1.10 / 1.02 / 1.05 / 1.08 / 1.12,
+          // 48: 1.26 / 1.30 / 1.14 / 1.09 / 1.10 / 1.15, 64: 1.36 / 1.59 / 1.39 / 1.29 / 1.28 / 1.29)
+          unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 0);
+          if (nwh < 1) {
+            const double waves_per_simd = (double)gg.JW * D / (4.0 * stb_cu_count());
+            nwh = waves_per_simd <= 1.9 ? 4 : (waves_per_simd <= 2.7 ? 6 : 8);
+          }
           for (; nwh <= 63; nwh++) {
             unsigned c = 0;
             for (unsigned k = nwh; k <= 63; k++) c += hist[k];

@@ -1,5 +1,5 @@
 """A/B timing of the fused grid aterms (D discounts x 10^6 pairs) in ONE process: forms and tunings alternating,
-several rounds, medians of wall time and of the summing kernel's device time; every result is compared with the
+several rounds, medians of the best wall time and of the best device time of the summing kernel of each round (16 evaluations), and the mean over all of them; every result is compared with the
 first spec's.
 usage: python tools/ab_grid.py NMAX D "hb2,hb2@STB_HB2_C=4,hb,chain,..." [rounds] [profile]     (repo root, GPU box)
 A spec is a form name (auto, hb2 the grid form whose walking waves sum, hb tile workers sum, chain, twopass) followed by @ENV=VALUE settings."""
@@ -32,6 +32,7 @@ M = max(int(g.t.max()) + 1, 10)
 N = max(int(g.n.max()) + 1, M)
 x = np.ascontiguousarray(np.resize(synth.discount_grid(64), D) if D > 1 else np.array([0.5]))
 res = {s: ([], []) for s in specs}
+allk = {}
 ref = None
 for r in range(rounds):
     for s in specs:
@@ -46,13 +47,15 @@ for r in range(rounds):
         out = np.zeros(D)
         fb = L.stb_fill_fallbacks()
         capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(out)))
-        wall, kern = 1e9, 1e9
+        wall, kern, ks = 1e9, 1e9, []
         mf, ms, mt = C.c_float(), C.c_float(), C.c_float()
-        for _ in range(8):
+        for _ in range(16):
             t0 = time.perf_counter()
             capi.check(L.stb_groups_aterms_timed(h, capi.dp(x), D, capi.dp(out), C.byref(mf), C.byref(ms), C.byref(mt)))
             wall = min(wall, time.perf_counter() - t0)
             kern = min(kern, mf.value)
+            ks.append(mf.value)
+        allk.setdefault(s, []).extend(ks)
         L.stb_groups_free(h)
         if L.stb_fill_fallbacks() != fb:
             print(f"{s}: FELL BACK", flush=True)
@@ -68,4 +71,4 @@ for r in range(rounds):
 for s in specs:
     w, k = res[s]
     print(f"N={N} M={M} D={D} {profile} {s:56s} wall " + " ".join(f"{v:.3f}" for v in w) + f"  median {np.median(w):.3f} ms | fill kernel median {np.median(k):.3f} ms"
-          f" | {D * g.pairs / np.median(w) / 1e6:7.2f} G grid-evals/s", flush=True)
+          f" (all launches: mean {np.mean(allk[s]):.3f}, max {np.max(allk[s]):.3f}) | {D * g.pairs / np.median(w) / 1e6:7.2f} G grid-evals/s", flush=True)
