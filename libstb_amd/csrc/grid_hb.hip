@@ -5,7 +5,8 @@
 // is walked as in the halo-block fill (fill_hb.hip: a wave owns a strip of columns of one table for all rows,
 // block-floating cells, blocks of R rows behind a halo of R columns, hand-overs through LDS inside a workgroup and
 // through records in HBM between workgroups), but here the walking wave itself sums its strip's listed cells:
-// no tile workers, no second walk of a tile, no S1 vector (column 1 is the last element of strip 0's halo).
+// no tile workers, a second walk only of the few tiles that go to helper jobs, no S1 vector (column 1 is the last
+// element of strip 0's halo).
 //
 // What it is built around (MI355X, tools/ubench/rowpace.hip and the timelines in profiles/):
 //   * a lone wave walks a row of 2 columns per lane in 32 cycles, of 4 in 50, and one walking wave keeps a SIMD's
@@ -18,7 +19,10 @@
 //     four walking waves saturate: only every other row is staged, and a listed cell of a row in between is
 //     taken from the staged row above it by one step of the recurrence, in the look-up;
 //   * a look-up pass costs the same for 1 or 64 cells: groups of G rows are sized so that a pass is mostly full;
-//   * the log: exponent field + lane exponent go to an exact integer sum, the mantissa part to a double.
+//   * the log: exponent field + lane exponent go to an exact integer sum, the mantissa part to a double;
+//   * every strip of a table moves at the pace of the strips to its left, which hold most of the pairs: a tile that
+//     needs many look-up passes is only walked by its strip, which leaves its wave's state as a record, and summed --
+//     as a job -- by a wave whose own strip has ended (see run_job).
 #include <mutex>
 #include <vector>
 
@@ -72,7 +76,7 @@ struct gh_args {
   int JWa, b_begin, b_end;     // this phase: strips whose first block lies before b_end, blocks [b_begin, b_end)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
   int poll_nap;
-  int diag;                    // STB_GRID_DIAG: 4 no look-ups, 8 nothing staged either (results wrong)
+  int diag;                    // STB_GRID_DIAG: 4 no look-ups, 8 nothing staged either, 32 nobody takes the jobs (results wrong)
   unsigned long long *dbg;     // STB_HB_TIMELINE: table 0, [JW][NB + 2] (start, block starts, end)
 };
 
