@@ -1079,7 +1079,10 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   X.poll_nap = stb_env_int("STB_CHAIN_POLL_NAP", 2);
   HIPCHK(hipMemsetAsync(ws, 0, stb_align_up(sg.bytes, 16), st));
   *hdr_out = X.hdr;
-  stb_launch_s1(A, D, st);
+  if (stb_launch_s1(A, D, st)) return 1;
+  // (cell lists are built for one form's tiling: col0 says which -- the chain form's is 1)
+  if (dot && dot->item_ptr && dot->col0 != 1)
+    return stb_fail("stb_groups_aterms: cell lists built for another form (layout %d) handed to the chain form", dot->col0);
   X.cnt = dot ? dot->cnt : nullptr;
   X.item_ptr = dot ? dot->item_ptr : nullptr;
   X.ent_pos = dot ? dot->ent_pos : nullptr;

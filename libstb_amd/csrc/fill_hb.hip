@@ -1075,9 +1075,11 @@ struct hb_order_entry {
   int C, P, R, NB, JW, U;
   int r_ns, L_ns, lag_ns;
   unsigned *d_buf;  // [JW + 2] rec_off, then [n_tiles] order
+  unsigned long long used;  // the look-up that last handed it out
 };
 static std::mutex g_hb_mu;
 static std::vector<hb_order_entry> g_hb_orders;
+static unsigned long long g_hb_lookups = 0;
 
 static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigned **rec_off, const unsigned **order) {
   int dev = 0;
@@ -1085,9 +1087,11 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   const int r_ns = stb_env_int("STB_HB_ORDER_R", 30), L_ns = stb_env_int("STB_HB_ORDER_L", 3000),
             lag_ns = stb_env_int("STB_HB_ORDER_LAG", 300);
   std::lock_guard<std::mutex> lock(g_hb_mu);
-  for (const hb_order_entry &e : g_hb_orders)
+  g_hb_lookups++;
+  for (hb_order_entry &e : g_hb_orders)
     if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.R == g.R && e.NB == g.NB && e.JW == g.JW && e.U == g.U &&
         e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
+      e.used = g_hb_lookups;
       *rec_off = e.d_buf;
       *order = e.d_buf + g.JW + 2;
       return 0;
@@ -1134,9 +1138,18 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   e.d_buf = nullptr;
   HIPCHK(hipMalloc((void **)&e.d_buf, buf.size() * sizeof(unsigned) + 16));
   HIPCHK(hipMemcpy(e.d_buf, buf.data(), buf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-  if (g_hb_orders.size() >= 16) {  // (shapes come and go in tests: keep the table small)
-    (void)hipFree(g_hb_orders.front().d_buf);
-    g_hb_orders.erase(g_hb_orders.begin());
+  // (Shapes come and go: the table is kept small, the least recently used entry goes.  A caller holds the pointers it
+  // was handed without this lock until its kernel is launched -- another host thread may be in here meanwhile -- so an
+  // entry handed out within the last 32 look-ups is never freed: the table grows instead.)
+  e.used = g_hb_lookups;
+  if (g_hb_orders.size() >= 48) {
+    size_t old = g_hb_orders.size();
+    for (size_t i = 0; i < g_hb_orders.size(); i++)
+      if (g_hb_orders[i].used + 32 < g_hb_lookups && (old == g_hb_orders.size() || g_hb_orders[i].used < g_hb_orders[old].used)) old = i;
+    if (old < g_hb_orders.size()) {
+      (void)hipFree(g_hb_orders[old].d_buf);
+      g_hb_orders.erase(g_hb_orders.begin() + (long)old);
+    }
   }
   g_hb_orders.push_back(e);
   *rec_off = e.d_buf;

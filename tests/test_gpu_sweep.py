@@ -421,6 +421,32 @@ def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G, PH, env):
         assert orc.close(outs[0][d], want, TOL), (d, outs[0][d], want)
 
 
+@pytest.mark.parametrize("order", [(8, 4, 2, 8), (3, 8, 5)])
+def test_fused_aterms_helper_jobs_one_set_many_grid_sizes(monkeypatch, order):
+    """the helper jobs of the grid form are chosen when a set's cell lists are built (at its first evaluation) and sized
+    for Dmax tables: later evaluations of the same set with fewer or more discounts use the same jobs -- every one equals
+    stored tables + gather"""
+    L = capi.lib()
+    monkeypatch.setenv("STB_ATERMS_GRID", "1")
+    monkeypatch.setenv("STB_GRID_C", "4")
+    monkeypatch.setenv("STB_GRID_HELP_NW", "1")
+    g, n, t = _edge_pairs(4)
+    grid = np.ascontiguousarray(synth.discount_grid(64)[::8])
+    h = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), 900, 900, 8)
+    assert h, capi.last_error()
+    try:
+        fb = L.stb_fill_fallbacks()
+        for D in order:
+            x = np.ascontiguousarray(grid[:D])
+            got, want = np.zeros(D), np.zeros(D)
+            capi.check(L.stb_groups_aterms(h, capi.dp(x), D, capi.dp(got)))
+            capi.check(L.stb_groups_aterms_tables(h, capi.dp(x), D, capi.dp(want)))
+            assert orc.close(got, want, 1e-12), (D, got, want)
+        assert L.stb_fill_fallbacks() == fb
+    finally:
+        L.stb_groups_free(h)
+
+
 def test_fused_aterms_the_spine_sums_log_zero_pairs(monkeypatch):
     """a pair outside the table's support has S_S = log 0 (lib/stable.c:948-949): the sum is -inf, as the
     reference's is, in the form that never gathers"""
