@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
       bool got = false;
       for (int tries = 0; tries < GH_JQ && !got; tries++) {
         const int q = q_next;
+        // (only strips of workgroups with LOWER tickets than this one -- the strip-major tickets' rule: whatever a wave
+        // waits for belongs to a workgroup that started before its own and is running or through)
+        if (q / P >= j) q_off |= 1ull << q;
         if ((q_off >> q) & 1ull) {
           q_next = (q_next + 1 == GH_JQ) ? 0 : q_next + 1;
           continue;

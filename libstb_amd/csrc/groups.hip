@@ -680,11 +680,10 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
           std::vector<unsigned> jobs, tjob(n_tiles, 0xffffffffu);
           stb_grid_tile_offsets(gg, off);
           const int UCg = gg.U * gg.C;
-          // (only tiles of strips whose workgroups are on the chip from the launch's first moment -- one workgroup per
-          // compute unit at the least, handed the lowest tickets -- so that whoever waits for a record waits for a wave
-          // that is running or through: Dmax tables x jlim / P workgroups <= compute units)
-          int jlim = (stb_cu_count() / (g->Dmax > 0 ? g->Dmax : 1)) * gg.P;
-          if (jlim > 64) jlim = 64;  // (GH_JQ of grid_hb.hip: a queue of jobs per strip)
+          // (a job is taken by a wave of a workgroup further right -- one with a higher ticket, for which the strip's own
+          // workgroup is running or through: the strips of a table's last workgroup have no jobs; GH_JQ = 64 queues)
+          int jlim = ((gg.JW - 1) / gg.P) * gg.P;
+          if (jlim > 64) jlim = 64;
           std::vector<unsigned> qoff(64 + 1, 0u);
           if (nwh <= 63) {
             // strip after strip, a strip's tiles by block: a queue per strip
