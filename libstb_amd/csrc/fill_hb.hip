@@ -944,7 +944,9 @@ int stb_cu_count() {  // compute units of the current device (256 on an MI355X)
 }
 
 // vt: the V table, whose rows include the diagonal (columns up to min(N, M) instead of min(N - 1, M))
-static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false, bool vt = false) {
+// (sum_C: 0 a storing fill; 2 or 4: a summing fill whose cell lists are laid out for strips of that many columns per lane)
+static hb_geom hb_geometry(unsigned N, unsigned M, int D, int sum_C = 0, bool vt = false) {
+  const bool summing = sum_C != 0;
   hb_geom g;
   memset(&g, 0, sizeof(g));
   g.ok = false;
@@ -960,8 +962,8 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, bool summing = false, 
     g.C = stb_env_int("STB_HB_C", waves2 <= (uint64_t)cus * 5 / 4 ? 2 : 4);  // (320 on 256 compute units)
   }
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
-  // (a summing fill's cell lists are laid out for one strip shape, whatever the number of discounts)
-  if (summing) g.C = 4;
+  // (a summing fill's cell lists are laid out for one strip shape, whatever the number of discounts: stb_hb_sum_C)
+  if (summing) g.C = (sum_C == 2) ? 2 : 4;
   g.P = 4;  // (one spine wave per SIMD: two on one slow each other by a third; see below)
   // a block is a renormalisation period (or less): rows in eights, halo lanes R / C <= 32
   int Pc = stb_period_rows(N);
@@ -1159,8 +1161,19 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
 
 // what the builder of a summing fill's cell lists has to know: the shape of the tiles and where a strip's
 // records start (device array of JW + 2 words; a tile's record index is its item base)
-int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
-  const hb_geom g = hb_geometry(N, M, D, true);
+// columns per lane of a summing fill's strips for a set that is evaluated with up to Dmax discounts: 2 -- the faster walk,
+// 22 against 33 ns a row, which is what a grid of a few discounts waits for -- while the spine waves of Dmax tables get a
+// SIMD each with room to spare for the tile workers (MI355X, kernel ms, 2 against 4 columns: N = 10^4, 2 discounts 0.296
+// against 0.331, 4: 0.337 against 0.333; N = 4000, 2: 0.156 against 0.164, 3: 0.137 against 0.145); 4 beyond
+int stb_hb_sum_C(unsigned N, unsigned M, int Dmax) {
+  const unsigned cmax = (M < N - 1) ? M : N - 1;
+  const uint64_t waves2 = (uint64_t)(Dmax > 0 ? Dmax : 1) * ((cmax - 1 + 79) / 80);
+  const int c = stb_env_int("STB_HB_DOT_C", waves2 <= (uint64_t)stb_cu_count() * 5 / 4 ? 2 : 4);
+  return c == 2 ? 2 : 4;
+}
+
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int sum_C) {
+  const hb_geom g = hb_geometry(N, M, D, sum_C == 2 ? 2 : 4);
   if (!g.ok || g.R % HB_DOT_GR != 0 || g.R / HB_DOT_GR > HB_DOT_NQ) return 1;
   const unsigned *rec_off = nullptr, *order = nullptr;
   if (hb_order_list(g, N, M, &rec_off, &order)) return 1;
@@ -1182,7 +1195,7 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out) {
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st, int out_kind) {
   const unsigned N = A.N, M = A.M;
   if (out_kind < 0 || out_kind > 3 || (out_kind && dot)) return stb_fail("stb_fill: output kind %d", out_kind);
-  const hb_geom g = hb_geometry(N, M, D, dot != nullptr, (out_kind & 2) != 0);
+  const hb_geom g = hb_geometry(N, M, D, dot ? (dot->geom_C == 2 ? 2 : 4) : 0, (out_kind & 2) != 0);
   if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
   if (dot && (!dot->item_ptr || dot->col0 != 3))
@@ -1272,6 +1285,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
     switch (g.C) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 2: STB_LAUNCH_SHM((k_fill_hb<2, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
     }
   } else {

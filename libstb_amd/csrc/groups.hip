@@ -59,6 +59,7 @@ struct stb_groups {
   unsigned *d_jobs[STB_NLISTS];                // [3], [4]: the tiles whose cells are left to helper waves, in the order they become ready
   unsigned *d_tjob[STB_NLISTS];                // [3], [4]: per tile its place in d_jobs, or 0xffffffff
   unsigned n_jobs[STB_NLISTS];
+  int hb_sum_C;                                // columns per lane of the halo-block summing form's strips for this set (stb_hb_sum_C at its creation)
   uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
   int sparse;
   int reused;  // stb_groups_update_restaurants has been called: the same pairs serve call after call
@@ -264,6 +265,7 @@ static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, 
   g->N = N;
   g->M = M;
   g->Dmax = Dmax;
+  g->hb_sum_C = stb_hb_sum_C(N, M, Dmax);
   g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
   GCHK(hipStreamCreate(&g->st));
   for (auto &e : g->ev) GCHK(hipEventCreate(&e));
@@ -486,7 +488,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
   const uint64_t G = g->G;
   hb_dot_info H;
   memset(&H, 0, sizeof(H));
-  if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
+  if (which == 2 && stb_hb_dot_info(N, M, g->Dmax, &H, g->hb_sum_C)) return stb_fail("stb_groups_aterms: no halo-block geometry for N=%u M=%u", N, M);
   grid_geom gg;
   memset(&gg, 0, sizeof(gg));
   if (which >= 3) {
@@ -728,7 +730,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       const size_t ckp = stb_launch_ck ? (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax) : 0;
       if (ckp > g->dotp_elems) g->dotp_elems = ckp;
       hb_dot_info H2;
-      if (stb_hb_dot_info(N, M, g->Dmax, &H2) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
+      if (stb_hb_dot_info(N, M, g->Dmax, &H2, g->hb_sum_C) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
         g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
       // (the self-summing form: two sums per strip, strips of 80 columns at the narrowest)
       size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
@@ -852,6 +854,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
   req.ent_cnt = g->d_ent_cnt[which];
   req.nsg = g->nsg;
   req.col0 = which >= 3 ? 4 : 3;
+  if (which == 2) req.geom_C = g->hb_sum_C;  // (the strip shape the set's lists were built for)
   if (which >= 3) {
     req.geom_C = which == 3 ? 2 : 4;
     req.geom_R = g->list_R[which];
@@ -1054,14 +1057,14 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
     grid_geom gg;
     if (force != 0 && stb_grid_geometry(g->N, g->M, D, &gg) == 0) {
       hb_dot_info H;
-      const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= hb_max_spine();
+      const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H, g->hb_sum_C) == 0 && H.n_spine <= hb_max_spine();
       const bool sparse_pairs = (double)g->G <= 0.04 * (double)stb_table_cells(g->N, g->M);
       if (force > 0 || (!hb_range && sparse_pairs && stb_env_int("STB_ATERMS_HB", 1))) which = (gg.C == 2) ? 3 : 4;
     }
   }
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {
     hb_dot_info H;
-    if (stb_hb_dot_info(g->N, g->M, D, &H) == 0 && H.n_spine <= hb_max_spine()) which = 2;
+    if (stb_hb_dot_info(g->N, g->M, D, &H, g->hb_sum_C) == 0 && H.n_spine <= hb_max_spine()) which = 2;
   }
   if (fuse && stb_env_int("STB_ATERMS_SPARSE", 1) && (!g->fused_ready || g->sparse) && groups_fused_setup_sparse(g, which, D)) return 1;
   if (fuse && !g->fused_ready && groups_fused_setup(g)) return 1;

@@ -176,7 +176,8 @@ struct hb_dot_info {  // the tiles of the summing halo-block form (cell lists: i
   unsigned n_tiles, n_rec, n_spine;
   const unsigned *rec_off;     // device: first record of strip index s = j + 1 (s = 0: the halo of strip 0)
 };
-int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out);
+int stb_hb_sum_C(unsigned N, unsigned M, int Dmax);  // columns per lane of the summing form's strips for a set of up to Dmax discounts
+int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int sum_C);
 
 // the fused grid evaluation in which the walking waves sum their own strips' listed cells (grid_hb.hip)
 struct grid_geom {

@@ -255,13 +255,17 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
             L.stb_groups_free(h)
 
 
-def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
-    """the default for a grid of discounts: the summing fill as k_fill_hb<4, DOT> (a spine that walks blocks of rows
-    alone + tile workers that sum their tiles' listed cells; cell lists keyed by (tile, group of 4 rows)).  Same
+@pytest.mark.parametrize("sum_C", ["2", "4"])
+def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir, sum_C):
+    """the default for a grid of discounts: the summing fill as k_fill_hb<C, DOT> (a spine that walks blocks of rows
+    alone + tile workers that sum their tiles' listed cells; cell lists keyed by (tile, group of 8 rows)), with strips of
+    2 columns per lane (a set of few discounts: the faster walk) or 4.  Same
     sums as the chain form to rounding -- against the reference's aterms golden values at 1e-10, against the
     chain form, run to run bit for bit -- with edge pairs, several tables, and a set whose chain-form lists are
     built later on the same object (both layouts live side by side)."""
     L = capi.lib()
+    monkeypatch.setenv("STB_HB_DOT_C", sum_C)
+    UC = 208 if sum_C == "4" else 80
     for name in ("mid_wide", "small_realistic"):
         spec = load(golden_dir, "aterms.json").get(name)
         if spec is None:
@@ -304,9 +308,10 @@ def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir):
     n[6:40], t[6:40] = 400, 123
     n[40], t[40] = 49, 2       # last row of block 0
     n[41], t[41] = 50, 2       # first row of block 1
-    n[42], t[42] = 300, 209    # last own column of strip 0 (208 own columns from column 2)
-    n[43], t[43] = 300, 210    # first own column of strip 1
-    n[44], t[44] = 211, 210    # next to the diagonal in strip 1's first block
+    n[42], t[42] = 300, UC + 1    # last own column of strip 0 (UC own columns from column 2)
+    n[43], t[43] = 300, UC + 2    # first own column of strip 1
+    n[44], t[44] = UC + 3, UC + 2  # next to the diagonal in strip 1's first block
+    n[45], t[45] = 301, UC + 2    # ... and in an odd row of a group (one step below the staged row)
     x = np.array([0.11, 0.5, 0.83])
     outs = []
     monkeypatch.setenv("STB_ATERMS_GRID", "0")
