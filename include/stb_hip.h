@@ -193,6 +193,32 @@ int stb_groups_aterms_device(stb_groups_t *g, const double *x_host, int D, doubl
 int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host);
 /* new per-restaurant totals T[I] and concentrations bpar[I] for the same pairs */
 int stb_groups_update_restaurants(stb_groups_t *g, const uint32_t *T, const double *bpar);
+/* NEW PAIRS for a set of the same shape (I restaurants, G = sum K pairs): what a caller whose counts change between
+ * calls does instead of stb_groups_free + stb_groups_create -- the reference's own Gibbs loop rewrites t[j][i] and T[j]
+ * in every iteration (test/demo.c:405-445) and then resamples a (:478-480).  No allocation, no sort: the pairs are
+ * copied once into pinned memory, piece by piece, each piece on its way to the device while the caller hands over the
+ * next; the cell lists of the fused evaluation are rebuilt on the device when the next evaluation is queued.
+ *   stb_groups_pairs_begin(g)                       waits for whatever still uses the old pairs
+ *   stb_groups_pairs_put(g, n, t, count, &mn, &mt)  the next `count` pairs, in order (e.g. restaurant after restaurant:
+ *                                                   n[i], t[i], K[i]); mn / mt (may be NULL) receive the largest n and t
+ *                                                   so far -- what samplea derives its table bounds from
+ *   stb_groups_pairs_commit(g, T, bpar, N, M)       all G pairs are in; T, bpar (both or neither NULL) new restaurant
+ *                                                   totals; N, M the table bounds (0, 0: unchanged).  New bounds
+ *                                                   re-size what depends on them (buffers come from the library's cache)
+ * stb_groups_update_pairs = begin + put + commit(NULL, NULL, 0, 0) from flat arrays.  A set may be created EMPTY
+ * (stb_groups_create with nflat = tflat = NULL, and N = M = 0 when the bounds are not known yet) and filled this way.
+ * Results are the same bits as those of a set created from the same pairs, in whatever order they are handed over. */
+int stb_groups_pairs_begin(stb_groups_t *g);
+int stb_groups_pairs_put(stb_groups_t *g, const uint32_t *n, const uint16_t *t, uint64_t count, unsigned *maxn, unsigned *maxt);
+/* all G pairs at once from samplea's ragged arrays (restaurant i: n[i][0..K[i]), t[i][0..K[i])), between begin and
+ * commit instead of the puts: a few host threads of the library's own copy (STB_PUT_THREADS, default 4; 0: the caller's
+ * thread alone) while the calling thread hands what is copied to the device */
+int stb_groups_pairs_put_ragged(stb_groups_t *g, int I, const int *K, uint32_t *const *n, uint16_t *const *t, unsigned *maxn, unsigned *maxt);
+int stb_groups_pairs_commit(stb_groups_t *g, const uint32_t *T, const double *bpar, unsigned N, unsigned M);
+int stb_groups_update_pairs(stb_groups_t *g, const uint32_t *nflat, const uint16_t *tflat);
+/* how often, in this process, a fused evaluation (halo-block, grid or chain form) gave up waiting for a neighbour and
+ * was repeated through stored tables (stb_fill_fallbacks counts the repeated FILLS of the calling thread) */
+unsigned stb_groups_fallbacks(void);
 /* what the set was created with (any pointer may be NULL) */
 int stb_groups_shape(const stb_groups_t *g, int *I, uint64_t *G, unsigned *N, unsigned *M, int *Dmax);
 /* pieces of the same evaluation, for timing: ms of device time per stage (may be NULL) */

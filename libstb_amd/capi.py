@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     sig("stb_fill_Sf", i, [c_double_p, i, u, u, vp, u64, vp, u64, vp, sz, vp])
     sig("stb_fill_takes_kind", i, [u, u, i, i])
     sig("stb_bterms_create", vp, [c_u32_p, i])
+    sig("stb_bterms_update", i, [vp, c_u32_p, i])
     sig("stb_bterms_eval", i, [vp, c_double_p, i, d, d, d, c_double_p])
     sig("stb_bterms_free", None, [vp])
     sig("stb_table_to_float", i, [vp, vp, u64, vp])
@@ -128,6 +129,12 @@ def lib() -> C.CDLL:
     sig("stb_groups_wait", i, [vp])
     sig("stb_groups_aterms_device", i, [vp, c_double_p, i, vp, vp])
     sig("stb_groups_update_restaurants", i, [vp, c_u32_p, c_double_p])
+    sig("stb_groups_pairs_begin", i, [vp])
+    sig("stb_groups_pairs_put", i, [vp, c_u32_p, c_u16_p, u64, C.POINTER(u), C.POINTER(u)])
+    sig("stb_groups_pairs_put_ragged", i, [vp, i, c_int_p, vp, vp, C.POINTER(u), C.POINTER(u)])
+    sig("stb_groups_pairs_commit", i, [vp, c_u32_p, c_double_p, u, u])
+    sig("stb_groups_update_pairs", i, [vp, c_u32_p, c_u16_p])
+    sig("stb_groups_fallbacks", C.c_uint, [])
     sig("stb_groups_shape", i, [vp, c_int_p, C.POINTER(u64), C.POINTER(u), C.POINTER(u), c_int_p])
     sig("stb_sampler_cache_clear", None, [])
     sig("stb_groups_aterms_timed", i, [vp, c_double_p, i, c_double_p, c_float_p, c_float_p, c_float_p])

@@ -6,78 +6,14 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "stb_common.h"
 
 void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off);  // grid_hb.hip
 
-#define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
-#define STB_NLISTS 5
-#define STB_WS_FORM 4096  // lean flow: the discounts at the start of d_ws_fill, the form's workspace from here
-
-// ------------------------------------------------------------------------------------------------
-// device-resident group set
-
-struct stb_groups {
-  int dev;  // the device everything below lives on
-  int I;
-  uint64_t G;
-  unsigned N, M;
-  int Dmax;
-  uint32_t *d_n, *d_T;
-  uint16_t *d_t;
-  double *d_bpar;
-  double *d_tables, *d_S1, *d_out;  // d_out: [2][Dmax]
-  uint64_t tstride;
-  void *d_ws_fill, *d_ws_sweep, *d_ws_terms;
-  size_t ws_fill, ws_sweep, ws_terms;
-  hipStream_t st;
-  hipEvent_t ev[4];
-  // fused evaluation (stb_groups_aterms with the chain form): occurrence count per table cell, the
-  // pairs that do not address a table cell (t = 1, t = n, out of bounds), partial sums of the fill
-  unsigned *d_cnt;
-  uint32_t *d_n2;
-  uint16_t *d_t2;
-  uint64_t G2;
-  double *d_dotp;
-  size_t dotp_elems;
-  int fused, fused_ready;
-  // sparse form of the fused evaluation: CSR of the occurring cells per item, in several layouts, each built when
-  // first needed: [0] (trip, 64-column slice from column 1) for k_fill_chain, [1] the same from column 2 for
-  // k_fill_ck, [2] (tile, group of 4 rows) for k_fill_hb's tile workers, [3] / [4] (strip, block, group of G rows)
-  // for k_fill_hb's self-summing spine with 2 / 4 columns per lane (column 1 -- the pairs with t = 1 -- included)
-  unsigned *d_item_ptr[STB_NLISTS];
-  unsigned short *d_ent_pos[STB_NLISTS];
-  unsigned *d_ent_cnt[STB_NLISTS];
-  unsigned nsg;
-  int lists_ready[STB_NLISTS];
-  int list_R[STB_NLISTS], list_G[STB_NLISTS];  // [3], [4]: the block and group length the list was built for
-  unsigned *d_tile_off[STB_NLISTS];            // [3], [4]: first tile of every strip (grid_hb.hip)
-  unsigned *d_dense[STB_NLISTS];               // [3], [4]: the listed cells as words per lane, group after group: what the walk reads
-  unsigned *d_tinfo[STB_NLISTS];               // [3], [4]: per tile, where its words start and how many a group has
-  unsigned *d_jobs[STB_NLISTS];                // [3], [4]: the tiles whose cells are left to helper waves, in the order they become ready
-  unsigned *d_tjob[STB_NLISTS];                // [3], [4]: per tile its place in d_jobs, or 0xffffffff
-  unsigned n_jobs[STB_NLISTS];
-  int hb_sum_C;                                // columns per lane of the halo-block summing form's strips for this set (stb_hb_sum_C at its creation)
-  uint64_t n_inf;                              // pairs whose S_S is log 0 (t = 0, t > n, outside the bounds)
-  int sparse;
-  int reused;  // stb_groups_update_restaurants has been called: the same pairs serve call after call
-  // an evaluation that has been queued and not yet waited for (stb_groups_aterms_async / stb_groups_wait)
-  double *h_out;  // pinned, [2][Dmax] + 2: what the stream copies the sums to (lean flow: totals, then the fill's error words)
-  double *h_out_dev;           // the device's address of it
-  size_t ws_zero;              // bytes from the start of d_ws_fill + STB_WS_FORM known to be zero (lean flow)
-  int pend_lean;               // the queued evaluation took the lean flow
-  double *pend_user;           // stb_groups_aterms_device: where the totals go on the device (or null)
-  double pend_host[STB_TERMS_DMAX];  // ... and where stb_groups_wait puts them on the host meanwhile
-  hipEvent_t ev_done;
-  hipEvent_t ev_dep;
-  int pending, pend_D, pend_fuse, pend_v;
-  int sel_which;  // the list layout aterms_prepare chose for a fused evaluation in the halo-block form
-  double *pend_out;
-  double pend_x[STB_TERMS_DMAX];
-  last_fill pend_fill;
-};
+#include "groups.h"
 
 // The sweep gathers table[row(n) + t]; pairs arrive in restaurant order, i.e. random in (n,t), and a
 // random 8-byte gather moves a whole 64-byte sector.  Sorting the pairs once by (n,t) (they are reused
@@ -144,10 +80,16 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                   g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
                   g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
                   g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4],
-                  g->d_tinfo[3], g->d_tinfo[4], g->d_jobs[3], g->d_jobs[4], g->d_tjob[3], g->d_tjob[4]};
+                  g->d_tinfo[3], g->d_tinfo[4], g->d_jobs[3], g->d_jobs[4], g->d_tjob[3], g->d_tjob[4],
+                  g->d_slab, g->d_icnt, g->d_ninf, g->d_scan_tmp, g->d_tnw[3], g->d_tnw[4], g->d_twords[3], g->d_twords[4], g->d_toff[3], g->d_toff[4]};
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
+  stb_pool_free(g->h_pn);
+  stb_pool_free(g->h_pt);
+  stb_pool_free(g->h_T);
+  stb_pool_free(g->h_bpar);
+  stb_pool_free(g->h_nw);
   if (g->ev_dep) (void)hipEventDestroy(g->ev_dep);
   if (g->ev_done) (void)hipEventDestroy(g->ev_done);
   for (auto &e : g->ev)
@@ -193,7 +135,8 @@ __global__ __launch_bounds__(256) void k_dot_reduce(const double *dotp, int part
 // terms' partial sums, each in a fixed order, their total written to pinned host memory together with the fill's
 // error words -- so that the host waits ONCE and copies nothing.
 __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts, int mode, const dd_t *tpart, int nbt, unsigned long long inf,
-                                                   const unsigned *hdr, double *out_dev, double *out_host, int Dmax, double *out_user) {
+                                                   const unsigned long long *inf_dev, const unsigned *hdr, double *out_dev, double *out_host, int Dmax,
+                                                   double *out_user) {
   __shared__ dd_t red[4];
   __shared__ double ks[4];
   const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -222,6 +165,7 @@ __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts
       dd_add(tot, k * LN2_LO);
       dd_add(tot, k * LN2_HI);
     }
+    if (inf_dev) inf += *inf_dev;  // (lists built from the count slab: counted on the device)
     const double dots = inf ? -HUGE_VAL : tot.hi + tot.lo;
     const double terms = tv.hi + tv.lo;
     out_dev[d] = dots;
@@ -237,6 +181,46 @@ __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts
 
 int stb_restaurant_partials(const double *x_host, int D, const uint32_t *d_T, const double *d_bpar, uint64_t I, void *d_ws,
                             size_t ws_bytes, double *a_out, const dd_t **partial_out, int *nb_out, hipStream_t st);  // sweep_terms.hip
+
+// What depends on the table bounds.  A Gibbs sampler's largest count moves from call to call, and with it the bounds
+// of the table samplea builds (lib/samplea.c:186-208): everything below is given back to the buffer cache and asked
+// for again in the new sizes (the cache hands a buffer of up to 5/4 the size out again).
+int stb_groups_set_bounds(stb_groups_t *g, unsigned N, unsigned M) {
+  if (g->have_bounds && g->N == N && g->M == M) return 0;
+  if (N < 1 || M < 1) return stb_fail("stb_groups: table bounds N=%u M=%u", N, M);
+  HIPCHK(hipStreamSynchronize(g->st));
+  stb_lists_drop(g, false);
+  void **ptrs[] = {(void **)&g->d_tables, (void **)&g->d_S1, &g->d_ws_fill};
+  for (void **p : ptrs) {
+    stb_pool_free(*p);
+    *p = nullptr;
+  }
+  g->N = N;
+  g->M = M;
+  g->hb_sum_C = stb_hb_sum_C(N, M, g->Dmax);
+  g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
+  g->ws_fill = stb_fill_workspace_bytes(N, M, g->Dmax);
+  g->ws_zero = 0;
+  HIPCHK(stb_pool_malloc((void **)&g->d_ws_fill, g->ws_fill));
+  g->fused = stb_env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);  // set up on first use
+  g->have_bounds = 1;
+  return 0;
+}
+
+// The tables of the evaluations that store them (one discount on a set without lists, the fallback of a fused
+// evaluation that gave up, stb_groups_aterms_tables) are asked for when the first of those comes: a grid of 64
+// discounts at N = M = 10^4 is 27 GB of tables that the fused evaluation never touches.
+static int ensure_tables(stb_groups_t *g) {
+  if (g->d_tables && g->d_S1 && g->d_ws_sweep) return 0;
+  if (!g->d_tables && stb_pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * g->Dmax) != hipSuccess)
+    return stb_fail("stb_groups_aterms: out of device memory for %d tables of %u x %u", g->Dmax, g->N, g->M);
+  if (!g->d_S1 && stb_pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)g->N * g->Dmax) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  if (!g->d_ws_sweep) {
+    g->ws_sweep = stb_sweep_workspace_bytes(g->G, g->Dmax);
+    if (stb_pool_malloc((void **)&g->d_ws_sweep, g->ws_sweep) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  }
+  return 0;
+}
 
 static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, const uint32_t *nflat,
                                         const uint16_t *tflat, const double *bpar, unsigned N, unsigned M, int Dmax) {
@@ -262,44 +246,54 @@ static stb_groups_t *groups_create_here(int I, const int *K, const uint32_t *T, 
   }
   g->I = I;
   g->G = G;
-  g->N = N;
-  g->M = M;
   g->Dmax = Dmax;
-  g->hb_sum_C = stb_hb_sum_C(N, M, Dmax);
-  g->tstride = (stb_table_elems(N, M) + 31) & ~31ull;
   GCHK(hipStreamCreate(&g->st));
   for (auto &e : g->ev) GCHK(hipEventCreate(&e));
   GCHK(stb_pool_malloc((void **)&g->d_n, sizeof(uint32_t) * (G ? G : 1)));
   GCHK(stb_pool_malloc((void **)&g->d_t, sizeof(uint16_t) * (G ? G : 1)));
   GCHK(stb_pool_malloc((void **)&g->d_T, sizeof(uint32_t) * (I > 0 ? I : 1)));
   GCHK(stb_pool_malloc((void **)&g->d_bpar, sizeof(double) * (I > 0 ? I : 1)));
-  GCHK(stb_pool_malloc((void **)&g->d_tables, sizeof(double) * g->tstride * Dmax));
-  GCHK(stb_pool_malloc((void **)&g->d_S1, sizeof(double) * (size_t)N * Dmax));
+  GCHK(stb_pool_malloc((void **)&g->h_T, sizeof(uint32_t) * (I > 0 ? I : 1), 1));
+  GCHK(stb_pool_malloc((void **)&g->h_bpar, sizeof(double) * (I > 0 ? I : 1), 1));
   GCHK(stb_pool_malloc((void **)&g->d_out, sizeof(double) * 2 * Dmax));
   GCHK(stb_pool_malloc((void **)&g->h_out, sizeof(double) * (2 * Dmax + 2), 1));
   GCHK(hipHostGetDevicePointer((void **)&g->h_out_dev, g->h_out, 0));
   GCHK(hipEventCreateWithFlags(&g->ev_dep, hipEventDisableTiming));
   GCHK(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
-  g->ws_fill = stb_fill_workspace_bytes(N, M, Dmax);
-  g->ws_sweep = stb_sweep_workspace_bytes(G, Dmax);
   g->ws_terms = stb_terms_workspace_bytes((uint64_t)I, Dmax);
-  GCHK(stb_pool_malloc((void **)&g->d_ws_fill, g->ws_fill));
-  GCHK(stb_pool_malloc((void **)&g->d_ws_sweep, g->ws_sweep));
   GCHK(stb_pool_malloc((void **)&g->d_ws_terms, g->ws_terms));
-  if (G) {
-    GCHK(hipMemcpy(g->d_n, nflat, sizeof(uint32_t) * G, hipMemcpyHostToDevice));
-    GCHK(hipMemcpy(g->d_t, tflat, sizeof(uint16_t) * G, hipMemcpyHostToDevice));
-  }
-  if (I > 0) {
-    GCHK(hipMemcpy(g->d_T, T, sizeof(uint32_t) * I, hipMemcpyHostToDevice));
-    GCHK(hipMemcpy(g->d_bpar, bpar, sizeof(double) * I, hipMemcpyHostToDevice));
-  }
-  if (stb_env_int("STB_SORT_PAIRS", 1) && sort_pairs(g->d_n, g->d_t, G, g->st)) {
+  if (N && M && stb_groups_set_bounds(g, N, M)) {
     stb_groups_free(g);
     return nullptr;
   }
-  g->fused = stb_env_int("STB_ATERMS_FUSED", 1) && N >= 3 && N < (1u << 27);  // set up on first use
+  // (a set may be made empty -- no pairs, or no bounds either -- and filled with stb_groups_pairs_begin / _put / _commit)
+  if (nflat && tflat) {
+    if (!g->have_bounds) {
+      stb_fail("stb_groups_create: pairs without table bounds");
+      stb_groups_free(g);
+      return nullptr;
+    }
+    int bad = stb_groups_pairs_begin(g);
+    for (uint64_t o = 0; !bad && o < G; o += (1u << 18)) bad = stb_groups_pairs_put(g, nflat + o, tflat + o, G - o < (1u << 18) ? G - o : (1u << 18), nullptr, nullptr);
+    if (!bad) bad = stb_groups_pairs_commit(g, T, bpar, N, M);
+    if (bad) {
+      stb_groups_free(g);
+      return nullptr;
+    }
+  } else if (T && bpar && I > 0 && stb_groups_update_restaurants(g, T, bpar)) {
+    stb_groups_free(g);
+    return nullptr;
+  }
+  if (T && bpar) g->reused = 0;  // (what stb_groups_update_restaurants marks is a set that serves call after call)
   return g;
+}
+
+// the pairs in (n, t) order, for the gather over stored tables (on first need: see lists.hip)
+int stb_groups_sort_pairs(stb_groups_t *g) {
+  if (g->sorted || !stb_env_int("STB_SORT_PAIRS", 1)) return 0;
+  if (sort_pairs(g->d_n, g->d_t, g->G, g->st)) return 1;
+  g->sorted = 1;
+  return 0;
 }
 
 // The set lives on the device stb_get_device() names (stb_set_device / STB_DEVICE / the runtime's
@@ -481,6 +475,110 @@ __global__ void k_item_ptr(const unsigned *item, const unsigned *runs, unsigned 
   ptr[i] = lo;
 }
 
+// partial sums of the fused forms: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
+// halo-block form, two per strip and per helper job for the grid form
+int stb_groups_alloc_dotp(stb_groups_t *g) {
+  const unsigned N = g->N, M = g->M;
+  g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
+  const size_t ckp = stb_launch_ck ? (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax) : 0;
+  if (ckp > g->dotp_elems) g->dotp_elems = ckp;
+  hb_dot_info H2;
+  if (stb_hb_dot_info(N, M, g->Dmax, &H2, g->hb_sum_C) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems) g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
+  // (the self-summing form: two sums per strip, strips of 80 columns at the narrowest)
+  size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
+  {
+    // (... and two per tile left to helper waves: at most grid_geom::job_cap of them)
+    grid_geom gj;
+    for (int dd : {1, g->Dmax})
+      if (stb_grid_geometry(N, M, dd, &gj) == 0 && (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2 > hb2)
+        hb2 = (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2;
+  }
+  if (hb2 > g->dotp_elems) g->dotp_elems = hb2;
+  if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  return 0;
+}
+
+// the dense layout of the grid form from the CSR lists, on the set's stream: stage 0 the words per tile and their
+// prefix sum, stage 1 the words themselves (lists.hip asks for the words per tile in between)
+void stb_lists_dense_kernels(stb_groups_t *g, int which, unsigned n_tiles, unsigned NQ, unsigned nitems, unsigned *tnw, unsigned *twords, unsigned *toff,
+                             int stage) {
+  if (!n_tiles) return;
+  if (stage == 0) {
+    hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ, tnw, twords);
+    size_t tb = g->scan_tmp_bytes;
+    (void)rocprim::exclusive_scan(g->d_scan_tmp, tb, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st);
+  } else if (nitems) {
+    hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which], g->d_ent_cnt[which], nitems, NQ,
+                       tnw, toff, g->d_dense[which], g->d_tinfo[which]);
+  }
+}
+
+// The tiles whose listed cells the strip's own wave does not look up: every strip of a table moves at the pace of
+// the strips to its left, and those hold most of the pairs (t uniform below n: columns like log) -- several
+// passes a group where the average strip has one.  Such a tile is only walked by its strip, which leaves the
+// state of its wave before the block as a record; waves whose strips the diagonal has not reached yet take the
+// tiles as jobs once their own strips have ended.  Which: all tiles of NWH passes a group and more (the lists in CSR
+// form among them), NWH chosen below and raised until the records fit (grid_geom::job_cap at Dmax discounts).
+// h_nw: words per group of every tile (host).  The lists go to the device on the set's stream.
+int stb_lists_jobs_from(stb_groups_t *g, int which, int D, const grid_geom &gg, const unsigned *h_nw) {
+  const unsigned n_tiles = gg.n_tiles;
+  g->n_jobs[which] = 0;
+  const unsigned cap = stb_grid_job_cap(gg.C, g->Dmax, n_tiles, gg.phases);
+  if (!cap || !n_tiles) return 0;
+  unsigned hist[65] = {0};  // (an upper bound: the tiles of all strips)
+  for (unsigned t = 0; t < n_tiles; t++) hist[h_nw[t] > 63 ? 63 : h_nw[t]]++;
+  // NWH at the least: what a job takes off the critical path it adds to the chip's work (the tile is walked twice),
+  // which the fuller chip can afford less (MI355X, 10^6 pairs, N = 10^4, kernel ms without jobs / NWH = 3 / 4 / 6 /
+  // 8 / 12: 32 discounts 1.21 / 1.00 / 0.96 / 1.01 / 1.04 / 1.09, 40: 1.26 / 1.10 / 1.02 / 1.05 / 1.08 / 1.12,
+  // 48: 1.26 / 1.30 / 1.14 / 1.09 / 1.10 / 1.15, 64: 1.36 / 1.59 / 1.39 / 1.29 / 1.28 / 1.29)
+  unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 0);
+  if (nwh < 1) {
+    const double waves_per_simd = (double)gg.JW * D / (4.0 * stb_cu_count());
+    nwh = waves_per_simd <= 1.9 ? 4 : (waves_per_simd <= 2.7 ? 6 : 8);
+  }
+  for (; nwh <= 63; nwh++) {
+    unsigned c = 0;
+    for (unsigned k = nwh; k <= 63; k++) c += hist[k];
+    if (c <= cap) break;
+  }
+  std::vector<unsigned> jobs, tjob(n_tiles, 0xffffffffu), off;
+  stb_grid_tile_offsets(gg, off);
+  const int UCg = gg.U * gg.C;
+  // (a job is taken by a wave of a workgroup further right -- one with a higher ticket, for which the strip's own
+  // workgroup is running or through: the strips of a table's last workgroup have no jobs; GH_JQ = 64 queues)
+  int jlim = ((gg.JW - 1) / gg.P) * gg.P;
+  if (jlim > 64) jlim = 64;
+  std::vector<unsigned> qoff(64 + 1, 0u);
+  if (nwh <= 63) {
+    // strip after strip, a strip's tiles by block: a queue per strip
+    for (int j = 0; j < gg.JW && j < jlim; j++) {
+      const int b00 = (int)(((long long)j * UCg) / gg.R);
+      qoff[j] = (unsigned)jobs.size();
+      for (int b = b00; b < gg.NB; b++)
+        if (h_nw[off[j + 1] + (unsigned)(b - b00)] >= nwh) {
+          tjob[off[j + 1] + (unsigned)(b - b00)] = (unsigned)jobs.size();
+          jobs.push_back((unsigned)j | ((unsigned)b << 16));
+        }
+    }
+    for (int j = (gg.JW < jlim ? gg.JW : jlim); j <= 64; j++) qoff[j] = (unsigned)jobs.size();
+    if (jobs.size() > cap) {  // (the bound above counted every strip's tiles: cannot happen)
+      jobs.clear();
+      std::fill(tjob.begin(), tjob.end(), 0xffffffffu);
+      std::fill(qoff.begin(), qoff.end(), 0u);
+    }
+  }
+  const size_t nj = jobs.size();
+  jobs.insert(jobs.end(), qoff.begin(), qoff.end());  // (behind the jobs: the first job of every strip)
+  // (buffers for the most there can be, kept from set to set; the copies are synchronous: the vectors above go away)
+  if (!g->d_jobs[which] && stb_pool_malloc((void **)&g->d_jobs[which], 4 * ((size_t)n_tiles + 66 + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  if (!g->d_tjob[which] && stb_pool_malloc((void **)&g->d_tjob[which], 4 * (size_t)(n_tiles + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  if (hipMemcpyAsync(g->d_tjob[which], tjob.data(), 4 * (size_t)n_tiles, hipMemcpyHostToDevice, g->st) != hipSuccess ||
+      hipMemcpyAsync(g->d_jobs[which], jobs.data(), 4 * jobs.size(), hipMemcpyHostToDevice, g->st) != hipSuccess || hipStreamSynchronize(g->st) != hipSuccess)
+    return stb_fail("stb_groups_aterms: %s", hipGetErrorString(hipGetLastError()));
+  g->n_jobs[which] = (unsigned)nj;
+  return 0;
+}
+
 // Returns 0 and sets g->sparse = 1 when the sparse form was built, 0 with g->sparse = 0 when the
 // pairs are too dense for it to pay (the caller then builds the count slab), non-zero on error.
 static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
@@ -505,25 +603,18 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     H.C = gg.C;
     H.n_tiles = gg.n_tiles;
     H.n_rec = gg.n_tiles;
-    if (g->lists_ready[which] && (g->list_R[which] != H.R || g->list_G[which] != H.G)) {
+    if ((g->lists_ready[which] || g->d_tile_off[which]) && (g->list_R[which] != H.R || g->list_G[which] != H.G)) {
       (void)hipStreamSynchronize(g->st);
-      stb_pool_free(g->d_item_ptr[which]);
-      stb_pool_free(g->d_ent_pos[which]);
-      stb_pool_free(g->d_ent_cnt[which]);
-      stb_pool_free(g->d_tile_off[which]);
-      stb_pool_free(g->d_dense[which]);
-      stb_pool_free(g->d_tinfo[which]);
-      stb_pool_free(g->d_jobs[which]);
-      stb_pool_free(g->d_tjob[which]);
-      g->d_jobs[which] = nullptr;
-      g->d_tjob[which] = nullptr;
+      void **olds[] = {(void **)&g->d_item_ptr[which], (void **)&g->d_ent_pos[which], (void **)&g->d_ent_cnt[which], (void **)&g->d_tile_off[which],
+                       (void **)&g->d_dense[which],    (void **)&g->d_tinfo[which],   (void **)&g->d_jobs[which],    (void **)&g->d_tjob[which],
+                       (void **)&g->d_tnw[which],      (void **)&g->d_twords[which],  (void **)&g->d_toff[which]};
+      for (void **q : olds) {
+        stb_pool_free(*q);
+        *q = nullptr;
+      }
       g->n_jobs[which] = 0;
-      g->d_dense[which] = nullptr;
-      g->d_tinfo[which] = nullptr;
-      g->d_item_ptr[which] = nullptr;
-      g->d_ent_pos[which] = nullptr;
-      g->d_ent_cnt[which] = nullptr;
-      g->d_tile_off[which] = nullptr;
+      g->ent_cap[which] = 0;
+      g->dense_cap[which] = 0;
       g->lists_ready[which] = 0;
     }
     if (!g->lists_ready[which] && !g->d_tile_off[which]) {
@@ -536,6 +627,11 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     H.rec_off = g->d_tile_off[which];
   }
   if (g->lists_ready[which]) return 0;
+  {
+    // from the count slab (lists.hip): no sort, no host round trip; where it does not apply, the sort below
+    const int rc = stb_lists_slab_build(g, which, D, H, gg);
+    if (rc != 2) return rc;
+  }
   if (!g->fused_ready) g->sparse = 0;
   if (G == 0 || G >= 0xffffffffull) return 0;
   const unsigned nsg = (M + 63) / 64 + 4;
@@ -611,6 +707,16 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     } else if (hipMemsetAsync(runs, 0, 4, g->st) != hipSuccess) {
       break;
     }
+    {
+      void **olds[] = {(void **)&g->d_ent_pos[which], (void **)&g->d_ent_cnt[which], (void **)&g->d_item_ptr[which], (void **)&g->d_dense[which],
+                       (void **)&g->d_tinfo[which], (void **)&g->d_jobs[which], (void **)&g->d_tjob[which]};
+      for (void **q : olds) {
+        stb_pool_free(*q);
+        *q = nullptr;
+      }
+      g->ent_cap[which] = 0;
+      g->dense_cap[which] = 0;
+    }
     if (stb_pool_malloc((void **)&g->d_ent_pos[which], 2 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
         stb_pool_malloc((void **)&g->d_ent_cnt[which], 4 * (size_t)(h_runs ? h_runs : 1)) != hipSuccess ||
         stb_pool_malloc((void **)&g->d_item_ptr[which], 4 * ((size_t)nitems + 2)) != hipSuccess) {
@@ -659,60 +765,8 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       // form among them), NWH chosen below and raised until the records fit (grid_geom::job_cap at Dmax discounts).
       g->n_jobs[which] = 0;
       if (ok && n_tiles) {
-        std::vector<unsigned> h_nw(n_tiles), off;
-        const unsigned cap = stb_grid_job_cap(gg.C, g->Dmax, n_tiles, gg.phases);
-        ok = hipMemcpy(h_nw.data(), tnw, 4 * (size_t)n_tiles, hipMemcpyDeviceToHost) == hipSuccess;
-        if (ok && cap) {
-          unsigned hist[65] = {0};  // (an upper bound: the tiles of all strips)
-          for (unsigned t = 0; t < n_tiles; t++) hist[h_nw[t] > 63 ? 63 : h_nw[t]]++;
-          // NWH at the least: what a job takes off the critical path it adds to the chip's work (the tile is walked twice),
-          // which the fuller chip can afford less (MI355X, 10^6 pairs, N = 10^4, kernel ms without jobs / NWH = 3 / 4 / 6 /
-          // 8 / 12: 32 discounts 1.21 / 1.00 / 0.96 / 1.01 / 1.04 / 1.09, 40: 1.26 / 1.10 / 1.02 / 1.05 / 1.08 / 1.12,
-          // 48: 1.26 / 1.30 / 1.14 / 1.09 / 1.10 / 1.15, 64: 1.36 / 1.59 / 1.39 / 1.29 / 1.28 / 1.29)
-          unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 0);
-          if (nwh < 1) {
-            const double waves_per_simd = (double)gg.JW * D / (4.0 * stb_cu_count());
-            nwh = waves_per_simd <= 1.9 ? 4 : (waves_per_simd <= 2.7 ? 6 : 8);
-          }
-          for (; nwh <= 63; nwh++) {
-            unsigned c = 0;
-            for (unsigned k = nwh; k <= 63; k++) c += hist[k];
-            if (c <= cap) break;
-          }
-          std::vector<unsigned> jobs, tjob(n_tiles, 0xffffffffu);
-          stb_grid_tile_offsets(gg, off);
-          const int UCg = gg.U * gg.C;
-          // (a job is taken by a wave of a workgroup further right -- one with a higher ticket, for which the strip's own
-          // workgroup is running or through: the strips of a table's last workgroup have no jobs; GH_JQ = 64 queues)
-          int jlim = ((gg.JW - 1) / gg.P) * gg.P;
-          if (jlim > 64) jlim = 64;
-          std::vector<unsigned> qoff(64 + 1, 0u);
-          if (nwh <= 63) {
-            // strip after strip, a strip's tiles by block: a queue per strip
-            for (int j = 0; j < gg.JW && j < jlim; j++) {
-              const int b00 = (int)(((long long)j * UCg) / gg.R);
-              qoff[j] = (unsigned)jobs.size();
-              for (int b = b00; b < gg.NB; b++)
-                if (h_nw[off[j + 1] + (unsigned)(b - b00)] >= nwh) {
-                  tjob[off[j + 1] + (unsigned)(b - b00)] = (unsigned)jobs.size();
-                  jobs.push_back((unsigned)j | ((unsigned)b << 16));
-                }
-            }
-            for (int j = (gg.JW < jlim ? gg.JW : jlim); j <= 64; j++) qoff[j] = (unsigned)jobs.size();
-            if (jobs.size() > cap) {  // (the bound above counted every strip's tiles: cannot happen)
-              jobs.clear();
-              std::fill(tjob.begin(), tjob.end(), 0xffffffffu);
-              std::fill(qoff.begin(), qoff.end(), 0u);
-            }
-          }
-          const size_t nj = jobs.size();
-          jobs.insert(jobs.end(), qoff.begin(), qoff.end());  // (behind the jobs: the first job of every strip)
-          ok = stb_pool_malloc((void **)&g->d_jobs[which], 4 * (jobs.size() + 1)) == hipSuccess &&
-               stb_pool_malloc((void **)&g->d_tjob[which], 4 * (size_t)(n_tiles + 1)) == hipSuccess &&
-               hipMemcpy(g->d_tjob[which], tjob.data(), 4 * (size_t)n_tiles, hipMemcpyHostToDevice) == hipSuccess &&
-               hipMemcpy(g->d_jobs[which], jobs.data(), 4 * jobs.size(), hipMemcpyHostToDevice) == hipSuccess;
-          if (ok) g->n_jobs[which] = (unsigned)nj;
-        }
+        std::vector<unsigned> h_nw(n_tiles);
+        ok = hipMemcpy(h_nw.data(), tnw, 4 * (size_t)n_tiles, hipMemcpyDeviceToHost) == hipSuccess && stb_lists_jobs_from(g, which, D, gg, h_nw.data()) == 0;
       }
       stb_pool_free(tnw);
       stb_pool_free(twords);
@@ -723,30 +777,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
         break;
       }
     }
-    if (!g->d_dotp) {
-      // partial sums: (column blocks of 64) x 16 waves per table for the chain form, one per tile for the
-      // checkpointed one
-      g->dotp_elems = (size_t)g->Dmax * ((size_t)(M + 63) / 64 + 1) * 16;
-      const size_t ckp = stb_launch_ck ? (size_t)g->Dmax * stb_ck_dot_parts(N, M, g->Dmax) : 0;
-      if (ckp > g->dotp_elems) g->dotp_elems = ckp;
-      hb_dot_info H2;
-      if (stb_hb_dot_info(N, M, g->Dmax, &H2, g->hb_sum_C) == 0 && (size_t)g->Dmax * H2.n_tiles > g->dotp_elems)
-        g->dotp_elems = (size_t)g->Dmax * H2.n_tiles;
-      // (the self-summing form: two sums per strip, strips of 80 columns at the narrowest)
-      size_t hb2 = (size_t)g->Dmax * ((size_t)M / 64 + 8) * 2;
-      {
-        // (... and two per tile left to helper waves: at most grid_geom::job_cap of them)
-        grid_geom gj;
-        for (int dd : {1, g->Dmax})
-          if (stb_grid_geometry(N, M, dd, &gj) == 0 && (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2 > hb2)
-            hb2 = (size_t)g->Dmax * ((size_t)gj.JW + gj.job_cap) * 2;
-      }
-      if (hb2 > g->dotp_elems) g->dotp_elems = hb2;
-      if (stb_pool_malloc((void **)&g->d_dotp, sizeof(double) * g->dotp_elems) != hipSuccess) {
-        stb_fail("stb_groups_aterms: out of device memory");
-        break;
-      }
-    }
+    if (!g->d_dotp && stb_groups_alloc_dotp(g)) break;
     if (hipStreamSynchronize(g->st) != hipSuccess || hipGetLastError() != hipSuccess) break;
     g->nsg = nsg;
     g->sparse = 1;
@@ -837,6 +868,10 @@ static int groups_fused_setup(stb_groups_t *g) {
 //   launch 3  k_eval_tail: every reduction, the total and the walk's error words to pinned host memory
 //   then, behind what the host waits for, the workspace is zeroed for the next evaluation.
 // ONE wait (an event after launch 3), no copy in either direction, no S1 vector, no gather pass.
+// fused evaluations that gave up waiting and were repeated through stored tables (process-wide; stb_groups_fallbacks)
+static std::atomic<unsigned> g_fused_giveups{0};
+extern "C" unsigned stb_groups_fallbacks(void) { return g_fused_giveups.load(); }
+
 static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, double *out_host, int which, bool timed) {
   g->pending = 0;
   char *ws0 = (char *)g->d_ws_fill;
@@ -886,7 +921,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
   if (timed) HIPCHK(hipEventRecord(g->ev[1], g->st));
   if (timed) HIPCHK(hipEventRecord(g->ev[2], g->st));
   hipLaunchKernelGGL(k_eval_tail, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, which >= 3 ? 2 : 1, tpart, nbt,
-                     (unsigned long long)g->n_inf, hdr, g->d_out, g->h_out_dev, g->Dmax, g->pend_user);
+                     (unsigned long long)g->n_inf, g->ent_cap[which] ? g->d_ninf : nullptr, hdr, g->d_out, g->h_out_dev, g->Dmax, g->pend_user);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g->ev[3], g->st));
   // zero for the next evaluation, behind the event the host waits for
@@ -909,6 +944,8 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
     return aterms_issue_lean(g, x_host, D, out_host, g->sel_which, timed);
   g->pend_lean = 0;
   g->ws_zero = 0;  // (this flow's fills zero and use the workspace themselves)
+  if (ensure_tables(g)) return 1;
+  if (!fuse && stb_groups_sort_pairs(g)) return 1;  // (the gather's sum is then independent of the caller's order)
   // (what is left for this flow: the chain form, v = STB_FILL_CK with fuse: the summing checkpointed form and its cell
   // lists, and every evaluation through stored tables)
   const int which = (fuse && v == STB_FILL_CK) ? 1 : 0;
@@ -975,6 +1012,7 @@ static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float
     if (code != 0) {
       stb_fail("stb_groups_aterms: the fused evaluation gave up waiting for a neighbour block (code 0x%x, block %u of table %u)", code,
                detail & 0xffffu, detail >> 16);
+      g_fused_giveups.fetch_add(1u);
       return 2;  // (the caller repeats the evaluation through stored tables)
     }
     for (int d = 0; d < D; d++) g->pend_out[d] = g->h_out[d];
@@ -984,7 +1022,10 @@ static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float
     return 0;
   }
   HIPCHK(hipStreamSynchronize(g->st));
-  if (stb_fill_status_of(&g->pend_fill)) return g->pend_fuse ? 2 : 1;
+  if (stb_fill_status_of(&g->pend_fill)) {
+    if (g->pend_fuse) g_fused_giveups.fetch_add(1u);
+    return g->pend_fuse ? 2 : 1;
+  }
   // (whether THIS fill was repeated in the producer/consumer form -- not a counter of the calling thread, which other
   // sets' fills move too and which the waiting thread need not share with the issuing one; a fused evaluation stores no
   // table to sweep again)
@@ -1021,13 +1062,22 @@ static unsigned hb_max_spine() {
 // which form an evaluation of D discounts takes, with the one-off set-up of the fused form done
 static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_out, int *v_out) {
   if (!g) return stb_fail("stb_groups_aterms: null group set");
+  if (!g->have_bounds || (g->G && !g->have_pairs)) return stb_fail("stb_groups_aterms: the set has no pairs yet (stb_groups_pairs_begin / _put / _commit)");
+  if (g->putting) return stb_fail("stb_groups_aterms: stb_groups_pairs_commit has not been called");
   if (D < 1 || D > g->Dmax) return stb_fail("stb_groups_aterms: D=%d outside 1..%d", D, g->Dmax);
   if (g->pending == 1) return stb_fail("stb_groups_aterms: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int v = stb_default_variant();
   // one discount: the gather over a stored table needs no set-up; a grid: fused -- and so is a single discount once
   // the set is known to be used again and again (stb_groups_update_restaurants has been called on it: samplea's kept
   // set), where the one-off set-up is paid back: an evaluation is then three launches and one wait whatever D is
-  const bool fuse = allow_fuse && g->fused && (D >= 2 || g->reused) &&
+  // (round 5: the lists of the halo-block and grid forms come from a count slab in four launches -- lists.hip -- so a
+  // single discount on a fresh set is fused too wherever those forms apply; STB_ATERMS_FUSE1=0 restores the old rule)
+  bool fuse1 = g->reused;
+  if (!fuse1 && D == 1 && stb_env_int("STB_ATERMS_FUSE1", 1) && stb_env_int("STB_LISTS_SLAB", 1) && g->G * 3 <= stb_table_cells(g->N, g->M)) {
+    hb_dot_info H1;
+    fuse1 = stb_env_int("STB_ATERMS_HB", 1) && stb_hb_dot_info(g->N, g->M, 1, &H1, g->hb_sum_C) == 0;
+  }
+  const bool fuse = allow_fuse && g->fused && (D >= 2 || fuse1) &&
                     (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK || v == STB_FILL_HB);
   // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
   // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine
@@ -1200,13 +1250,20 @@ extern "C" int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, i
 extern "C" int stb_groups_update_restaurants(stb_groups_t *g, const uint32_t *T, const double *bpar) {
   STB_ENTRY;
   if (!g) return stb_fail("stb_groups_update_restaurants: null group set");
+  if (g->pending == 1) return stb_fail("stb_groups_update_restaurants: an evaluation queued with stb_groups_aterms_async has not been waited for");
   const int prev_dev = stb_device_enter(g->dev);
   int rc = 0;
   g->reused = 1;
   if (g->I > 0) {
-    if (hipMemcpyAsync(g->d_T, T, sizeof(uint32_t) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
-        hipMemcpyAsync(g->d_bpar, bpar, sizeof(double) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
-        hipStreamSynchronize(g->st) != hipSuccess)
+    // through pinned memory: the caller's arrays are free again on return, and nothing waits for the copy but the
+    // evaluation queued behind it (the wait at the START is for an earlier copy out of the same staging area)
+    if (hipStreamSynchronize(g->st) != hipSuccess) rc = 1;
+    if (!rc) {
+      memcpy(g->h_T, T, sizeof(uint32_t) * (size_t)g->I);
+      memcpy(g->h_bpar, bpar, sizeof(double) * (size_t)g->I);
+    }
+    if (rc || hipMemcpyAsync(g->d_T, g->h_T, sizeof(uint32_t) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess ||
+        hipMemcpyAsync(g->d_bpar, g->h_bpar, sizeof(double) * g->I, hipMemcpyHostToDevice, g->st) != hipSuccess)
       rc = stb_fail("stb_groups_update_restaurants: %s", hipGetErrorString(hipGetLastError()));
   }
   stb_device_leave(prev_dev);

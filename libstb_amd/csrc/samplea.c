@@ -55,13 +55,19 @@ static double aterms(double x, void *vp) {
   return val;
 }
 
-/* The device copy of the pairs of the last call: a Gibbs sampler resamples a over and over on counts
- * that change slowly or not at all, and uploading and sorting 10^6 pairs costs as much as four
- * posterior evaluations.  Kept only while the next call brings exactly the same pairs (64-bit hash
- * of K, n, t plus the shapes); T and bpar are refreshed on every call. */
+/* The device set of the last call, per calling thread.  A Gibbs sampler changes its counts between two calls
+ * (test/demo.c:405-445), so what is kept is the set as a CONTAINER -- device buffers, pinned staging, stream, count
+ * slab: a call with the same number of restaurants and pairs hands its pairs over with stb_groups_pairs_begin / _put /
+ * _commit and allocates nothing.  Only with STB_SAMPLEA_CACHE=1 in the environment are the CONTENTS reused too, when a
+ * 128-bit fingerprint of K, n, t and the bounds says the pairs are those of the last call (a sampler that resamples a
+ * several times over unchanged counts); T and bpar are refreshed on every call. */
+typedef struct {
+  uint64_t a, b;
+} fp128;
 static _Thread_local struct { /* (one per calling thread: samplers of different threads do not share a set) */
   stb_groups_t *dev;
-  uint64_t hash;
+  fp128 fp;
+  int have_fp; /* the set's pairs are those `fp` was taken from */
   int I;
   size_t G;
   unsigned N, M;
@@ -84,9 +90,10 @@ static uint64_t mix64(uint64_t h, uint64_t v) {
 #include <immintrin.h>
 /* the same job with the AES round as the mixing step (four 128-bit lanes, a round per 16 bytes of input, three more
  * rounds to fold them): 0.17 ms for the 6 MB of 10^6 pairs where the multiplicative hash below takes 0.48 -- a third
- * of a whole samplea call.  Only a fingerprint that says "the same pairs as last time": any 64 bits that depend on every
- * input bit will do, they need not be the same on every machine. */
-__attribute__((target("aes,sse4.1"))) static uint64_t hash_bytes_aes(uint64_t h, const void *p, size_t bytes) {
+ * of a whole samplea call.  Only a fingerprint that says "the same pairs as last time" (STB_SAMPLEA_CACHE=1): 128 bits
+ * that depend on every input bit; they need not be the same on every machine.  Not a cryptographic hash (the rounds are
+ * un-keyed): an adversary could construct a collision, chance will not -- see INTEGRATION.md for what a collision does. */
+__attribute__((target("aes,sse4.1"))) static fp128 hash_bytes_aes(uint64_t h, const void *p, size_t bytes) {
   const unsigned char *b = p;
   __m128i s0 = _mm_set_epi64x((long long)h, (long long)0x6a09e667f3bcc908ull),
           s1 = _mm_set_epi64x((long long)~h, (long long)0xbb67ae8584caa73bull),
@@ -111,7 +118,12 @@ __attribute__((target("aes,sse4.1"))) static uint64_t hash_bytes_aes(uint64_t h,
   s0 = _mm_aesenc_si128(s0, s2);
   s0 = _mm_aesenc_si128(s0, _mm_set_epi64x((long long)bytes, 0));
   s0 = _mm_aesenc_si128(s0, s0);
-  return (uint64_t)_mm_extract_epi64(s0, 0) ^ (uint64_t)_mm_extract_epi64(s0, 1);
+  {
+    fp128 r;
+    r.a = (uint64_t)_mm_extract_epi64(s0, 0);
+    r.b = (uint64_t)_mm_extract_epi64(s0, 1);
+    return r;
+  }
 }
 #define STB_HAVE_AES_HASH 1
 #endif
@@ -135,13 +147,20 @@ static uint64_t hash_bytes_mul(uint64_t h, const void *p, size_t bytes) {
   for (; i < bytes; i++) lanes[i & 3] = (lanes[i & 3] ^ b[i]) * 0x100000001b3ull;
   return mix64(mix64(mix64(mix64(h, lanes[0]), lanes[1]), lanes[2]), lanes[3] ^ bytes);
 }
-static uint64_t hash_bytes(uint64_t h, const void *p, size_t bytes) {
+static fp128 hash_bytes(fp128 h, const void *p, size_t bytes) {
+  fp128 r;
 #ifdef STB_HAVE_AES_HASH
   static int have_aes = -1; /* (a benign race: every thread computes the same value) */
   if (have_aes < 0) have_aes = __builtin_cpu_supports("aes") && __builtin_cpu_supports("sse4.1") ? 1 : 0;
-  if (have_aes) return hash_bytes_aes(h, p, bytes);
+  if (have_aes) {
+    r = hash_bytes_aes(h.a ^ (h.b << 1 | h.b >> 63), p, bytes);
+    r.a ^= h.b; /* (chained: every piece's fingerprint depends on all of the earlier ones') */
+    return r;
+  }
 #endif
-  return hash_bytes_mul(h, p, bytes);
+  r.a = hash_bytes_mul(h.a, p, bytes); /* (two passes with unrelated seeds: 2 x 64 bits) */
+  r.b = hash_bytes_mul(h.b ^ 0xa54ff53a5f1d36f1ull, p, bytes);
+  return r;
 }
 
 /* largest entry of an array (0 for an empty one); loops the compiler turns into vector code */
@@ -174,13 +193,14 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
                rngp_t rng, int loops, int verbose) {
   double inita[3] = {A_MIN, 1, A_MAX};
   a_posterior ap;
-  scnt_int *nflat;
-  stcnt_int *tflat;
+  scnt_int *nflat = NULL;
+  stcnt_int *tflat = NULL;
   size_t G = 0, g = 0;
-  unsigned N, M;
-  uint64_t pairs_hash = 0;
+  unsigned N, M, mn = 0, mt = 0;
+  fp128 fp = {0x5eedull, 0x9e3779b97f4a7c15ull};
   double xspec[NPRE], yspec[NPRE];
-  int i, k, keep, spec = 0;
+  int i, k, cache, spec = 0, hit = 0;
+  const int slice = use_slice();
 
   /* lib/samplea.c:161-177: start point nudged off the ends, move limited to +-SQUEEZEA */
   inita[1] = mya;
@@ -190,18 +210,13 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
   if (inita[1] - SQUEEZEA > A_MIN) inita[0] = inita[1] - SQUEEZEA;
   if (inita[1] + SQUEEZEA < A_MAX) inita[2] = inita[1] + SQUEEZEA;
 #endif
+  /* ARMS starts from three abscissae it fixes before any evaluation (lib/arms.c:117-119, the same expression here, so
+   * the same bits): they are evaluated in ONE batched device call */
+  for (i = 0; i < NPRE; i++) xspec[i] = inita[0] + (i + 1.0) * (inita[2] - inita[0]) / (NPRE + 1.0);
 
-  /* the bounds: maxn = max n + 1, maxt = max t + 1, both at least 1 (lib/samplea.c:184-208), and a hash of the
-   * pairs, in ONE pass over the caller's arrays; they are flattened (copied) only when the device does not hold
-   * them already -- a Gibbs sampler resamples a over counts that change slowly or not at all, and the copy costs as
-   * much as three posterior evaluations */
   for (i = 0; i < I; i++) G += (size_t)(K[i] > 0 ? K[i] : 0);
-  nflat = NULL;
-  tflat = NULL;
-  ap.maxt = 1;
-  ap.maxn = 1;
   ap.verbose = verbose;
-  if (getval) { /* (a callback has to be asked pair by pair: flattened first, then as arrays) */
+  if (getval) { /* (a callback has to be asked pair by pair: flattened first, then handed over as arrays) */
     nflat = malloc(sizeof(*nflat) * (G ? G : 1));
     tflat = malloc(sizeof(*tflat) * (G ? G : 1));
     if (!nflat || !tflat) {
@@ -211,116 +226,123 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
     for (i = 0; i < I; i++)
       for (k = 0; k < K[i]; k++, g++) getval(&nflat[g], &tflat[g], i, k);
   }
-  /* A kept set is most likely still the right one (a Gibbs sampler's counts change slowly or not at all): its three
-   * pre-evaluations (below) are queued on that guess BEFORE the host reads the caller's pairs, so the device walks the
-   * tables while the host hashes 6 MB; should the hash then differ, the values are waited for and thrown away. */
   {
     const char *ce = getenv("STB_SAMPLEA_CACHE");
-    keep = !(ce && strcmp(ce, "0") == 0);
+    cache = ce && strcmp(ce, "1") == 0;
   }
-  for (i = 0; i < NPRE; i++) xspec[i] = inita[0] + (i + 1.0) * (inita[2] - inita[0]) / (NPRE + 1.0);
-  if (keep && kept.dev && kept.I == I && kept.G == G && !use_slice())
-    spec = !stb_groups_update_restaurants(kept.dev, T, bpar) && !stb_groups_aterms_async(kept.dev, xspec, NPRE, yspec, NULL);
-  {
-    uint64_t hh = hash_bytes(0x5eedull, K, sizeof(int) * (size_t)(I > 0 ? I : 0));
+  /* the thread's device set, as a container: one of this shape is used again, another shape makes a new one (empty:
+   * pairs and bounds follow) */
+  if (kept.dev && (kept.I != I || kept.G != G)) stb_sampler_cache_clear();
+  if (!kept.dev) {
+    kept.dev = stb_groups_create(I, K, NULL, NULL, NULL, NULL, 0, 0, NPRE);
+    if (!kept.dev) {
+      fprintf(stderr, "Out of memory for S table (%s)\n", stb_last_error()); /* lib/samplea.c:61-64 */
+      exit(1);
+    }
+    kept.I = I;
+    kept.G = G;
+    kept.have_fp = 0;
+  }
+  ap.dev = kept.dev;
+  if (cache) {
+    /* The contents may still be right (a sampler that resamples a over unchanged counts): the three starting
+     * evaluations are queued on that guess BEFORE the host reads the caller's pairs, so the device walks the tables
+     * while the host takes the fingerprint of 6 MB; should it differ, the values are waited for and thrown away. */
     size_t off = 0;
+    if (kept.have_fp && !slice)
+      spec = !stb_groups_update_restaurants(kept.dev, T, bpar) && !stb_groups_aterms_async(kept.dev, xspec, NPRE, yspec, NULL);
+    fp = hash_bytes(fp, K, sizeof(int) * (size_t)(I > 0 ? I : 0));
     for (i = 0; i < I; i++) {
       const size_t Ki = (size_t)(K[i] > 0 ? K[i] : 0);
       const scnt_int *ni = getval ? nflat + off : n[i];
       const stcnt_int *ti = getval ? tflat + off : t[i];
-      const unsigned mn = max_u32(ni, Ki), mt = max_u16(ti, Ki);
-      if ((int)mt >= ap.maxt) ap.maxt = (int)mt + 1;
-      if (Ki && mn >= (unsigned)ap.maxn) ap.maxn = (int)mn + 1;
-      hh = mix64(hash_bytes(hh, ni, sizeof(*ni) * Ki), hash_bytes(hh, ti, sizeof(*ti) * Ki));
+      const unsigned a = max_u32(ni, Ki), b = max_u16(ti, Ki);
+      mn = a > mn ? a : mn;
+      mt = b > mt ? b : mt;
+      fp = hash_bytes(fp, ni, sizeof(*ni) * Ki);
+      fp = hash_bytes(fp, ti, sizeof(*ti) * Ki);
       off += Ki;
     }
-    pairs_hash = hh;
-  }
-  /* the table aterms builds is S_make(maxn,maxt,maxn,maxt) (lib/samplea.c:60) after S_make's
-   * clamps (lib/stable.c:118-129): M = max(maxt,10), N = max(maxn,M) */
-  M = ap.maxt < 10 ? 10u : (unsigned)ap.maxt;
-  N = (unsigned)ap.maxn < M ? M : (unsigned)ap.maxn;
-  {
-    const uint64_t h = pairs_hash;
-    ap.reused = 0;
-    if (keep && kept.dev && kept.hash == h && kept.I == I && kept.G == G && kept.N == N && kept.M == M) {
-      ap.dev = kept.dev;
-      ap.reused = 1;
-      if (!spec && stb_groups_update_restaurants(ap.dev, T, bpar)) {
-        stb_sampler_cache_clear();
-        ap.dev = NULL;
-      }
-    } else {
-      if (spec) (void)stb_groups_wait(kept.dev); /* the guess was wrong: let the device finish before the set goes */
+    hit = kept.have_fp && kept.fp.a == fp.a && kept.fp.b == fp.b;
+    if (!hit && spec) { /* the guess was wrong: let the device finish before the pairs go */
+      (void)stb_groups_wait(kept.dev);
       spec = 0;
-      stb_sampler_cache_clear();
-      ap.dev = NULL;
     }
-    if (!ap.dev) {
-      if (!getval) { /* not on the device yet: now the pairs are copied, restaurant after restaurant */
-        size_t off = 0;
-        nflat = malloc(sizeof(*nflat) * (G ? G : 1));
-        tflat = malloc(sizeof(*tflat) * (G ? G : 1));
-        if (!nflat || !tflat) {
-          fprintf(stderr, "Out of memory for S table\n");
-          exit(1);
-        }
-        for (i = 0; i < I; i++) {
-          const size_t Ki = (size_t)(K[i] > 0 ? K[i] : 0);
-          memcpy(nflat + off, n[i], sizeof(*nflat) * Ki);
-          memcpy(tflat + off, t[i], sizeof(*tflat) * Ki);
-          off += Ki;
-        }
-      }
-      ap.dev = stb_groups_create(I, K, T, nflat, tflat, bpar, N, M, NPRE);
+  }
+  if (!hit) {
+    /* the pairs go to the device restaurant after restaurant, copied once (into pinned memory, each piece on its way
+     * while the next is copied); the largest n and t fall out of the same pass */
+    int bad = stb_groups_pairs_begin(kept.dev);
+    if (!bad && G) {
+      if (getval) bad = stb_groups_pairs_put(kept.dev, nflat, tflat, G, &mn, &mt);
+      else bad = stb_groups_pairs_put_ragged(kept.dev, I, K, n, t, &mn, &mt);
     }
-    if (ap.dev && keep) {
-      kept.dev = ap.dev;
-      kept.hash = h;
-      kept.I = I;
-      kept.G = G;
-      kept.N = N;
-      kept.M = M;
+    if (bad) {
+      fprintf(stderr, "Out of memory for S table (%s)\n", stb_last_error());
+      exit(1);
     }
-    ap.keep = keep;
   }
   free(nflat);
   free(tflat);
-  if (!ap.dev) {
-    fprintf(stderr, "Out of memory for S table (%s)\n", stb_last_error()); /* lib/samplea.c:61-64 */
+  /* the bounds: maxn = max n + 1, maxt = max t + 1, both at least 1 (lib/samplea.c:184-208); the table aterms builds
+   * is S_make(maxn,maxt,maxn,maxt) (lib/samplea.c:60) after S_make's clamps (lib/stable.c:118-129): M = max(maxt,10),
+   * N = max(maxn,M) */
+  ap.maxt = (int)mt + 1;
+  ap.maxn = G ? (int)mn + 1 : 1;
+  M = ap.maxt < 10 ? 10u : (unsigned)ap.maxt;
+  N = (unsigned)ap.maxn < M ? M : (unsigned)ap.maxn;
+  {
+    /* The table is private to this call and its cells do not depend on its bounds: the device walks one whose bounds
+     * are rounded up to multiples of 128 (at most 127 rows of 22 ns more), so that a largest count that moves a little
+     * from call to call -- a Gibbs sampler's does -- finds the geometry, the workspace and the count slab of the last
+     * call.  STB_SAMPLEA_QUANT=1 walks the reference's exact bounds. */
+    const char *qe = getenv("STB_SAMPLEA_QUANT");
+    unsigned q = qe && *qe ? (unsigned)atoi(qe) : 128u;
+    if (q > 1 && q <= 4096) {
+      N = (N + q - 1) / q * q;
+      M = (M + q - 1) / q * q;
+      if (M > N) M = N;
+    }
+  }
+  if (hit && (kept.N != N || kept.M != M)) hit = 0; /* (cannot happen: the same pairs have the same maxima) */
+  if (!hit) {
+    if (stb_groups_pairs_commit(kept.dev, T, bpar, N, M)) {
+      fprintf(stderr, "Out of memory for S table (%s)\n", stb_last_error());
+      exit(1);
+    }
+    kept.N = N;
+    kept.M = M;
+    kept.fp = fp;
+    kept.have_fp = cache;
+  } else if (!spec && stb_groups_update_restaurants(kept.dev, T, bpar)) {
+    fprintf(stderr, "aterms(): %s\n", stb_last_error());
     exit(1);
   }
+  ap.keep = 1;
+  ap.reused = hit;
   ap.npre = 0;
-  {
-    if (!use_slice()) {
-      /* ARMS starts from three abscissae it fixes before any evaluation (lib/arms.c:117-119, the
-       * same expression here, so the same bits): evaluate them in ONE batched device call */
-      double x3[NPRE], y3[NPRE];
-      int bad;
-      for (i = 0; i < NPRE; i++) x3[i] = xspec[i];
-      /* (a fresh set: through stored tables, no set-up; a kept one: the fused evaluation, whose cell lists it has --
-       * queued above when the set was there before the pairs were read) */
-      if (spec && ap.reused && ap.dev) {
-        bad = stb_groups_wait(ap.dev);
-        spec = 0;
-        for (i = 0; i < NPRE; i++) y3[i] = yspec[i];
-      } else {
-        bad = ap.reused ? stb_groups_aterms(ap.dev, x3, NPRE, y3) : stb_groups_aterms_tables(ap.dev, x3, NPRE, y3);
-      }
-      if (bad) {
-        fprintf(stderr, "aterms(): device evaluation failed: %s\n", stb_last_error());
-        exit(1);
-      }
-      for (i = 0; i < NPRE; i++) {
-        ap.xpre[i] = x3[i];
-        ap.ypre[i] = y3[i];
-      }
-      ap.npre = NPRE;
+  if (!slice) {
+    double y3[NPRE];
+    int bad;
+    if (spec) {
+      bad = stb_groups_wait(ap.dev);
+      for (i = 0; i < NPRE; i++) y3[i] = yspec[i];
+    } else {
+      bad = stb_groups_aterms(ap.dev, xspec, NPRE, y3);
     }
+    if (bad) {
+      fprintf(stderr, "aterms(): device evaluation failed: %s\n", stb_last_error());
+      exit(1);
+    }
+    for (i = 0; i < NPRE; i++) {
+      ap.xpre[i] = xspec[i];
+      ap.ypre[i] = y3[i];
+    }
+    ap.npre = NPRE;
   }
 
   stb_trace_reset();
-  if (!use_slice()) {
+  if (!slice) {
     int code = arms_simple(3, inita, inita + 2, aterms, &ap, 0, inita + 1, &mya); /* :210 */
     stb_trace_code(code);
     if (mya < inita[0] || mya > inita[2]) {
@@ -334,6 +356,6 @@ double samplea(double mya, int I, int *K, scnt_int *T, scnt_int **n, stcnt_int *
       exit(1);
     }
   }
-  if (!ap.keep) stb_groups_free(ap.dev); /* else: kept for the next call */
+  /* (the set stays with the thread, as a container; stb_sampler_cache_clear releases it) */
   return mya;
 }

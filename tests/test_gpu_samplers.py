@@ -174,9 +174,12 @@ def test_samplea_keeps_the_pairs_between_calls(monkeypatch):
     L.stb_sampler_cache_clear()
 
 
-def test_aterms_tables_equals_fused_and_single(golden_dir):
-    """stb_groups_aterms_tables (stored tables + gather at any D) against the one-at-a-time path"""
+def test_aterms_tables_equals_fused_and_single(golden_dir, monkeypatch):
+    """stb_groups_aterms_tables (stored tables + gather at any D) against the one-at-a-time path through stored tables
+    (STB_ATERMS_FUSE1=0: since round 5 a single discount is summed inside the table walk wherever the lists come from
+    the count slab), bit for bit; and against the fused single evaluation at 1e-12"""
     L = capi.lib()
+    monkeypatch.setenv("STB_ATERMS_FUSE1", "0")
     g = synth.groups(100, 100, 1000, "wide")
     M = max(int(g.t.max()) + 1, 10)
     N = max(int(g.n.max()) + 1, M)
@@ -189,6 +192,10 @@ def test_aterms_tables_equals_fused_and_single(golden_dir):
         for d in range(3):
             capi.check(L.stb_groups_aterms(h, capi.dp(x[d:d + 1].copy()), 1, capi.dp(one)))
             assert one[0] == three[d]
+        monkeypatch.delenv("STB_ATERMS_FUSE1")
+        for d in range(3):
+            capi.check(L.stb_groups_aterms(h, capi.dp(x[d:d + 1].copy()), 1, capi.dp(one)))
+            assert orc.close(one[0], three[d], 1e-12)
     finally:
         L.stb_groups_free(h)
 
