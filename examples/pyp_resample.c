@@ -9,11 +9,14 @@
  *   3. every few sweeps resample the concentration b (sampleb) and the discount a (samplea) and
  *      rebuild the table for the new discount (S_remake);
  *   4. optionally (-g D) also evaluate the discount's log-posterior on a D-point grid in one batched
- *      device call (stb_groups_aterms) and report its mode next to the sampled value.
+ *      device call (stb_groups_aterms) and report its mode next to the sampled value;
+ *   5. with -G k as well: the same grid sharded over k group sets, set s on GPU s % (number of GPUs), driven by
+ *      THIS one host thread (stb_set_device + stb_groups_aterms_async on every set, then stb_groups_wait on
+ *      every set: INTEGRATION.md section 5, pattern (a)) -- the discount axis of SURVEY 8e without MPI.
  *
  * All table builds and every log-posterior evaluation run on the GPU through libstb_amd.so; this file
  * only uses the public headers.  Usage: pyp_resample [-J 3] [-n 2000] [-a 0.5] [-b 10] [-c 60]
- *                                                    [-g 64] [-s seed]
+ *                                                    [-g 64] [-G 2] [-s seed]
  */
 #include <math.h>
 #include <stdio.h>
@@ -29,16 +32,17 @@
 #define DISHES 50
 
 int main(int argc, char **argv) {
-  int J = 3, ncust = 2000, cycles = 60, grid = 0, c, j, i, it;
+  int J = 3, ncust = 2000, cycles = 60, grid = 0, nsets = 0, c, j, i, it;
   double a0 = 0.5, b0 = 10.0;
   long seed = 12345;
-  while ((c = getopt(argc, argv, "J:n:a:b:c:g:s:")) >= 0) {
+  while ((c = getopt(argc, argv, "J:n:a:b:c:g:G:s:")) >= 0) {
     if (c == 'J') J = atoi(optarg);
     else if (c == 'n') ncust = atoi(optarg);
     else if (c == 'a') a0 = atof(optarg);
     else if (c == 'b') b0 = atof(optarg);
     else if (c == 'c') cycles = atoi(optarg);
     else if (c == 'g') grid = atoi(optarg);
+    else if (c == 'G') nsets = atoi(optarg);
     else if (c == 's') seed = atol(optarg);
     else return 2;
   }
@@ -154,6 +158,34 @@ int main(int argc, char **argv) {
     printf("grid of %d discounts in one batched call: posterior mode at a=%.3f (log-posterior %.3f)\n", grid,
            x[best], lp[best]);
     stb_groups_free(gs);
+    /* ---- 5. the same grid, a contiguous block of it per group set, the sets spread over the GPUs ---- */
+    if (nsets >= 1 && nsets <= 8 && nsets <= grid) {
+      const int ndev = stb_device_count(), home = stb_get_device();
+      stb_groups_t *set[8];
+      double lp2[64];
+      int lo[9], s, worst = 0;
+      for (s = 0; s <= nsets; s++) lo[s] = (int)((long)grid * s / nsets);
+      for (s = 0; s < nsets; s++) {
+        if (stb_set_device(s % (ndev > 0 ? ndev : 1))) yaps_quit("stb_set_device: %s\n", stb_last_error());
+        set[s] = stb_groups_create(J, K, T, nf, tf, bvec, Nb, M, lo[s + 1] - lo[s]); /* (lives on that GPU from now on) */
+        if (!set[s]) yaps_quit("stb_groups_create: %s\n", stb_last_error());
+      }
+      stb_set_device(home);
+      for (s = 0; s < nsets; s++) /* queue everything ... */
+        if (stb_groups_aterms_async(set[s], x + lo[s], lo[s + 1] - lo[s], lp2 + lo[s], NULL)) yaps_quit("grid evaluation: %s\n", stb_last_error());
+      for (s = 0; s < nsets; s++) /* ... then wait: the GPUs (or the sets of one GPU) work side by side */
+        if (stb_groups_wait(set[s])) yaps_quit("grid evaluation: %s\n", stb_last_error());
+      for (d = 0; d < grid; d++) {
+        const double err = fabs(lp2[d] - lp[d]) / (fabs(lp[d]) > 1 ? fabs(lp[d]) : 1);
+        if (err > 1e-12) worst++;
+      }
+      best = 0;
+      for (d = 1; d < grid; d++)
+        if (lp2[d] > lp2[best]) best = d;
+      printf("the same grid over %d group sets on %d GPU(s), one host thread: posterior mode at a=%.3f (log-posterior %.3f), %d of %d values differ from the single call by more than 1e-12\n",
+             nsets, ndev < nsets ? ndev : nsets, x[best], lp2[best], worst, grid);
+      for (s = 0; s < nsets; s++) stb_groups_free(set[s]);
+    }
     free(nf);
     free(tf);
   }

@@ -18,15 +18,16 @@ def counts(D_total: int, world: int):
     return [my_slice(D_total, r, world).stop - my_slice(D_total, r, world).start for r in range(world)]
 
 
-def gather_scalars(local, D_total: int, dist=None, group=None):
+def gather_scalars(local, D_total: int, dist=None, group=None, force_collective: bool = False):
     """all ranks end up with the D_total per-discount scalars in grid order.
 
     `local` is a 1-D torch tensor with this rank's values.  Equal shares use
     all_gather_into_tensor (one collective, 8 bytes per discount); ragged shares pad to the
-    largest share first."""
+    largest share first.  A single rank has nothing to exchange and gets a copy -- unless
+    force_collective asks for the collective anyway (the one-GPU test of the RCCL path)."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return local.clone()
     world = dist.get_world_size(group)
     cnt = counts(D_total, world)

@@ -29,7 +29,21 @@ static int ref_arms_hook(int ninit, double *xl, double *xr,
  * source is untouched, and samplea()'s own call (which passes &ald) is unaffected. */
 #define arms_simple(ni, xl, xr, f, d, m, xp, xs) \
   ref_arms_hook(ni, xl, xr, f, ((d) ? (void *)(d) : (void *)&ald), m, xp, xs)
+#ifdef REF_SLICE_A
+/* _ref/libstb_ref_slice.so: samplea's OTHER branch (lib/samplea.c:216-221), which the reference compiles when
+ * PSAMPLE_ARS is not defined (lib/psample.h:37).  The switch is turned off for samplea.c alone -- sampleb's slice
+ * branch (lib/sampleb.c:141-153) needs digammaInv, which lib/digamma.h:25 compiles out in the shipped configuration --
+ * and SliceSimple (lib/sslice.c, compiled in as it is) is reached through a hook that records every evaluation. */
+#undef PSAMPLE_ARS
+int SliceSimple(double *xp, double (*post)(double, void *), double *bounds, rngp_t rng, int loops, void *pars);
+static int ref_slice_hook(double *xp, double (*post)(double, void *), double *bounds, rngp_t rng, int loops, void *pars);
+#define SliceSimple ref_slice_hook
+#include "samplea.c"
+#undef SliceSimple
+#define PSAMPLE_ARS
+#else
 #include "samplea.c" /* -I$(REF)/lib : lib/samplea.c (ALData, aterms, samplea; aterms2, samplea2) */
+#endif
 #undef arms_simple
 #define arms_simple ref_arms_hook
 #include "sampleb.c" /* -I$(REF)/lib : lib/sampleb.c (BLData, bterms, sampleb) */
@@ -67,6 +81,18 @@ static int ref_arms_hook(int ninit, double *xl, double *xr,
   ref_trace.code = arms_simple(ninit, xl, xr, ref_tramp, NULL, dometrop, xprev, xsamp);
   return ref_trace.code;
 }
+#ifdef REF_SLICE_A
+static int ref_slice_hook(double *xp, double (*post)(double, void *), double *bounds, rngp_t rng, int loops, void *pars) {
+  ref_last_mydata = pars;
+  ref_trace.f = post;
+  ref_trace.d = pars;
+  ref_trace.n = 0;
+  ref_trace.xl = bounds[0];
+  ref_trace.xr = bounds[1];
+  ref_trace.code = SliceSimple(xp, ref_tramp, bounds, rng, loops, NULL);
+  return ref_trace.code;
+}
+#endif
 int ref_trace_count(void) { return ref_trace.n; }
 int ref_trace_code(void) { return ref_trace.code; }
 double ref_trace_x(int i) { return ref_trace.xs[i]; }

@@ -442,12 +442,33 @@ def g15_samplea2(R):
     dump("samplea2.json", out)
 
 
+def g16_samplea_slice(R):
+    """samplea's OTHER sampler: the slice branch (lib/samplea.c:216-221, lib/sslice.c:33-80), from the reference built with
+    PSAMPLE_ARS off for lib/samplea.c (oracle/_ref/libstb_ref_slice.so): the draw, the number of posterior evaluations,
+    every abscissa and value, the bracket handed to SliceSimple, under srand48(12345)"""
+    if not orc.have_ref_slice():
+        sys.exit("oracle/_ref/libstb_ref_slice.so missing: run `make -C oracle`")
+    RS = orc.ref_slice()
+    out = {"seed_rand": 777, "seed_rand48": 12345, "runs": []}
+    for name, a0, loops in (("small_wide", 0.5, 1), ("small_wide", 0.1, 3), ("small_real", 0.3, 2), ("small_real", 0.9, 1),
+                            ("mid_wide", 0.5, 2), ("mid_wide", 0.25, 1), ("mid_wide", 0.97, 3), ("big_real", 0.5, 1)):
+        I, K, nmax, prof = GROUP_SETS[name]
+        g = synth.groups(I, K, nmax, prof)
+        orc.seed_libc(777, 12345)
+        r = RS.ref_samplea_flat(a0, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), loops, 0)
+        n = RS.ref_trace_count()
+        out["runs"].append({"set": name, "a_in": hx(a0), "loops": loops, "a_out": hx(r),
+                            "trace": {"count": n, "code": RS.ref_trace_code(), "xl": hx(RS.ref_trace_xl()), "xr": hx(RS.ref_trace_xr()),
+                                      "x": [hx(RS.ref_trace_x(i)) for i in range(n)], "y": [hx(RS.ref_trace_y(i)) for i in range(n)]}})
+    dump("samplers_slice.json", out)
+
+
 def main():
     if not orc.have_ref():
         sys.exit("oracle/_ref/libstb_ref.so missing: run `make -C oracle` where /root/reference exists")
     R = orc.ref()
     gens = [g1_small_tables, g2_big_probes, g3_asympt, g4_extend, g5_aterms, g6_bterms,
-            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng, g13_grid_tables, g14_grid_aterms, g15_samplea2]
+            g7_samplers, g8_arms, g9_slice, g10_sapprox, g11_uv, g12_rng, g13_grid_tables, g14_grid_aterms, g15_samplea2, g16_samplea_slice]
     want = sys.argv[1:]
     for g in gens:
         if not want or g.__name__.split("_")[0] in want:

@@ -114,6 +114,30 @@ def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
 
+REF_SLICE_SO = os.path.join(ORACLE_DIR, "_ref", "libstb_ref_slice.so")
+
+
+def have_ref_slice() -> bool:
+    return os.path.exists(REF_SLICE_SO)
+
+
+@lru_cache(maxsize=None)
+def ref_slice() -> C.CDLL:
+    """The real reference with samplea's slice-sampler branch (lib/samplea.c:216-221; oracle/Makefile); build container only."""
+    L = C.CDLL(REF_SLICE_SO)
+    d, i = C.c_double, C.c_int
+    L.ref_samplea_flat.restype = d
+    L.ref_samplea_flat.argtypes = [d, i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, i, i]
+    L.ref_trace_count.restype = i
+    L.ref_trace_code.restype = i
+    for name in ("ref_trace_x", "ref_trace_y"):
+        getattr(L, name).restype = d
+        getattr(L, name).argtypes = [i]
+    L.ref_trace_xl.restype = d
+    L.ref_trace_xr.restype = d
+    return L
+
+
 REF_M_SO = os.path.join(ORACLE_DIR, "_ref", "libstb_ref_m.so")
 
 

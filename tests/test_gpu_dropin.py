@@ -13,9 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref")
 need = [os.path.join(BIN, b) for b in ("list_ref", "list_amd", "demo_ref", "demo_amd")]
-if not all(os.path.exists(b) for b in need):
-    pytest.skip("oracle/_ref driver binaries not built (make -C oracle where the reference exists)",
-                allow_module_level=True)
+have_drivers = all(os.path.exists(b) for b in need)
+needs_drivers = pytest.mark.skipif(not have_drivers, reason="oracle/_ref driver binaries not built (make -C oracle where the reference exists)")
+
+
+def test_the_dropin_evidence_has_not_vanished():
+    """The four driver binaries are built where the reference exists and travel with the tree.  Their absence used to skip
+    this whole module silently; now it FAILS whenever the reference library itself was built (then the drivers should
+    have been too: a half-built oracle/_ref) or when STB_EXPECT_DROPIN=1 says the evidence is expected on this box."""
+    missing = [os.path.basename(b) for b in need if not os.path.exists(b)]
+    ref_built = os.path.exists(os.path.join(BIN, "libstb_ref.so"))
+    if missing and (ref_built or os.environ.get("STB_EXPECT_DROPIN") == "1"):
+        pytest.fail(f"drop-in driver binaries missing from oracle/_ref: {missing} (run `make -C oracle` after `make -C libstb_amd/csrc`)")
+    if missing:
+        pytest.skip("no reference build on this box: the drop-in comparison cannot run here")
 
 
 def run(binary, *args):
@@ -26,6 +37,7 @@ def run(binary, *args):
     return [re.sub(r"mem=\d+k", "mem=*", ln) for ln in text.splitlines() if "amdgpu.ids" not in ln]
 
 
+@needs_drivers
 @pytest.mark.parametrize("args", [("-a", "0.5", "-N", "200", "-T", "50"),
                                   ("-a", "0.25", "-N", "60", "-T", "20"),
                                   ("-a", "0.9", "-N", "120", "-T", "30", "-n", "12"),
@@ -38,6 +50,7 @@ def test_list_program_prints_the_same(args):
     assert not bad, bad[:5]
 
 
+@needs_drivers
 @pytest.mark.parametrize("args", [("-s", "7", "-a", "0.5", "-I", "5", "-H", "5", "-N", "200", "-C", "40"),
                                   ("-s", "11", "-a", "0.3", "-b", "5", "-I", "3", "-H", "2", "-N", "300", "-C", "30")])
 def test_demo_gibbs_run_prints_the_same(args):
@@ -65,3 +78,22 @@ def test_own_end_to_end_driver():
     a, b, amode = float(m.group(1)), float(m.group(2)), float(g.group(1))
     assert 0.01 <= a <= 0.98 and 0.01 <= b <= 2000
     assert abs(a - amode) < 0.15  # sampled discount and batched-grid mode describe the same posterior
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_one_host_thread_drives_several_group_sets(k):
+    """examples/pyp_resample.c -G k: the discount grid in k contiguous blocks, a group set per block, set s on GPU
+    s % (number of GPUs) (stb_set_device), everything queued with stb_groups_aterms_async before anything is waited for
+    (pattern (a)).  On a one-GPU box the k sets share device 0; every value must equal the
+    single 64-discount call's."""
+    exe = os.path.join(ROOT, "examples", "bin", "pyp_resample")
+    if not os.path.exists(exe):
+        pytest.fail("examples/bin/pyp_resample not built (make -C libstb_amd/csrc)")
+    p = subprocess.run([exe, "-J", "3", "-n", "2000", "-a", "0.4", "-b", "15", "-c", "12", "-g", "64", "-G", str(k), "-s", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = re.search(r"in one batched call: posterior mode at a=([0-9.]+) \(log-posterior ([-0-9.]+)\)", p.stdout)
+    many = re.search(rf"over {k} group sets on (\d+) GPU\(s\), one host thread: posterior mode at a=([0-9.]+) \(log-posterior ([-0-9.]+)\), (\d+) of 64", p.stdout)
+    assert one and many, p.stdout
+    assert many.group(2) == one.group(1) and many.group(3) == one.group(2)
+    assert int(many.group(4)) == 0, p.stdout

@@ -54,6 +54,23 @@ def trace(L):
     return np.array(xs), np.array(ys), L.stb_sampler_trace_code()
 
 
+# End-to-end bars per recorded run: 10 x the worst deviation observed on MI355X (round 5, gpurun_out/r05/t_new.txt) of the
+# adaptive abscissae (relative) and of the draw (absolute), so that a regression of one run is caught by that run's own
+# bar -- the reference sums up to 10^6 terms left to right in one double, the device in double-double, and ARMS
+# exponentiates differences of these sums: the big sets deviate most.
+OBS_A_RELX = [0, 0, 4.8e-13, 4.43e-15, 8e-11, 3.41e-14, 7.23e-14, 1.11e-15, 3.98e-9, 4.76e-15, 2.76e-5]
+OBS_A_DA = [3.5e-14, 1.8e-14, 4.29e-13, 3.06e-13, 2.51e-12, 2.65e-14, 5.06e-14, 3.33e-16, 2.36e-10, 3.33e-15, 2.12e-8]
+OBS_B_RELX = [4.09e-12, 4.87e-12, 1.27e-11, 0, 4.7e-13, 2.58e-13, 1.4e-12, 0, 4.63e-11, 1.29e-10, 5.01e-9, 0, 5.22e-7, 8.73e-14, 2.62e-6, 0,
+              1.53e-9, 1.79e-10, 4.69e-9, 0]
+OBS_B_DB = [1.43e-10, 8.03e-11, 1.42e-8, 0, 3.46e-14, 3.31e-12, 1.82e-11, 0, 9.7e-9, 1.05e-8, 2.95e-7, 0, 1.13e-5, 1.75e-10, 1.35e-4, 0,
+            7.04e-8, 1.94e-8, 3.89e-8, 0]
+
+
+def bars(obs_relx, obs_d):
+    relx = max(10 * obs_relx, 1e-11)
+    return relx, max(10 * obs_d, 1e-12), max(1e-10, 100 * relx)
+
+
 @pytest.mark.parametrize("rec_index", range(11))
 def test_samplea_vs_reference(golden_dir, rec_index):
     L = capi.lib()
@@ -71,9 +88,10 @@ def test_samplea_vs_reference(golden_dir, rec_index):
     assert orc.close(ys[:3], want_y[:3], 1e-10)                  # log-posterior parity where x is identical
     relx = np.max(np.abs(xs - want_x) / np.abs(want_x))
     print(f"{rec['set']}: {len(xs)} evals, max rel dx {relx:.2e}, da {abs(got - fh(rec['a_out'])):.2e}")
-    assert relx <= 1e-4                                          # adaptive abscissae: see module docstring
-    assert orc.close(ys, want_y, 1e-7)                           # y at (slightly) different x
-    assert abs(got - fh(rec["a_out"])) <= 1e-6 * abs(fh(rec["a_out"]))
+    bar_x, bar_a, bar_y = bars(OBS_A_RELX[rec_index], OBS_A_DA[rec_index])
+    assert relx <= bar_x, (relx, bar_x)                           # adaptive abscissae: see module docstring
+    assert orc.close(ys, want_y, bar_y)                           # y at (slightly) different x
+    assert abs(got - fh(rec["a_out"])) <= bar_a, (abs(got - fh(rec["a_out"])), bar_a)
 
 
 @pytest.mark.parametrize("rec_index", range(11))
@@ -239,20 +257,42 @@ def test_sampleb_vs_reference(golden_dir, rec_index):
     assert orc.close(ys[:3], want_y[:3], 1e-10)
     relx = np.max(np.abs(xs - want_x) / np.abs(want_x))
     print(f"{rec['set']}: {len(xs)} evals, max rel dx {relx:.2e}, db {abs(got - want):.2e}")
-    assert relx <= 1e-4
-    assert orc.close(ys, want_y, 1e-7)
-    assert abs(got - want) <= 1e-6 * abs(want)
+    bar_x, bar_b, bar_y = bars(OBS_B_RELX[rec_index], OBS_B_DB[rec_index])
+    assert relx <= bar_x, (relx, bar_x)
+    assert orc.close(ys, want_y, bar_y)
+    assert abs(got - want) <= bar_b, (abs(got - want), bar_b)
 
 
-def test_slice_variant_runs_on_device(monkeypatch):
-    """STB_SAMPLER=slice routes samplea/sampleb through SliceSimple (lib/sslice.c path)"""
+@pytest.mark.parametrize("run", range(8))
+def test_samplea_slice_branch_vs_reference(golden_dir, monkeypatch, run):
+    """samplea's slice-sampler branch (lib/samplea.c:216-221 -> SliceSimple, lib/sslice.c:33-80) against the reference
+    compiled with that branch (oracle/_ref/libstb_ref_slice.so, tests/golden/samplers_slice.json): the bracket, the
+    number of posterior evaluations and EVERY abscissa are exact (they depend on the drand48 stream and on comparisons
+    of posterior values only), the draw is exact, the posterior values agree at 1e-10"""
+    L = capi.lib()
+    rec = load(golden_dir, "samplers_slice.json")["runs"][run]
+    monkeypatch.setenv("STB_SAMPLER", "slice")
+    g = synth.groups(*SETS[rec["set"]])
+    n, t = ragged(g)
+    orc.seed_libc(777, 12345)
+    got = L.samplea(fh(rec["a_in"]), g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, rec["loops"], 0)
+    xs, ys, _ = trace(L)
+    want_x = np.array([fh(v) for v in rec["trace"]["x"]])
+    want_y = np.array([fh(v) for v in rec["trace"]["y"]])
+    assert len(xs) == rec["trace"]["count"], (len(xs), rec["trace"]["count"])
+    assert np.array_equal(xs, want_x)
+    assert orc.close(ys, want_y, 1e-10), orc.max_err(ys, want_y)
+    assert got == fh(rec["a_out"])
+
+
+def test_sampleb_slice_variant_runs_on_device(monkeypatch):
+    """STB_SAMPLER=slice routes sampleb through SliceSimple too.  The reference's own slice branch of sampleb
+    (lib/sampleb.c:141-153) starts from bmax(), which needs digammaInv -- compiled out in the shipped configuration
+    (lib/digamma.h:25) -- so there is nothing to record: this variant starts from b_in (DESIGN deviation 7) and is checked
+    for its range only"""
     L = capi.lib()
     monkeypatch.setenv("STB_SAMPLER", "slice")
     g = synth.groups(20, 30, 300, "realistic")
-    n, t = ragged(g)
-    orc.seed_libc(777, 12345)
-    a = L.samplea(0.3, g.I, orc.i32p(g.K), orc.u32p(g.T), n, t, None, orc.dp(g.bpar), None, 2, 0)
-    assert 0.01 <= a <= 0.98 and L.stb_sampler_trace_count() >= 4
     orc.seed_libc(777, 12345)
     b = L.sampleb(10.0, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), 0.5, None, 2, 0)
     assert 0.01 <= b <= 2000

@@ -71,3 +71,28 @@ def test_asympt_and_policy_bitwise():
         for (n, m) in ((30, 3), (10 ** 6, 40), (2 * 10 ** 9, 7)):
             assert L.orc_S_asympt(a, n, m) == R.S_asympt(sp, n, m)
         R.S_free(sp)
+
+
+def test_slice_fixture_is_what_the_slice_build_of_the_reference_gives(golden_dir):
+    """tests/golden/samplers_slice.json against oracle/_ref/libstb_ref_slice.so (samplea's slice branch,
+    lib/samplea.c:216-221): the committed fixture is reproduced bit for bit"""
+    import json
+    import os
+    if not orc.have_ref_slice():
+        pytest.skip("oracle/_ref/libstb_ref_slice.so not built")
+    RS = orc.ref_slice()
+    SETS = {"small_wide": (20, 30, 300, "wide"), "small_real": (20, 30, 300, "realistic"), "mid_wide": (100, 100, 1000, "wide")}
+    runs = json.load(open(os.path.join(golden_dir, "samplers_slice.json")))["runs"]
+    seen = 0
+    for rec in runs:
+        if rec["set"] not in SETS:
+            continue
+        g = synth.groups(*SETS[rec["set"]])
+        orc.seed_libc(777, 12345)
+        r = RS.ref_samplea_flat(float.fromhex(rec["a_in"]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t),
+                                orc.dp(g.bpar), rec["loops"], 0)
+        assert r == float.fromhex(rec["a_out"])
+        assert RS.ref_trace_count() == rec["trace"]["count"]
+        assert [RS.ref_trace_x(i) for i in range(RS.ref_trace_count())] == [float.fromhex(v) for v in rec["trace"]["x"]]
+        seen += 1
+    assert seen >= 6
