@@ -1090,6 +1090,7 @@ int stb_launch_chain(fill_args &A, int D, char *ws, size_t ws_left, const dot_re
   X.nsg = dot ? dot->nsg : 0;
   X.dotp = dot ? dot->dotp : nullptr;
   if (dot) const_cast<dot_request *>(dot)->parts_per_table = sg.B * sg.MG * sg.C * sg.P;
+  if (dot && dot->dotp_cap && (size_t)D * (size_t)dot->parts_per_table > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
   const int dk = !dot ? 0 : (dot->item_ptr ? 2 : 1);
 #ifdef STB_STAMPS
   X.dbg = nullptr;

@@ -1237,6 +1237,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     X.ent_cnt = dot->ent_cnt;
     X.dotp = dot->dotp;
     const_cast<dot_request *>(dot)->parts_per_table = (int)g.n_tiles;
+    if (dot->dotp_cap && (size_t)D * g.n_tiles > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
   }
   if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");

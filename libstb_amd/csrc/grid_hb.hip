@@ -40,6 +40,9 @@
 #define GH_JOB_MB 192          // room for the records of helper jobs
 #define GH_JOBS 1500           // jobs of a table at most
 #define GH_JQ 64               // strips (from the left) whose tiles can be jobs: a queue each
+// a listed cell's position: row in group << GH_PB(C) | element of the wave (64 C of them, halo included); a dense word is
+// position | count << (GH_PB(C) + 5)
+#define GH_PB(C) ((C) == 8 ? 9 : 8)
 #ifndef GH_NOSTORE
 #define GH_NOSTORE 0          // diagnostic build: 1 nothing is staged (results wrong)
 #endif
@@ -119,10 +122,10 @@ __host__ __device__ static inline int gh_first_block(int j, int UC, int R) { ret
 template <int C, int K>
 __device__ __forceinline__ void gh_lookup(bool valid, unsigned pos, unsigned cnt, const double *stage, const int *se,
                                           const double2 *lt, double a, int mE0, int nrow0, int one_hi, long long &accK, double &accF) {
-  static_assert(K == 2 || (K == 4 && C == 4), "rows between two staged ones");
+  static_assert(K == 2 || (K == 4 && C >= 4), "rows between two staged ones");
   constexpr int WS = 64 * C;
   if (valid) {
-    const int cw = (int)(pos & 255u), r = (int)(pos >> 8) & 31;
+    const int cw = (int)(pos & ((1u << GH_PB(C)) - 1u)), r = (int)(pos >> GH_PB(C)) & 31;
     const int j = r & (K - 1);  // steps below the staged row
     const double *row = stage + (r / K) * WS;
     const int ln = cw / C;
@@ -166,9 +169,12 @@ __device__ __forceinline__ void gh_lookup(bool valid, unsigned pos, unsigned cnt
 }
 
 // K: every K-th row of a group is staged (2, or 4 with 4 columns per lane)
+#ifndef GH_C8_WAVES
+#define GH_C8_WAVES 2  // waves per SIMD the 8-column kernels are compiled for (191 registers; with 3 the compiler spills into the block loop: bare walk 1.32 against 1.04 ms)
+#endif
 template <int C, int G, int K>
-__global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
-  static_assert(C == 2 || C == 4, "columns per lane");
+__global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_grid_hb(gh_args X) {
+  static_assert(C == 2 || C == 4 || C == 8, "columns per lane");
   static_assert(G % K == 0 && G >= K && G <= 32, "rows per group");
   constexpr int WS = 64 * C, SR = G / K;  // doubles of a staged row, staged rows of a group
   constexpr int MHL = GH_MAXR / C;
@@ -298,12 +304,8 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
             gh_row<C>(v, coef, s);
             if ((r % K) == 0 && !GH_NOSTORE) {
               double *dst = stage + (r / K) * WS + lane * C;
-              if constexpr (C == 4) {
-                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
-                *reinterpret_cast<gh_double2 *>(dst + 2) = gh_double2{v[2], v[3]};
-              } else {
-                *reinterpret_cast<gh_double2 *>(dst) = gh_double2{v[0], v[1]};
-              }
+#pragma unroll
+              for (int i = 0; i < C; i += 2) *reinterpret_cast<gh_double2 *>(dst + i) = gh_double2{v[i], v[i + 1]};
             }
           }
           const int nrow0 = 2 + b * R + q * G;  // the row the group's first step produces
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
               asm volatile("" ::: "memory");
               unsigned wn = 0;
               if (k + 1 < nw) wn = gw[(size_t)(k + 1) * 64];
-              gh_lookup<C, K>(wd != 0, wd & 0x1fffu, wd >> 13, stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
+              gh_lookup<C, K>(wd != 0, wd & ((1u << (GH_PB(C) + 5)) - 1u), wd >> (GH_PB(C) + 5), stage, se, lt, a, mE0, nrow0, one_hi, accK, accF);
               wd = wn;
             }
           } else {
@@ -414,13 +416,15 @@ __global__ __launch_bounds__(64 * GH_NWMAX, 2) void k_grid_hb(gh_args X) {
         unsigned idle = 0;
         while (__hip_atomic_load(X.jflag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(8);
-          if ((++idle & 31) != 0) continue;
+          // (a timeout of 0 means "give up at once" in EVERY wait of this kernel and of k_fill_hb -- the fetcher's, the
+          // spine's, the tile workers' and this one: what STB_CHAIN_TIMEOUT_MS=0 is for, the tests of the fallback)
+          if ((++idle & 31) != 0 && X.timeout != 0) continue;
           if (!timing) {
             timing = true;
             t_begin = wall_clock64();
           }
           const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || (X.timeout != 0 && (unsigned long long)wall_clock64() - t_begin >= X.timeout)) {
+          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
             if (err == 0 && lane == 0) {
               __hip_atomic_store(X.hdr + 2, (unsigned)(jj | (dd << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -672,8 +676,23 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
     const int HL2 = R / 2, U2 = 64 - HL2;
     const uint64_t strips2 = (cmax - 1 + U2 * 2 - 1) / (U2 * 2);
     const uint64_t wgs2 = (strips2 + 3) / 4 * (uint64_t)D;
-    g.C = stb_env_int("STB_GRID_C", wgs2 <= (uint64_t)cus ? 2 : 4);
-    if (g.C != 2 && g.C != 4) g.C = 2;
+    // ... 8 columns per lane (round 5; a strip is 58 own lanes = 464 columns, a table of 10^4 columns 22 strips) only when
+    // asked for, STB_GRID_C=8 or a threshold of 4-column workgroups in STB_GRID_C8_WGS.  Built on the review's advice for
+    // 64 discounts -- 704 workgroups of 3 waves, all resident, where the 4-column form's 784 do not fit and the strips
+    // right of column 6656 start when the first end -- and on tools/ubench/rowpace.hip (chip full: 0.104 against 0.197 ns
+    // per own column and row).  Measured (MI355X, 64 discounts x 10^6 pairs, N = 10^4, kernel ms, profiles/r05_grid_c8.txt):
+    // 1.57 against the 4-column form's 1.42; the bare walk 0.98 against 0.80.  Why: a table is a CHAIN of N row steps
+    // whatever the strip width, and under this load (two walking waves a SIMD, clock ~2.0 GHz) a row of 8 columns per
+    // lane takes 62 ns against 41 -- strip 0 alone is 0.65 ms against 0.41 -- so what the wider strip saves in
+    // instructions and residency it loses on every table's critical path.  The form is kept (tested in every strip
+    // shape) for batches whose chain is not what bounds them.
+    const int HL4 = R / 4, U4 = 64 - HL4;
+    const uint64_t strips4 = (cmax - 1 + U4 * 4 - 1) / (U4 * 4);
+    const uint64_t wgs4 = (strips4 + 3) / 4 * (uint64_t)D;
+    const int c8_from = stb_env_int("STB_GRID_C8_WGS", 0);  // 4-column workgroups from which the 8-column form takes over (0: never)
+    g.C = stb_env_int("STB_GRID_C", wgs2 <= (uint64_t)cus ? 2 : ((c8_from > 0 && wgs4 > (uint64_t)c8_from && R % 8 == 0) ? 8 : 4));
+    if (g.C != 2 && g.C != 4 && g.C != 8) g.C = 2;
+    if (R % g.C != 0) return 1;
   }
   g.R = R;
   g.HL = R / g.C;
@@ -685,8 +704,9 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
   if (g.JW >= 65535 || g.NB >= 65536) return 1;
   // strips per workgroup: 4, a walking wave per SIMD (MI355X, 64 discounts x 10^6 pairs, N = M = 10^4, groups of 12
   // rows, kernel ms: 3 strips 1.84, 4: 1.73, 5: 1.81, 6: 1.90, 7: 1.85)
-  g.P = stb_env_int("STB_GRID_P", 4);
-  if (g.P < 1 || g.P > GH_PMAX) g.P = 4;
+  // (8 columns per lane: 3 -- a staged row is 4 KB; 512 workgroups of 4 waves for 64 tables of 10^4 columns, two a unit)
+  g.P = stb_env_int("STB_GRID_P", g.C == 8 ? 3 : 4);
+  if (g.P < 1 || g.P > GH_PMAX) g.P = g.C == 8 ? 3 : 4;
   g.B = (g.JW + g.P - 1) / g.P;
   // rows per group: a look-up pass costs the same for 1 or 64 listed cells (10^6 pairs over a 10^4 x 10^4 table: 1.6
   // a row in a strip of 80 columns, 4.2 in one of 208), and half of a group's rows are staged in LDS per walking wave
@@ -696,8 +716,8 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
     // (4 columns per lane, 64 discounts as above: groups of 8 rows 1.85, 12: 1.73, 16: 1.97)
     const bool two_per_cu = (int64_t)g.B * D > cus;
     // (... with the dense lists: 12 rows 1.57, 16: 1.46, 24: 1.39)
-    int Gd = (g.C == 2) ? 24 : ((g.P > 4 && two_per_cu) ? 8 : 24);
-    g.K = (g.C == 4) ? (stb_env_int("STB_GRID_K", 4) == 2 ? 2 : 4) : 2;  // every K-th row of a group is staged
+    int Gd = (g.C == 2) ? 24 : (g.C == 8 ? 16 : ((g.P > 4 && two_per_cu) ? 8 : 24));
+    g.K = (g.C >= 4) ? (stb_env_int("STB_GRID_K", 4) == 2 ? 2 : 4) : 2;  // every K-th row of a group is staged
     Gd = stb_env_int("STB_GRID_G", Gd);
     while (Gd > 2 && (R % Gd != 0 || (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24))) Gd -= 2;
     if (Gd != 8 && Gd != 12 && Gd != 16 && Gd != 24) Gd = 8;
@@ -767,15 +787,16 @@ size_t stb_grid_workspace(unsigned N, unsigned M, int D) {
   size_t need = 0;
   grid_geom g;
   if (stb_grid_geometry(N, M, D, &g) == 0) need = g.bytes;
-  const int cs[2] = {2, 4};
+  const int cs[3] = {2, 4, 8};
   const int Pc = stb_period_rows(N);
   int R = GH_MAXR < Pc ? GH_MAXR : Pc;
   R = R / 8 * 8;
   if (R < 8 || N < 3 || M < 2) return need;
   const unsigned cmax = (M < N - 1) ? M : N - 1;
   for (int c : cs) {
+    if (R % c != 0) continue;
     const int HL = R / c, U = 64 - HL, UC = U * c;
-    const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R, B = (JW + 3) / 4;
+    const size_t JW = (cmax - 1 + UC - 1) / UC, NB = (N - 1 + R - 1) / R, B = (JW + (c == 8 ? 0 : 3)) / (c == 8 ? 1 : 4);
     const size_t jobs = stb_grid_job_cap(c, D, (unsigned)(JW * NB), 1);  // (records and "written" words of the helper jobs)
     const size_t b = 4096 + 64 * (GH_MAXPH + GH_JQ) + (size_t)D * B * NB * HL * (4 + 8 * c) + (size_t)D * JW * 64 * (4 + 8 * c) + 2048 +
                      (size_t)D * jobs * (64 * (4 + 8 * c) + 4) + 1024;
@@ -864,6 +885,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   X.jrec_e = (int *)(ws + g.off_jrec_e);
   X.jrec_v = (double *)(ws + g.off_jrec_v);
   const_cast<dot_request *>(dot)->parts_per_table = g.JW + (int)dot->n_jobs;
+  if (dot->dotp_cap && (size_t)D * (size_t)(g.JW + (int)dot->n_jobs) * 2 > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
   const char *tl_file = getenv("STB_HB_TIMELINE");
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2);
   if (tl_file && *tl_file) {
@@ -884,7 +906,8 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
     X.ticket = X.hdr + 64 + 16 * ph;
     const unsigned grid = (unsigned)((jwa + g.P - 1) / g.P) * (unsigned)D;
     const int rc = (g.C == 2) ? gh_launch<2, 2>(X, g.G, grid, g.P, st)
-                              : (g.K == 4 ? gh_launch<4, 4>(X, g.G, grid, g.P, st) : gh_launch<4, 2>(X, g.G, grid, g.P, st));
+                   : (g.C == 8) ? (g.K == 4 ? gh_launch<8, 4>(X, g.G, grid, g.P, st) : gh_launch<8, 2>(X, g.G, grid, g.P, st))
+                                : (g.K == 4 ? gh_launch<4, 4>(X, g.G, grid, g.P, st) : gh_launch<4, 2>(X, g.G, grid, g.P, st));
     if (rc) return 1;
   }
   HIPCHK(hipGetLastError());

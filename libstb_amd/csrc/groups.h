@@ -7,7 +7,7 @@
 #include "stb_common.h"
 
 #define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
-#define STB_NLISTS 5
+#define STB_NLISTS 6
 #define STB_WS_FORM 4096  // lean flow: the discounts at the start of d_ws_fill, the form's workspace from here
 
 // ------------------------------------------------------------------------------------------------
@@ -40,7 +40,7 @@ struct stb_groups {
   // sparse form of the fused evaluation: CSR of the occurring cells per item, in several layouts, each built when
   // first needed: [0] (trip, 64-column slice from column 1) for k_fill_chain, [1] the same from column 2 for
   // k_fill_ck, [2] (tile, group of 4 rows) for k_fill_hb's tile workers, [3] / [4] (strip, block, group of G rows)
-  // for k_fill_hb's self-summing spine with 2 / 4 columns per lane (column 1 -- the pairs with t = 1 -- included)
+  // for k_grid_hb's self-summing spine with 2 / 4 columns per lane, [5] with 8 (column 1 -- the pairs with t = 1 -- included)
   unsigned *d_item_ptr[STB_NLISTS];
   unsigned short *d_ent_pos[STB_NLISTS];
   unsigned *d_ent_cnt[STB_NLISTS];
@@ -102,6 +102,11 @@ struct stb_groups {
   unsigned *h_nw;              // pinned [n_tiles + 2]: words per tile, read back for the helper jobs
   size_t h_nw_cap;
 };
+
+// the list layout of the grid form with C columns per lane, and back; a position is row << stb_pos_bits(C) | element of the wave
+static inline int stb_grid_which(int C) { return C == 2 ? 3 : (C == 4 ? 4 : 5); }
+static inline int stb_which_C(int which) { return which == 3 ? 2 : (which == 4 ? 4 : 8); }
+static inline int stb_pos_bits(int C) { return C == 8 ? 9 : 8; }
 
 // lists.hip
 int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H, const grid_geom &gg);  // 0 built (queued), 1 error, 2 not applicable

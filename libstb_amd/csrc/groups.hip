@@ -75,13 +75,12 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   STB_ENTRY;
   if (!g) return;
   const int prev_dev = stb_device_enter(g->dev);
-  void *ptrs[] = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out,
-                  g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms, g->d_cnt, g->d_n2, g->d_t2, g->d_dotp,
-                  g->d_item_ptr[0], g->d_ent_pos[0], g->d_ent_cnt[0], g->d_item_ptr[1], g->d_ent_pos[1], g->d_ent_cnt[1],
-                  g->d_item_ptr[2], g->d_ent_pos[2], g->d_ent_cnt[2], g->d_item_ptr[3], g->d_ent_pos[3], g->d_ent_cnt[3],
-                  g->d_item_ptr[4], g->d_ent_pos[4], g->d_ent_cnt[4], g->d_tile_off[3], g->d_tile_off[4], g->d_dense[3], g->d_dense[4],
-                  g->d_tinfo[3], g->d_tinfo[4], g->d_jobs[3], g->d_jobs[4], g->d_tjob[3], g->d_tjob[4],
-                  g->d_slab, g->d_icnt, g->d_ninf, g->d_scan_tmp, g->d_tnw[3], g->d_tnw[4], g->d_twords[3], g->d_twords[4], g->d_toff[3], g->d_toff[4]};
+  std::vector<void *> ptrs = {g->d_n, g->d_T, g->d_t, g->d_bpar, g->d_tables, g->d_S1, g->d_out, g->d_ws_fill, g->d_ws_sweep, g->d_ws_terms,
+                              g->d_cnt, g->d_n2, g->d_t2, g->d_dotp, g->d_slab, g->d_icnt, g->d_ninf, g->d_scan_tmp};
+  for (int w = 0; w < STB_NLISTS; w++)
+    for (void *q : {(void *)g->d_item_ptr[w], (void *)g->d_ent_pos[w], (void *)g->d_ent_cnt[w], (void *)g->d_tile_off[w], (void *)g->d_dense[w],
+                    (void *)g->d_tinfo[w], (void *)g->d_jobs[w], (void *)g->d_tjob[w], (void *)g->d_tnw[w], (void *)g->d_twords[w], (void *)g->d_toff[w]})
+      ptrs.push_back(q);
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
   stb_pool_free(g->h_out);
@@ -361,7 +360,7 @@ __global__ void k_item_keys_hb(const uint32_t *n, const uint16_t *t, uint64_t G,
 // item = (record index of tile (strip, block)) * NQ + group of G rows.  Column 1 (t = 1) is a cell too -- the last
 // element of strip 0's halo, which that strip computes along -- and a pair with t = n contributes log 1 = 0: what is
 // left as "other" are the pairs whose S_S is log 0 (lib/stable.c:948-949).
-__global__ void k_item_keys_hb2(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, hb_dot_info H,
+__global__ void k_item_keys_hb2(const uint32_t *n, const uint16_t *t, uint64_t G, unsigned N, unsigned M, hb_dot_info H, int posbits,
                                 uint64_t *key, uint32_t *payload) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
@@ -380,7 +379,7 @@ __global__ void k_item_keys_hb2(const uint32_t *n, const uint16_t *t, uint64_t G
     const unsigned b0 = (unsigned)(((unsigned long long)j * (unsigned)H.UC) / (unsigned)H.R);
     const unsigned rec = H.rec_off[j + 1] + (b - b0);
     const unsigned q = r / (unsigned)H.G;
-    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << 13) | ((uint64_t)(r - q * (unsigned)H.G) << 8) | cw;
+    k = ((((uint64_t)rec * (unsigned)H.NQ) + q) << (posbits + 5)) | ((uint64_t)(r - q * (unsigned)H.G) << posbits) | cw;
   }
   key[g] = k;
   payload[g] = (uint32_t)g;
@@ -431,7 +430,7 @@ __global__ void k_split_runs(const uint64_t *ukey, const unsigned *runs, unsigne
 // NW = 63 marks a tile taken from the CSR lists instead (a count of 2^19 or more, or more words than STB_DENSE_NWMAX).
 #define STB_DENSE_NWMAX 40
 #define STB_DENSE_CSR 63u
-__global__ void k_tile_words(const unsigned *item_ptr, const unsigned *cnt, unsigned n_tiles, unsigned NQ, unsigned *tnw, unsigned *twords) {
+__global__ void k_tile_words(const unsigned *item_ptr, const unsigned *cnt, unsigned n_tiles, unsigned NQ, int wbits, unsigned *tnw, unsigned *twords) {
   const unsigned t = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
   if (t >= n_tiles) return;
   const unsigned e0 = item_ptr[(size_t)t * NQ], e1 = item_ptr[(size_t)t * NQ + NQ];
@@ -441,7 +440,7 @@ __global__ void k_tile_words(const unsigned *item_ptr, const unsigned *cnt, unsi
     nw = max(nw, (c + 63) / 64);
   }
   bool big = false;
-  for (unsigned e = e0 + lane; e < e1; e += 64) big = big || cnt[e] >= (1u << 19);
+  for (unsigned e = e0 + lane; e < e1; e += 64) big = big || cnt[e] >= (1u << (32 - wbits));  // (a word is position | count << wbits)
   if (__any(big) || nw > STB_DENSE_NWMAX) nw = STB_DENSE_CSR;
   if (lane == 0) {
     tnw[t] = nw;
@@ -449,7 +448,7 @@ __global__ void k_tile_words(const unsigned *item_ptr, const unsigned *cnt, unsi
   }
 }
 
-__global__ void k_dense_fill(const unsigned *item_ptr, const unsigned short *pos, const unsigned *cnt, unsigned nitems, unsigned NQ,
+__global__ void k_dense_fill(const unsigned *item_ptr, const unsigned short *pos, const unsigned *cnt, unsigned nitems, unsigned NQ, int wbits,
                              const unsigned *tnw, const unsigned *toff, unsigned *dense, unsigned *tinfo) {
   const unsigned i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
   if (i >= nitems) return;
@@ -459,7 +458,7 @@ __global__ void k_dense_fill(const unsigned *item_ptr, const unsigned short *pos
   if (nw == STB_DENSE_CSR) return;
   const unsigned e0 = item_ptr[i], e1 = item_ptr[i + 1];
   unsigned *dst = dense + ((size_t)toff[t] + (size_t)q * nw) * 64;
-  for (unsigned k = lane; k < nw * 64; k += 64) dst[k] = (e0 + k < e1) ? ((unsigned)pos[e0 + k] | (cnt[e0 + k] << 13)) : 0u;
+  for (unsigned k = lane; k < nw * 64; k += 64) dst[k] = (e0 + k < e1) ? ((unsigned)pos[e0 + k] | (cnt[e0 + k] << wbits)) : 0u;
 }
 
 // item_ptr[i] = first run whose item index is >= i
@@ -504,12 +503,13 @@ void stb_lists_dense_kernels(stb_groups_t *g, int which, unsigned n_tiles, unsig
                              int stage) {
   if (!n_tiles) return;
   if (stage == 0) {
-    hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ, tnw, twords);
+    const int wbits = stb_pos_bits(stb_which_C(which)) + 5;
+    hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ, wbits, tnw, twords);
     size_t tb = g->scan_tmp_bytes;
     (void)rocprim::exclusive_scan(g->d_scan_tmp, tb, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st);
   } else if (nitems) {
     hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which], g->d_ent_cnt[which], nitems, NQ,
-                       tnw, toff, g->d_dense[which], g->d_tinfo[which]);
+                       stb_pos_bits(stb_which_C(which)) + 5, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
   }
 }
 
@@ -592,7 +592,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
   if (which >= 3) {
     // (the strip shape of the grid form depends on the number of discounts: a list per shape)
     if (stb_grid_geometry(N, M, D, &gg)) return stb_fail("stb_groups_aterms: no grid geometry for N=%u M=%u", N, M);
-    which = (gg.C == 2) ? 3 : 4;
+    which = stb_grid_which(gg.C);
     H.R = gg.R;
     H.UC = gg.U * gg.C;
     H.HC = gg.HL * gg.C;
@@ -655,7 +655,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       break;
     }
     if (which >= 3)
-      hipLaunchKernelGGL(k_item_keys_hb2, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, k0, p0);
+      hipLaunchKernelGGL(k_item_keys_hb2, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, stb_pos_bits(H.C), k0, p0);
     else if (which == 2)
       hipLaunchKernelGGL(k_item_keys_hb, dim3(blocks), dim3(256), 0, g->st, g->d_n, g->d_t, G, N, M, H, k0, p0);
     else
@@ -725,7 +725,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
     }
     if (h_runs) {
       hipLaunchKernelGGL(k_split_runs, dim3((h_runs + 255) / 256), dim3(256), 0, g->st, uk, runs, g->d_ent_pos[which], item,
-                         which >= 3 ? 13 : (which == 2 ? 11 : 9));
+                         which >= 3 ? stb_pos_bits(H.C) + 5 : (which == 2 ? 11 : 9));
       if (hipMemcpyAsync(g->d_ent_cnt[which], cnt, 4 * (size_t)h_runs, hipMemcpyDeviceToDevice, g->st) != hipSuccess) break;
     }
     hipLaunchKernelGGL(k_item_ptr, dim3((nitems + 1 + 255) / 256), dim3(256), 0, g->st, item, runs, nitems, g->d_item_ptr[which]);
@@ -742,7 +742,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       unsigned h_last[2] = {0, 0};
       if (ok && n_tiles) {
         hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ,
-                           tnw, twords);
+                           stb_pos_bits(H.C) + 5, tnw, twords);
         ok = rocprim::exclusive_scan(nullptr, b3, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st) == hipSuccess &&
              stb_pool_malloc(&tmp2, b3 ? b3 : 1) == hipSuccess &&
              rocprim::exclusive_scan(tmp2, b3, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st) == hipSuccess &&
@@ -755,7 +755,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       ok = ok && stb_pool_malloc((void **)&g->d_dense[which], 256 * (words ? words : 1)) == hipSuccess;
       if (ok && nitems)
         hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which],
-                           g->d_ent_cnt[which], nitems, NQ, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
+                           g->d_ent_cnt[which], nitems, NQ, stb_pos_bits(H.C) + 5, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
       if (ok) ok = hipStreamSynchronize(g->st) == hipSuccess;
       // The tiles whose listed cells the strip's own wave does not look up: every strip of a table moves at the pace of
       // the strips to its left, and those hold most of the pairs (t uniform below n: columns like log) -- several
@@ -891,7 +891,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
   req.col0 = which >= 3 ? 4 : 3;
   if (which == 2) req.geom_C = g->hb_sum_C;  // (the strip shape the set's lists were built for)
   if (which >= 3) {
-    req.geom_C = which == 3 ? 2 : 4;
+    req.geom_C = stb_which_C(which);
     req.geom_R = g->list_R[which];
     req.geom_G = g->list_G[which];
     req.tile_off = g->d_tile_off[which];
@@ -902,6 +902,7 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
     req.n_jobs = g->n_jobs[which];
   }
   req.dotp = g->d_dotp;
+  req.dotp_cap = g->dotp_elems;
   req.ws_zero = g->ws_zero;
   req.no_s1 = 1;
   fill_args A;
@@ -965,6 +966,7 @@ static int aterms_issue(stb_groups_t *g, const double *x_host, int D, double *ou
       req.cnt = g->d_cnt;
     }
     req.dotp = g->d_dotp;
+    req.dotp_cap = g->dotp_elems;
     stb_set_dot_request(&req);
     const int rc = stb_fill_S(x_host, D, g->N, g->M, g->d_tables, g->tstride, g->d_S1, g->N, g->d_ws_fill,
                               g->ws_fill, which ? STB_FILL_CK : STB_FILL_CHAIN, g->st);
@@ -1109,7 +1111,7 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
       hb_dot_info H;
       const bool hb_range = stb_hb_dot_info(g->N, g->M, D, &H, g->hb_sum_C) == 0 && H.n_spine <= hb_max_spine();
       const bool sparse_pairs = (double)g->G <= 0.04 * (double)stb_table_cells(g->N, g->M);
-      if (force > 0 || (!hb_range && sparse_pairs && stb_env_int("STB_ATERMS_HB", 1))) which = (gg.C == 2) ? 3 : 4;
+      if (force > 0 || (!hb_range && sparse_pairs && stb_env_int("STB_ATERMS_HB", 1))) which = stb_grid_which(gg.C);
     }
   }
   if (fuse && which == 0 && (v == STB_FILL_HB || (v == STB_FILL_SCALED && stb_env_int("STB_ATERMS_HB", 1)))) {

@@ -37,6 +37,7 @@ void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off);  // 
 
 struct slab_info {
   int R, G, NQ, UC, HC;  // rows of a block / of a group, groups per item base, own columns of a strip, halo columns
+  int PB;                // a position is row in group << PB | element of the wave
   unsigned UCp;          // words of a row of an item: column 1 (strip 0 only) + the strip's own columns
   const unsigned *rec_off;
 };
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(unsigned *slab, const unsign
     if (c != 0u) {
       const unsigned o = out + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
       const unsigned r = i / H.UCp, col = i - r * H.UCp;
-      ent_pos[o] = (unsigned short)((r << 8) | ((unsigned)H.HC - 1u + col));
+      ent_pos[o] = (unsigned short)((r << H.PB) | ((unsigned)H.HC - 1u + col));
       ent_cnt[o] = c;
       w[i] = 0u;
     }
@@ -200,7 +201,8 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
   const uint64_t nitems64 = (uint64_t)H.n_rec * (unsigned)H.NQ;
   const uint64_t elems64 = nitems64 * (unsigned)H.G * S.UCp;
   if (nitems64 >= (1ull << 31) || elems64 * 4 > slab_limit_bytes()) return 2;
-  if (H.G > 32 || H.HC - 1 + (int)S.UCp > 256) return 2;  // (a position is row << 8 | element, 13 bits)
+  S.PB = which >= 3 ? stb_pos_bits(H.C) : 8;
+  if (H.G > 32 || H.HC - 1 + (int)S.UCp > (1 << S.PB)) return 2;  // (a position is row << PB | element)
   const unsigned nitems = (unsigned)nitems64;
   const size_t elems = (size_t)elems64;
   hipStream_t st = g->st;

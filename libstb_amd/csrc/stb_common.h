@@ -141,6 +141,7 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   unsigned n_jobs = 0;
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
+  size_t dotp_cap = 0;                     // in: doubles `dotp` holds; a launch whose partial sums would not fit is refused BEFORE anything is queued
   size_t ws_zero = 0;                      // in: bytes at the start of the workspace the caller knows to be zero (no memset then)
   size_t zero_bytes = 0;                   // out: bytes at the start of the workspace the launch needs zero (and dirties)
   int no_s1 = 0;                           // in: nobody reads the S1 vector (column 1 is among the listed cells)

@@ -365,11 +365,14 @@ def _edge_pairs(C):
     n[6:40], t[6:40] = 400, 123    # many pairs on one cell
     n[40], t[40] = 49, 2       # last row of block 0
     n[41], t[41] = 50, 2       # first row of block 1
-    n[42], t[42] = 300, UC + 1     # last own column of strip 0
-    n[43], t[43] = 300, UC + 2     # first own column of strip 1
+    nr = 300 if UC + 2 < 300 else UC + 120   # (a row below the diagonal at the strip edge: 8 columns per lane make strips of 464)
+    n[42], t[42] = nr, UC + 1      # last own column of strip 0
+    n[43], t[43] = nr, UC + 2      # first own column of strip 1
     n[44], t[44] = UC + 3, UC + 2  # next to the diagonal in strip 1's first block
-    n[60], t[60] = 301, UC + 2     # the same column in an odd row of a group (taken from the staged row above it)
-    n[61], t[61] = 302, UC + 2
+    n[60], t[60] = nr + 1, UC + 2  # the same column in an odd row of a group (taken from the staged row above it)
+    n[61], t[61] = nr + 2, UC + 2
+    n[64], t[64] = nr + 3, UC + 2  # ... three rows below a staged one (every 4th row staged)
+    n[65], t[65] = nr + 3, UC + 4
     n[62], t[62] = 52, 3
     n[63], t[63] = 53, 3
     n[45], t[45] = 2, 1        # S^2_1 = 1 - a: a negative log
@@ -385,7 +388,9 @@ HELP_OFF = {"STB_GRID_HELP": "0"}
 
 @pytest.mark.parametrize("C,P,G,PH,env", [(2, 4, 24, 1, {}), (2, 7, 12, 3, {}), (2, 2, 8, 1, {}), (4, 4, 12, 1, {}), (4, 7, 8, 4, {}),
                                           (4, 3, 16, 2, {}), (4, 4, 24, 5, {}), (2, 4, 24, 1, HELP_ALL), (4, 4, 24, 1, HELP_ALL),
-                                          (4, 3, 12, 1, HELP_ALL), (4, 4, 24, 1, HELP_FEW), (4, 4, 24, 1, HELP_OFF), (4, 4, 8, 3, HELP_ALL)])
+                                          (4, 3, 12, 1, HELP_ALL), (4, 4, 24, 1, HELP_FEW), (4, 4, 24, 1, HELP_OFF), (4, 4, 8, 3, HELP_ALL),
+                                          (8, 2, 16, 1, {}), (8, 3, 24, 1, {}), (8, 2, 8, 2, {}), (8, 4, 12, 1, HELP_ALL), (8, 2, 16, 1, HELP_ALL),
+                                          (8, 2, 16, 1, {"STB_GRID_K": "2"}), (8, 1, 24, 3, HELP_OFF)])
 def test_fused_aterms_the_spine_sums(monkeypatch, C, P, G, PH, env):
     """the default for a grid since round 4: k_grid_hb<C, G> (grid_hb.hip), whose walking waves stage every other
     row of a group of G in LDS and sum their own strip's listed cells (column 1 included; no tile workers, no S1

@@ -57,5 +57,10 @@ int main(){
   for (int wgs : {1, 64, 256}) run<4>(d, wgs, 8, 4, big);
   for (int wgs : {64, 256}) run<4>(d, wgs, 8, 8, big);
   for (int wgs : {512}) run<4>(d, wgs, 8, 7, 40*1024);
+  // (round 5) 8 columns per lane: 464 own columns a strip, 22 strips a 10^4-column table
+  for (int wgs : {1, 64, 256}) run<8>(d, wgs, 8, 4, big);
+  for (int wgs : {256}) run<8>(d, wgs, 8, 8, big);
+  for (int wgs : {512, 768}) run<8>(d, wgs, 3, 2, 50*1024);
+  for (int wgs : {768}) run<4>(d, wgs, 5, 4, 50*1024);
   return 0;
 }
