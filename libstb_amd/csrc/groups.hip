@@ -1084,7 +1084,7 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
   // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine
   // workgroups all fit on the chip.  It is not the default: MI355X, 10^6 pairs, N = M = 10^4, its 0.66 ms
-  // at 2-4 discounts and 0.85-0.96 at 8 against the chain form's 0.73-0.77 and 0.87-0.97 (tools/time_grid.py)
+  // at 2-4 discounts and 0.85-0.96 at 8 against the chain form's 0.73-0.77 and 0.87-0.97 (tools/ablation/time_grid.py)
   // -- the tiles' requests for edges, checkpoints and cell lists stretch the spine's hand-offs between
   // workgroups from 2 to ~17 us, which eats what the lighter spine gains.
   int which = 0;
@@ -1094,7 +1094,7 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
   // ... and in the halo-block form (a spine that walks blocks of rows alone + tile workers that sum their
   // tiles' listed cells): the default for a grid while the chip holds its spine -- 49 strips per table of 10^4
   // columns, four to a workgroup up to 17 discounts, seven beyond: up to 24 discounts (1200 strips in all); STB_ATERMS_HB=0 switches
-  // it off.  (MI355X, tools/time_grid.py, 10^6 pairs, N = M = 10^4, kernel / wall ms: 2 discounts 0.36 / 0.45
+  // it off.  (MI355X, tools/ablation/time_grid.py, 10^6 pairs, N = M = 10^4, kernel / wall ms: 2 discounts 0.36 / 0.45
   // against 0.76 / 0.83 chain, 4: 0.36 / 0.45 against 0.78 / 0.86, 8: 0.44 / 0.53 against 0.89 / 0.97, 16: 0.76 /
   // 0.86 against 0.98 / 1.07, 24: 1.07 / 1.15 against 1.25 / 1.34, 28: 1.22 against 1.32, 30: 1.55 against 1.37,
   // 64: 2.7 against 2.4.)
