@@ -18,6 +18,9 @@ GPU by then).  WHAT:
     sweep64              the same grid through stored tables             (k_fill_pc, k_sweep_partial)
     eval1                one-discount aterms, 10^6 pairs, n < 4000       (k_fill_chain, k_sweep_partial, k_terms_partial)
     bterms               stb_bterms, 10^6 restaurants x 20 abscissae     (k_terms_partial)
+    fresh_samplea        samplea on pairs that change between calls (10^6 pairs, n < 4000): upload, cell lists from the count
+                         slab (k_count_cells, k_item_count, k_emit_cells), 8 fused evaluations (k_fill_hb<2,1,0>)
+    fresh_grid64 fresh_grid8   stb_groups_update_pairs + the first 64- / 8-discount evaluation on the new pairs, n < 10000
 """
 import os
 import sys
@@ -102,6 +105,35 @@ elif what == "bterms":
     for _ in range(reps):
         capi.bterms(x, 0.05, g.shape, 0.5, dg)
     torch.cuda.synchronize()
+elif what == "fresh_samplea":
+    import ctypes as C
+    import orc
+    g = synth.groups(1000, 1000, 4000, "wide")
+    NP = C.POINTER(C.c_uint32) * g.I
+    TP = C.POINTER(C.c_uint16) * g.I
+    nn, tt = NP(), TP()
+    off = 0
+    for i in range(g.I):
+        nn[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+        tt[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
+        off += int(g.K[i])
+    for r in range(reps + 2):
+        g.n[12345 + 977 * r] += 1
+        orc.seed_libc(777, 12345)
+        L.samplea(0.5, g.I, g.K.ctypes.data_as(capi.c_int_p), g.T.ctypes.data_as(capi.c_u32_p), nn, tt, None, capi.dp(g.bpar), None, 1, 0)
+    L.stb_sampler_cache_clear()
+elif what in ("fresh_grid64", "fresh_grid8"):
+    Dg = 8 if what.endswith("8") else 64
+    g = synth.groups(1000, 1000, N, "wide")
+    h = groups_handle(g, Dg)
+    x = np.ascontiguousarray(synth.discount_grid(64)[:Dg])
+    out = np.zeros(Dg)
+    capi.check(L.stb_groups_aterms(h, capi.dp(x), Dg, capi.dp(out)))
+    for r in range(reps + 1):
+        g.n[12345 + 977 * r] += 1
+        capi.check(L.stb_groups_update_pairs(h, g.n.ctypes.data_as(capi.c_u32_p), g.t.ctypes.data_as(capi.c_u16_p)))
+        capi.check(L.stb_groups_aterms(h, capi.dp(x), Dg, capi.dp(out)))
+    L.stb_groups_free(h)
 else:
     raise SystemExit("unknown workload " + what)
 print("done", what, reps)
