@@ -44,8 +44,9 @@ import torch
 from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-TRAFFIC_DB = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (4, 3)) if os.path.exists(p)),
-                  os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
+TRAFFIC_DB = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
+                  os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"))
+PROFILE_ROUND = next((r for r in (5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r0{r}_sq_counters_fill1.txt"))), 4)
 N_SIMD = 1024           # 256 compute units x 4 SIMDs (MI355X)
 NOMINAL_CLOCK_HZ = 2.4e9
 FORM_NAMES = {2: "pc", 3: "chain", 4: "ck", 6: "hb"}
@@ -171,12 +172,13 @@ def traffic_lookup(key: str, kernel_prefix: str):
 
 def valu_busy(workload: str, kernel_prefix: str):
     """fraction of the chip's vector-issue slots a kernel uses (SURVEY 8d asks for it beside the HBM fraction), from the
-    COMMITTED profiles of the same workload: SQ_INSTS_VALU wave-instructions (profiles/r04_sq_counters_<workload>.txt)
-    x 4 cycles / (1024 SIMDs x the kernel's average duration (profiles/r04_<workload>_kernel_stats.csv) x 2.4 GHz);
-    also SALU per VALU instruction and the share of LDS cycles lost to bank conflicts"""
+    COMMITTED profiles of the same workload -- static numbers, NOT measured by this run (PMC counters need rocprofv3):
+    SQ_INSTS_VALU wave-instructions (profiles/r0N_sq_counters_<workload>.txt) x 4 cycles / (1024 SIMDs x the kernel's
+    average duration (profiles/r0N_<workload>_kernel_stats.csv) x 2.4 GHz); also SALU per VALU instruction and the share
+    of LDS cycles lost to bank conflicts"""
     import csv
-    cpath = os.path.join(ROOT, "profiles", f"r04_sq_counters_{workload}.txt")
-    spath = os.path.join(ROOT, "profiles", f"r04_{workload}_kernel_stats.csv")
+    cpath = os.path.join(ROOT, "profiles", f"r0{PROFILE_ROUND}_sq_counters_{workload}.txt")
+    spath = os.path.join(ROOT, "profiles", f"r0{PROFILE_ROUND}_{workload}_kernel_stats.csv")
     if not (os.path.exists(cpath) and os.path.exists(spath)):
         return None
     vals, on = {}, False
@@ -195,12 +197,25 @@ def valu_busy(workload: str, kernel_prefix: str):
     if not vals.get("SQ_INSTS_VALU") or not dur_ns:
         return None
     out = {"valu_busy_frac": vals["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * dur_ns * 1e-9 * NOMINAL_CLOCK_HZ),
-           "valu_busy_source": f"profiles/r04_sq_counters_{workload}.txt, profiles/r04_{workload}_kernel_stats.csv ({kernel_prefix}, {dur_ns / 1e3:.1f} us)"}
+           "valu_busy_source": f"STATIC, from committed profiles (not this run): profiles/r0{PROFILE_ROUND}_sq_counters_{workload}.txt, "
+                               f"profiles/r0{PROFILE_ROUND}_{workload}_kernel_stats.csv ({kernel_prefix}, {dur_ns / 1e3:.1f} us)"}
     if vals.get("SQ_INSTS_SALU"):
         out["salu_per_valu"] = vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"]
     if vals.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_frac"] = vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / vals["SQ_LDS_IDX_ACTIVE"]
     return out
+
+
+def grid_kernel_label(N, M, D):
+    """the instantiation of k_grid_hb this run's geometry selects (env switches included), from the library itself"""
+    L = capi.lib()
+    try:
+        C_, G_, K_ = C.c_int(), C.c_int(), C.c_int()
+        if L.stb_grid_shape(N, M, D, C.byref(C_), C.byref(G_), C.byref(K_)) == 0:
+            return f"k_grid_hb<{C_.value},{G_.value},{K_.value}>"
+    except AttributeError:
+        pass
+    return "k_grid_hb"
 
 
 def groups_handle(L, g, N, M, Dmax):
@@ -643,16 +658,17 @@ def main():
                 vbg = valu_busy("grid64", "k_grid_hb")
                 out["roofline_sweep"] = {
                     "metric": "sampler grid-evals/s", "bound": "hbm",
-                    "kernel": "k_grid_hb<4,24,4>: the table walk of 64 discounts at N=M=10000 whose walking waves sum count * log S over "
-                              "their own strips' listed cells (no table stored, no tile workers, every 4th row staged in LDS), + the "
-                              "restaurant terms; what stb_groups_aterms runs for a grid beyond the tile-worker form's range",
+                    "kernel": f"{grid_kernel_label(s10k['N'], s10k['M'], 64)}: the table walk of 64 discounts at N=M=10000 whose walking waves sum "
+                              "count * log S over their own strips' listed cells (no table stored, no tile workers, every K-th row staged in "
+                              "LDS), + the restaurant terms; what stb_groups_aterms runs for a grid beyond the tile-worker form's range",
                     "grid_evals": fu["grid_evals"], "device_ms": dev_ms, "fill_ms": fu["fill_ms"],
                     "value": fu["grid_evals"] / (dev_ms * 1e-3), "unit": "grid-evals/s",
                     "algorithmic_bytes": alg, "achieved": alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "frac": alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
-                    "note": "not an HBM-bound kernel (its traffic is the cell lists and the records between workgroups, not tables): at 64 "
-                            "discounts it is bound by vector instruction issue -- 3.1 walking waves per SIMD, every table's strips in "
-                            "lockstep, the look-ups' recompute -- see valu_busy_frac and DESIGN.md",
+                    "note": "not an HBM-bound kernel (its traffic is the cell lists and the records between workgroups, not tables): every "
+                            "table is a chain of N row steps walked with two waves a SIMD, the look-ups of the leftmost strips sit on it, and "
+                            "a third of the workgroups start when the first end -- see valu_busy_frac (a static figure from the committed "
+                            "profiles) and DESIGN.md section 4",
                     **(vbg or {}),
                     "end_to_end": {"fused_grid_evals_per_s": fu["grid_evals_per_s_end_to_end"], "fused_wall_ms": fu["wall_ms"],
                                    "two_pass_grid_evals_per_s": tp["grid_evals_per_s_end_to_end"], "two_pass_wall_ms": tp["wall_ms"]},

@@ -219,6 +219,9 @@ int stb_groups_update_pairs(stb_groups_t *g, const uint32_t *nflat, const uint16
 /* how often, in this process, a fused evaluation (halo-block, grid or chain form) gave up waiting for a neighbour and
  * was repeated through stored tables (stb_fill_fallbacks counts the repeated FILLS of the calling thread) */
 unsigned stb_groups_fallbacks(void);
+/* the strip shape the grid form (k_grid_hb) takes for D discounts of an N x M table: columns per lane, rows per group,
+ * every K-th row staged (any pointer may be NULL); non-zero where that form does not apply.  Diagnostics. */
+int stb_grid_shape(unsigned N, unsigned M, int D, int *C_out, int *G_out, int *K_out);
 /* what the set was created with (any pointer may be NULL) */
 int stb_groups_shape(const stb_groups_t *g, int *I, uint64_t *G, unsigned *N, unsigned *M, int *Dmax);
 /* pieces of the same evaluation, for timing: ms of device time per stage (may be NULL) */

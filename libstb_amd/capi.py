@@ -56,8 +56,18 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     u, d, i, vp, u64, sz = C.c_uint, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_size_t
 
+    # entry points added in round 5: an older build loaded through STB_LIB_PATH (tools/ab_lib.py, A/B against an
+    # earlier round's library) simply lacks them; everything else must be there
+    ROUND5 = {"stb_groups_pairs_begin", "stb_groups_pairs_put", "stb_groups_pairs_put_ragged", "stb_groups_pairs_commit",
+              "stb_groups_update_pairs", "stb_groups_fallbacks", "stb_grid_shape", "stb_bterms_update"}
+
     def sig(name, res, args):
-        f = getattr(L, name)
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            if name in ROUND5 and os.environ.get("STB_LIB_PATH"):
+                return
+            raise
         f.restype = res
         f.argtypes = args
 
@@ -135,6 +145,7 @@ def lib() -> C.CDLL:
     sig("stb_groups_pairs_commit", i, [vp, c_u32_p, c_double_p, u, u])
     sig("stb_groups_update_pairs", i, [vp, c_u32_p, c_u16_p])
     sig("stb_groups_fallbacks", C.c_uint, [])
+    sig("stb_grid_shape", i, [u, u, i, c_int_p, c_int_p, c_int_p])
     sig("stb_groups_shape", i, [vp, c_int_p, C.POINTER(u64), C.POINTER(u), C.POINTER(u), c_int_p])
     sig("stb_sampler_cache_clear", None, [])
     sig("stb_groups_aterms_timed", i, [vp, c_double_p, i, c_double_p, c_float_p, c_float_p, c_float_p])

@@ -772,6 +772,17 @@ int stb_grid_geometry(unsigned N, unsigned M, int D, grid_geom *out) {
   return 0;
 }
 
+// the strip shape the grid form takes for these sizes: columns per lane, rows per group, every K-th row staged (diagnostics:
+// bench.py names the kernel instantiation with it); non-zero where the form does not apply
+extern "C" int stb_grid_shape(unsigned N, unsigned M, int D, int *C_out, int *G_out, int *K_out) {
+  grid_geom g;
+  if (stb_grid_geometry(N, M, D, &g)) return 1;
+  if (C_out) *C_out = g.C;
+  if (G_out) *G_out = g.G;
+  if (K_out) *K_out = g.K;
+  return 0;
+}
+
 unsigned stb_grid_job_cap(int C, int D, unsigned n_tiles, int phases) {
   if (phases != 1 || D < 1 || !stb_env_int("STB_GRID_HELP", 1)) return 0;
   uint64_t rec = 64ull * (4 + 8 * C), room = ((uint64_t)stb_env_int("STB_GRID_JOB_MB", GH_JOB_MB) << 20) / ((uint64_t)D * rec);
