@@ -40,6 +40,11 @@
 #define GH_JOB_MB 192          // room for the records of helper jobs
 #define GH_JOBS 1500           // jobs of a table at most
 #define GH_JQ 64               // strips (from the left) whose tiles can be jobs: a queue each
+// the job list in device memory: words [0, GH_JQ] the first job of every strip's queue (the last: the number of jobs),
+// word GH_JNUM the number of jobs -- read by the kernels, so that a list built ON the device needs no host round trip --,
+// jobs from word GH_JBASE on
+#define GH_JNUM (GH_JQ + 1)
+#define GH_JBASE 128
 // a listed cell's position: row in group << GH_PB(C) | element of the wave (64 C of them, halo included); a dense word is
 // position | count << (GH_PB(C) + 5)
 #define GH_PB(C) ((C) == 8 ? 9 : 8)
@@ -65,10 +70,10 @@ struct gh_args {
   const unsigned short *ent_pos;  // row in group << 8 | element of the wave
   const unsigned *ent_cnt;     // occurrence count
   double *dotp;                // [D][JW + n_jobs][2]: sum of count x binary exponent (an integer), sum of count x log of the mantissa part; a strip's, then a job's
-  const unsigned *jobs;        // [n_jobs] tiles left to helper waves: strip | block << 16, strip after strip, a strip's by block;
-                               // then [GH_JQ + 1] the first job of every strip (a queue per strip)
+  const unsigned *jobs;        // the job list (GH_JQ + 1 queue starts, the number of jobs at GH_JNUM, from GH_JBASE on the tiles left
+                               // to helper waves: strip | block << 16, strip after strip, a strip's by block), or null
   const unsigned *tjob;        // [n_tiles] a tile's place in `jobs`, or 0xffffffff
-  unsigned n_jobs;
+  unsigned job_cap;            // jobs a table has at most (what the records below are sized for)
   unsigned *jticket;           // [GH_JQ] x 16 words: per strip the next (job, table) to hand out, on a line of its own
   unsigned *jflag;             // [D][n_jobs] non-zero: the record is written
   int *jrec_e;                 // [D][n_jobs][64]      a job's record: the lane exponents of the tile's own wave before the block
@@ -194,8 +199,10 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_ticket = atomicAdd(X.ticket, 1u);
   if (tid < 128) lt[tid] = X.lt[tid];
-  if (X.n_jobs && tid <= GH_JQ) s_jq[tid] = X.jobs[X.n_jobs + tid];
+  if (X.jobs && tid <= GH_JQ) s_jq[tid] = X.jobs[tid];
   __syncthreads();
+  // (the number of jobs comes from device memory: the list may have been built on the device a moment ago)
+  const unsigned n_jobs = X.jobs ? min((unsigned)__builtin_amdgcn_readfirstlane((int)X.jobs[GH_JNUM]), X.job_cap) : 0u;
   const unsigned ticket = s_ticket;
   const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
   const int UC = U * C;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
     double a = X.a[d];
     int mE0 = 2 + (jw * U - HL) * C;            // column of the wave's first element (halo included; <= 0 in strip 0's halo)
     int m0 = mE0 + lane * C;
-    const size_t strip = ((size_t)d * (size_t)(X.JW + (int)X.n_jobs) + jw);  // the strip's pair of sums
+    const size_t strip = ((size_t)d * (size_t)(X.JW + (int)n_jobs) + jw);  // the strip's pair of sums
     double v[C], coef[C];
     int ep = 1 + PC_BIAS;
 #pragma unroll
@@ -367,7 +374,6 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
     // ---- helper jobs: a tile (strip jj, block jb, table dd) whose own wave only walked it, leaving the state of the
     // wave before the block; tickets go through the jobs in the order the tiles become ready, table after table.
     // Returns false when there is none left (or the launch is being given up). ----
-    const unsigned n_jobs = X.n_jobs;
     bool jobs_left = n_jobs != 0 && b00 >= bB && !(X.diag & 32);
     unsigned long long q_off = 0;  // queues this wave has found exhausted, or too late for it
     int q_next = (int)((ticket * 4u + (unsigned)w) % GH_JQ);
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
         got = true;
       }
       if (!got) return false;
-      const unsigned jd = X.jobs[job];
+      const unsigned jd = X.jobs[GH_JBASE + job];
       const int jj = (int)(jd & 0xffffu), jb = (int)(jd >> 16);
       const size_t slot = (size_t)dd * n_jobs + job;
       const unsigned tile = X.tile_off[jj + 1] + (unsigned)(jb - gh_first_block(jj, UC, R));
@@ -886,17 +892,19 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   X.poll_nap = stb_env_int("STB_HB_POLL_NAP", 4);
   if (X.poll_nap < 1) X.poll_nap = 1;
   X.diag = stb_env_int("STB_GRID_DIAG", 0);
-  if (dot->n_jobs > g.job_cap || (dot->n_jobs && (!dot->jobs || !dot->tjob)))
-    return stb_fail("stb_groups_aterms: %u helper jobs in the cell lists, room for %u in the workspace", dot->n_jobs, g.job_cap);
+  if (dot->jobs && !dot->tjob) return stb_fail("stb_groups_aterms: a job list without the tiles' places in it");
   X.jobs = dot->jobs;
   X.tjob = dot->tjob;
-  X.n_jobs = dot->n_jobs;
+  X.job_cap = g.job_cap;
+  if (!g.job_cap) X.jobs = nullptr;
   X.jticket = X.hdr + 64 + 16 * GH_MAXPH;  // (GH_JQ lines)
   X.jflag = (unsigned *)(ws + g.off_jflag);
   X.jrec_e = (int *)(ws + g.off_jrec_e);
   X.jrec_v = (double *)(ws + g.off_jrec_v);
-  const_cast<dot_request *>(dot)->parts_per_table = g.JW + (int)dot->n_jobs;
-  if (dot->dotp_cap && (size_t)D * (size_t)(g.JW + (int)dot->n_jobs) * 2 > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+  // (partial sums: two per strip and per job; the number of jobs is read from the list by whoever sums them up)
+  const_cast<dot_request *>(dot)->parts_per_table = g.JW;
+  const_cast<dot_request *>(dot)->parts_extra_dev = X.jobs ? X.jobs + GH_JNUM : nullptr;
+  if (dot->dotp_cap && (size_t)D * (size_t)(g.JW + (int)g.job_cap) * 2 > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
   const char *tl_file = getenv("STB_HB_TIMELINE");
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2);
   if (tl_file && *tl_file) {

@@ -8,7 +8,16 @@
 
 #define STB_TERMS_DMAX 64  // (as in sweep_terms.hip: abscissae per stb_restaurant_terms call)
 #define STB_NLISTS 6
+#define GH_JQ_HOST 64  // (grid_hb.hip: GH_JQ, the strips from the left whose tiles can be helper jobs)
 #define STB_WS_FORM 4096  // lean flow: the discounts at the start of d_ws_fill, the form's workspace from here
+
+// the count slab's geometry (lists.hip): what k_count_cells needs to find a pair's word
+struct slab_info {
+  int R, G, NQ, UC, HC;  // rows of a block / of a group, groups per item base, own columns of a strip, halo columns
+  int PB;                // a position is row in group << PB | element of the wave
+  unsigned UCp;          // words of a row of an item: column 1 (strip 0 only) + the strip's own columns
+  const unsigned *rec_off;
+};
 
 // ------------------------------------------------------------------------------------------------
 // device-resident group set
@@ -114,6 +123,7 @@ void stb_lists_drop(stb_groups_t *g, bool keep_capacity);   // new pairs or new 
 int stb_groups_set_bounds(stb_groups_t *g, unsigned N, unsigned M);
 int stb_groups_sort_pairs(stb_groups_t *g);                  // groups.hip
 int stb_groups_alloc_dotp(stb_groups_t *g);
+int stb_lists_jobs_device(stb_groups_t *g, int which, int D, const grid_geom &gg, const unsigned *tnw);
 
 
 #endif

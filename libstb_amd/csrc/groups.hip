@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_dot_reduce(const double *dotp, int part
 // (mode 1: one double per tile; mode 2: per strip an exact exponent sum and a mantissa-log sum) and the restaurant
 // terms' partial sums, each in a fixed order, their total written to pinned host memory together with the fill's
 // error words -- so that the host waits ONCE and copies nothing.
-__global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts, int mode, const dd_t *tpart, int nbt, unsigned long long inf,
+__global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts, const unsigned *parts_extra, int mode, const dd_t *tpart, int nbt, unsigned long long inf,
                                                    const unsigned long long *inf_dev, const unsigned *hdr, double *out_dev, double *out_host, int Dmax,
                                                    double *out_user) {
   __shared__ dd_t red[4];
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts
   const int d = blockIdx.x;
   dd_t acc{0.0, 0.0};
   double k = 0.0;  // (integers below 2^53: exact in any order)
+  if (parts_extra) parts += (int)*parts_extra;  // (the grid form's helper jobs: their number lives with their list, on the device)
   if (mode == 2) {
     for (int i = threadIdx.x; i < parts; i += 256) {
       k += dotp[((size_t)d * parts + i) * 2];
@@ -513,6 +514,98 @@ void stb_lists_dense_kernels(stb_groups_t *g, int which, unsigned n_tiles, unsig
   }
 }
 
+// The same choice made ON the device (round 5: a set whose pairs are new gets its lists without a host round trip): one
+// workgroup; the tiles' words per group in, the job list in the layout of grid_hb.hip out (queue starts, number of jobs,
+// jobs in tile order = strip after strip, a strip's by block) together with every tile's place in it.
+__global__ __launch_bounds__(1024) void k_jobs_build(const unsigned *tnw, unsigned n_tiles, const unsigned *tile_off, int JW, int jlim, int R, int UC, int NB,
+                                                     unsigned cap, unsigned nwh0, unsigned *jobs, unsigned *tjob) {
+  __shared__ unsigned hist[64], s_nwh, s_scan[1024], s_total;
+  const unsigned tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (unsigned t = tid; t < n_tiles; t += 1024) atomicAdd(&hist[min(tnw[t], 63u)], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned nwh = nwh0;
+    for (; nwh <= 63; nwh++) {
+      unsigned c = 0;
+      for (unsigned k = nwh; k <= 63; k++) c += hist[k];
+      if (c <= cap) break;
+    }
+    s_nwh = nwh;
+  }
+  __syncthreads();
+  const unsigned nwh = s_nwh;
+  // strip of a tile: tile_off[j + 1] is the first tile of strip j (entry 0 holds the total)
+  auto strip_of = [&](unsigned t) -> int {
+    int lo = 0, hi = JW - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) / 2;
+      if (tile_off[mid + 1] <= t) lo = mid;
+      else hi = mid - 1;
+    }
+    return lo;
+  };
+  const int jend = JW < jlim ? JW : jlim;  // strips that may have jobs
+  const unsigned per = (n_tiles + 1023u) / 1024u, t0 = tid * per, t1 = min(t0 + per, n_tiles);
+  unsigned mine = 0;
+  if (nwh <= 63)
+    for (unsigned t = t0; t < t1; t++) mine += (tnw[t] >= nwh && strip_of(t) < jend) ? 1u : 0u;
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (unsigned o = 1; o < 1024; o <<= 1) {  // inclusive scan over the threads' counts
+    const unsigned v = (tid >= o) ? s_scan[tid - o] : 0u;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  unsigned k = s_scan[tid] - mine;
+  if (tid == 1023) s_total = s_scan[1023];
+  __syncthreads();
+  const unsigned total = s_total;
+  for (unsigned t = t0; t < t1; t++) {
+    const int j = strip_of(t);
+    if (t == tile_off[j + 1] && j <= GH_JQ_HOST) jobs[j] = (j < jend) ? k : total;  // the first tile of strip j: its queue starts here
+    if (nwh <= 63 && tnw[t] >= nwh && j < jend) {
+      const int b = (int)(((long long)j * UC) / R) + (int)(t - tile_off[j + 1]);
+      jobs[128 + k] = (unsigned)j | ((unsigned)b << 16);
+      tjob[t] = k;
+      k++;
+    } else {
+      tjob[t] = 0xffffffffu;
+    }
+  }
+  // queue starts of the strips there are not (or that may have no jobs), and the number of jobs
+  for (int j = (int)tid; j <= GH_JQ_HOST; j += 1024)
+    if (j >= jend) jobs[j] = total;
+  if (tid == 0) jobs[GH_JQ_HOST + 1] = total;
+}
+
+// queued on the set's stream behind the kernels that produced `tnw`; no host synchronisation
+int stb_lists_jobs_device(stb_groups_t *g, int which, int D, const grid_geom &gg, const unsigned *tnw) {
+  const unsigned n_tiles = gg.n_tiles;
+  g->n_jobs[which] = 0;
+  const unsigned cap = stb_grid_job_cap(gg.C, g->Dmax, n_tiles, gg.phases);
+  if (!cap || !n_tiles) {
+    if (g->d_jobs[which]) HIPCHK(hipMemsetAsync(g->d_jobs[which], 0, 4 * 128, g->st));
+    return 0;
+  }
+  unsigned nwh = (unsigned)stb_env_int("STB_GRID_HELP_NW", 0);
+  if (nwh < 1) {
+    const double waves_per_simd = (double)gg.JW * D / (4.0 * stb_cu_count());
+    nwh = waves_per_simd <= 1.9 ? 4 : (waves_per_simd <= 2.7 ? 6 : 8);
+  }
+  int jlim = ((gg.JW - 1) / gg.P) * gg.P;
+  if (jlim > 64) jlim = 64;
+  if (!g->d_jobs[which] && stb_pool_malloc((void **)&g->d_jobs[which], 4 * ((size_t)n_tiles + 128 + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  if (!g->d_tjob[which] && stb_pool_malloc((void **)&g->d_tjob[which], 4 * (size_t)(n_tiles + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  hipLaunchKernelGGL(k_jobs_build, dim3(1), dim3(1024), 0, g->st, tnw, n_tiles, g->d_tile_off[which], gg.JW, jlim, gg.R, gg.U * gg.C, gg.NB, cap, nwh,
+                     g->d_jobs[which], g->d_tjob[which]);
+  HIPCHK(hipGetLastError());
+  g->n_jobs[which] = cap;  // (at most; the number itself stays on the device)
+  return 0;
+}
+
 // The tiles whose listed cells the strip's own wave does not look up: every strip of a table moves at the pace of
 // the strips to its left, and those hold most of the pairs (t uniform below n: columns like log) -- several
 // passes a group where the average strip has one.  Such a tile is only walked by its strip, which leaves the
@@ -524,7 +617,12 @@ int stb_lists_jobs_from(stb_groups_t *g, int which, int D, const grid_geom &gg, 
   const unsigned n_tiles = gg.n_tiles;
   g->n_jobs[which] = 0;
   const unsigned cap = stb_grid_job_cap(gg.C, g->Dmax, n_tiles, gg.phases);
-  if (!cap || !n_tiles) return 0;
+  if (!cap || !n_tiles) {
+    // (no jobs: a list left by an earlier build must say so -- the kernels read the number of jobs from it)
+    if (g->d_jobs[which] && (hipMemsetAsync(g->d_jobs[which], 0, 4 * 128, g->st) != hipSuccess || hipStreamSynchronize(g->st) != hipSuccess))
+      return stb_fail("stb_groups_aterms: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+  }
   unsigned hist[65] = {0};  // (an upper bound: the tiles of all strips)
   for (unsigned t = 0; t < n_tiles; t++) hist[h_nw[t] > 63 ? 63 : h_nw[t]]++;
   // NWH at the least: what a job takes off the critical path it adds to the chip's work (the tile is walked twice),
@@ -568,9 +666,16 @@ int stb_lists_jobs_from(stb_groups_t *g, int which, int D, const grid_geom &gg, 
     }
   }
   const size_t nj = jobs.size();
-  jobs.insert(jobs.end(), qoff.begin(), qoff.end());  // (behind the jobs: the first job of every strip)
+  {
+    // the list as the kernels read it (grid_hb.hip: GH_JQ + 1 queue starts, the number of jobs at word 65, jobs from word 128)
+    std::vector<unsigned> lay(128, 0u);
+    for (int j = 0; j <= 64; j++) lay[(size_t)j] = qoff[(size_t)j];
+    lay[65] = (unsigned)nj;
+    lay.insert(lay.end(), jobs.begin(), jobs.end());
+    jobs.swap(lay);
+  }
   // (buffers for the most there can be, kept from set to set; the copies are synchronous: the vectors above go away)
-  if (!g->d_jobs[which] && stb_pool_malloc((void **)&g->d_jobs[which], 4 * ((size_t)n_tiles + 66 + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
+  if (!g->d_jobs[which] && stb_pool_malloc((void **)&g->d_jobs[which], 4 * ((size_t)n_tiles + 128 + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
   if (!g->d_tjob[which] && stb_pool_malloc((void **)&g->d_tjob[which], 4 * (size_t)(n_tiles + 1)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
   if (hipMemcpyAsync(g->d_tjob[which], tjob.data(), 4 * (size_t)n_tiles, hipMemcpyHostToDevice, g->st) != hipSuccess ||
       hipMemcpyAsync(g->d_jobs[which], jobs.data(), 4 * jobs.size(), hipMemcpyHostToDevice, g->st) != hipSuccess || hipStreamSynchronize(g->st) != hipSuccess)
@@ -899,7 +1004,6 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
     req.tinfo = g->d_tinfo[which];
     req.jobs = g->d_jobs[which];
     req.tjob = g->d_tjob[which];
-    req.n_jobs = g->n_jobs[which];
   }
   req.dotp = g->d_dotp;
   req.dotp_cap = g->dotp_elems;
@@ -918,10 +1022,10 @@ static int aterms_issue_lean(stb_groups_t *g, const double *x_host, int D, doubl
   unsigned *hdr = nullptr;
   g->ws_zero = 0;  // (whatever happens below, the workspace is no longer known to be zero)
   if (which >= 3 ? stb_launch_grid(A, D, ws, ws_left, &req, &hdr, g->st) : stb_launch_hb(A, D, ws, ws_left, &req, &hdr, g->st)) return 1;
-  if ((size_t)D * req.parts_per_table * (which >= 3 ? 2 : 1) > g->dotp_elems) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
+  // (the partial sums' room was checked inside the launch functions, before anything was queued: dot_request::dotp_cap)
   if (timed) HIPCHK(hipEventRecord(g->ev[1], g->st));
   if (timed) HIPCHK(hipEventRecord(g->ev[2], g->st));
-  hipLaunchKernelGGL(k_eval_tail, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, which >= 3 ? 2 : 1, tpart, nbt,
+  hipLaunchKernelGGL(k_eval_tail, dim3(D), dim3(256), 0, g->st, g->d_dotp, req.parts_per_table, req.parts_extra_dev, which >= 3 ? 2 : 1, tpart, nbt,
                      (unsigned long long)g->n_inf, g->ent_cap[which] ? g->d_ninf : nullptr, hdr, g->d_out, g->h_out_dev, g->Dmax, g->pend_user);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g->ev[3], g->st));

@@ -35,13 +35,6 @@ void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off);  // 
 // ------------------------------------------------------------------------------------------------
 // count slab -> CSR lists
 
-struct slab_info {
-  int R, G, NQ, UC, HC;  // rows of a block / of a group, groups per item base, own columns of a strip, halo columns
-  int PB;                // a position is row in group << PB | element of the wave
-  unsigned UCp;          // words of a row of an item: column 1 (strip 0 only) + the strip's own columns
-  const unsigned *rec_off;
-};
-
 // the word of the slab a pair falls on: 0 nothing (n <= 1 or t = n: log 1), 1 its S_S is log 0 (lib/stable.c:948-949), 2 a cell
 __device__ __forceinline__ int slab_word(unsigned nn, unsigned tt, unsigned N, unsigned M, const slab_info &H, unsigned &item, size_t &idx) {
   if (nn <= 1 || nn == tt) return 0;
@@ -98,7 +91,10 @@ __global__ __launch_bounds__(256) void k_item_count(const unsigned *slab, unsign
   if (lane == 0) icnt[item] = c;
 }
 
-// a wave per item: its words, in order, become its list; what was read goes back to zero
+// a wave per item: its words, in order, become its list; what was read goes back to zero.  A lane takes four
+// consecutive words a step (one 16-byte load where the item starts on a 16-byte boundary: its length is a multiple of 8
+// words), the next step's load in flight while this one's words are placed; the order of the entries is the order of the
+// words.
 __global__ __launch_bounds__(256) void k_emit_cells(unsigned *slab, const unsigned *item_ptr, unsigned nitems, slab_info H, unsigned short *ent_pos,
                                                     unsigned *ent_cnt) {
   const unsigned item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -108,7 +104,43 @@ __global__ __launch_bounds__(256) void k_emit_cells(unsigned *slab, const unsign
   if (out == end) return;  // (nothing of this item occurs: its words are zero, nobody reads them)
   const unsigned len = (unsigned)H.G * H.UCp;
   unsigned *w = slab + (size_t)item * len;
-  // two pieces of 64 words in flight
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if ((((size_t)item * len) & 3u) == 0 && (len & 3u) == 0) {
+    auto load4 = [&](unsigned i) -> uint4 { return (i + 3 < len) ? *reinterpret_cast<const uint4 *>(w + i) : uint4{0u, 0u, 0u, 0u}; };
+    uint4 nx = load4(lane * 4);
+    for (unsigned k = 0; k < len && out < end; k += 256) {
+      const unsigned i = k + lane * 4;
+      const uint4 c = nx;
+      if (k + 256 < len) nx = load4(i + 256);
+      const unsigned cc[4] = {c.x, c.y, c.z, c.w};
+      // entries before this lane's first word: the non-zero words of the lanes below it
+      const unsigned mine = (cc[0] != 0u) + (cc[1] != 0u) + (cc[2] != 0u) + (cc[3] != 0u);
+      unsigned before = 0, total = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned long long m = __ballot(cc[j] != 0u);
+        before += (unsigned)__popcll(m & below);
+        total += (unsigned)__popcll(m);
+      }
+      if (mine) {
+        unsigned o = out + before;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (cc[j] != 0u) {
+            const unsigned ii = i + j, r = ii / H.UCp, col = ii - r * H.UCp;
+            ent_pos[o] = (unsigned short)((r << H.PB) | ((unsigned)H.HC - 1u + col));
+            ent_cnt[o] = cc[j];
+            o++;
+            any = true;
+          }
+        if (any) *reinterpret_cast<uint4 *>(w + i) = uint4{0u, 0u, 0u, 0u};
+      }
+      out += total;
+    }
+    return;
+  }
+  // (an item that does not start on a 16-byte boundary: word by word, two pieces of 64 words in flight)
   unsigned c0 = (lane < len) ? w[lane] : 0u;
   for (unsigned k = 0; k < len && out < end; k += 64) {
     const unsigned i = k + lane;
@@ -116,7 +148,7 @@ __global__ __launch_bounds__(256) void k_emit_cells(unsigned *slab, const unsign
     if (k + 64 < len) c0 = (i + 64 < len) ? w[i + 64] : 0u;
     const unsigned long long m = __ballot(c != 0u);
     if (c != 0u) {
-      const unsigned o = out + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      const unsigned o = out + (unsigned)__popcll(m & below);
       const unsigned r = i / H.UCp, col = i - r * H.UCp;
       ent_pos[o] = (unsigned short)((r << H.PB) | ((unsigned)H.HC - 1u + col));
       ent_cnt[o] = c;
@@ -255,6 +287,9 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
     g->ent_cap[which] = (size_t)G;
   }
   g->slab_clean = 0;
+  // (counting the pieces of a hand-over while the next ones still arrive -- on the guess that layout and bounds stay --
+  // was built and measured: in the copies' stream the DMA engine waits for every count, the hand-over ends 55 us LATER; on a
+  // stream of its own it ends 20 us later still (tools/ab_spec.py in the history of this file): removed)
   HIPCHK(hipMemsetAsync(g->d_ninf, 0, 8, st));
   hipLaunchKernelGGL(k_count_cells, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, g->d_n, g->d_t, G, N, M, S, g->d_slab, g->d_ninf);
   hipLaunchKernelGGL(k_item_count, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, nitems, (unsigned)H.G * S.UCp, g->d_icnt);
@@ -282,20 +317,11 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
       if (stb_pool_malloc((void **)&g->d_dense[which], 256 * words_cap) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
       g->dense_cap[which] = words_cap;
     }
-    if (g->h_nw_cap < (size_t)n_tiles + 2) {
-      stb_pool_free(g->h_nw);
-      g->h_nw = nullptr;
-      if (stb_pool_malloc((void **)&g->h_nw, 4 * ((size_t)n_tiles + 2), 1) != hipSuccess) return stb_fail("stb_groups_aterms: out of pinned memory");
-      g->h_nw_cap = (size_t)n_tiles + 2;
-    }
     stb_lists_dense_kernels(g, which, n_tiles, NQ, nitems, g->d_tnw[which], g->d_twords[which], g->d_toff[which], 0);
-    // (the words per tile come back for the job list while the dense words are written)
-    HIPCHK(hipMemcpyAsync(g->h_nw, g->d_tnw[which], 4 * (size_t)n_tiles, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(g->ev_dep, st));
     stb_lists_dense_kernels(g, which, n_tiles, NQ, nitems, g->d_tnw[which], g->d_twords[which], g->d_toff[which], 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventSynchronize(g->ev_dep));
-    if (stb_lists_jobs_from(g, which, D, gg, g->h_nw)) return 1;
+    // the tiles left to helper jobs: chosen on the device too (no host round trip anywhere in a set's lists)
+    if (stb_lists_jobs_device(g, which, D, gg, g->d_tnw[which])) return 1;
   }
   if (!g->d_dotp && stb_groups_alloc_dotp(g)) return 1;
   g->sparse = 1;

@@ -138,7 +138,7 @@ struct dot_request {  // set by stb_groups_aterms around its fill: the chain for
   const unsigned *tinfo = nullptr;         //         col0 = 4: per tile, first word / 64 << 6 | words per group (63: the CSR lists)
   const unsigned *jobs = nullptr;          //         col0 = 4: tiles left to helper waves, strip | block << 16, in the order they become ready
   const unsigned *tjob = nullptr;          //         col0 = 4: per tile its place in `jobs`, or 0xffffffff
-  unsigned n_jobs = 0;
+  const unsigned *parts_extra_dev = nullptr;  // out: device word with further partial sums per table (the grid form's helper jobs), or null
   double *dotp = nullptr;                  // partial sums [D][parts_per_table]
   int parts_per_table = 0;                 // out
   size_t dotp_cap = 0;                     // in: doubles `dotp` holds; a launch whose partial sums would not fit is refused BEFORE anything is queued
