@@ -264,3 +264,62 @@ def test_a_fused_evaluation_that_gives_up_is_counted_and_redone(monkeypatch):
         assert L.stb_groups_fallbacks() == fb + 2
     finally:
         L.stb_groups_free(h)
+
+
+def test_a_cell_with_a_huge_count_and_an_empty_set(monkeypatch):
+    """600 000 pairs on ONE cell (its count does not fit a dense word: the tile goes through the CSR lists) beside ordinary
+    pairs, in the grid form and in the halo-block form, lists from the count slab: equal to stored tables + gather; then a
+    set without any pair (every K = 0): the restaurant terms alone, as the reference's aterms gives"""
+    L = capi.lib()
+    I, K = 700, 1000
+    g = synth.groups(I, K, 1200, "wide", seed=21)
+    n, t = g.n.copy(), g.t.copy()
+    n[:600000], t[:600000] = 1000, 37
+    x = np.ascontiguousarray(synth.discount_grid(64)[::9])
+    D = len(x)
+    for env in ({"STB_ATERMS_GRID": "1", "STB_GRID_C": "4"}, {"STB_ATERMS_GRID": "1", "STB_GRID_C": "2"}, {"STB_ATERMS_GRID": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = create(L, g, n, t, 1200, 1200, D)
+        try:
+            got = aterms(L, h, x)
+            want = np.zeros(D)
+            capi.check(L.stb_groups_aterms_tables(h, capi.dp(x), D, capi.dp(want)))
+            assert np.all(np.isfinite(got)) and orc.close(got, want, 1e-12), (env, got, want)
+            capi.check(L.stb_groups_update_pairs(h, orc.u32p(n), orc.u16p(t)))
+            assert np.array_equal(aterms(L, h, x), got)
+        finally:
+            L.stb_groups_free(h)
+        for k in env:
+            monkeypatch.delenv(k)
+    # no pairs at all
+    K0 = np.zeros(5, dtype=np.int32)
+    T0 = np.array([3, 1, 4, 1, 5], dtype=np.uint32)
+    b0 = np.full(5, 10.0)
+    h = L.stb_groups_create(5, orc.i32p(K0), orc.u32p(T0), None, None, orc.dp(b0), 10, 10, 2)
+    assert h, capi.last_error()
+    try:
+        capi.check(L.stb_groups_pairs_begin(h))
+        capi.check(L.stb_groups_pairs_commit(h, orc.u32p(T0), orc.dp(b0), 10, 10))
+        xs = np.array([0.3, 0.6])
+        got = aterms(L, h, xs)
+        import math
+        for d, xv in enumerate(xs):
+            want = sum(float(Ti) * math.log(xv) + math.lgamma(float(Ti) + 10.0 / xv) - math.lgamma(10.0 / xv) for Ti in T0)
+            assert abs(got[d] - want) <= 1e-10 * max(1.0, abs(want)), (got[d], want)
+    finally:
+        L.stb_groups_free(h)
+    # ... and samplea on it (lib/samplea.c:184-208: maxn = maxt = 1, a 10 x 10 table nobody reads)
+    NP = C.POINTER(C.c_uint32) * 5
+    TP = C.POINTER(C.c_uint16) * 5
+    orc.seed_libc(777, 12345)
+    a = L.samplea(0.5, 5, orc.i32p(K0), orc.u32p(T0), NP(), TP(), None, orc.dp(b0), None, 1, 0)
+    assert 0.3 <= a <= 0.7 and L.stb_sampler_trace_count() >= 3     # (ARMS may accept by the squeeze test: no fourth evaluation)
+    if orc.have_ref():
+        R = orc.ref()
+        orc.seed_libc(777, 12345)
+        empty_n, empty_t = np.zeros(1, dtype=np.uint32), np.zeros(1, dtype=np.uint16)
+        want = R.ref_samplea_flat(0.5, 5, orc.i32p(K0), orc.u32p(T0), orc.u32p(empty_n), orc.u16p(empty_t), orc.dp(b0), 1, 0)
+        assert R.ref_trace_count() == L.stb_sampler_trace_count()
+        assert abs(a - want) <= 1e-12
+    L.stb_sampler_cache_clear()
