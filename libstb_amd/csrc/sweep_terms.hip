@@ -231,6 +231,26 @@ __global__ __launch_bounds__(256) void k_terms_partial(terms_args A, const uint3
   if (threadIdx.x == 0) partial[(size_t)d * nb + blockIdx.x] = r;
 }
 
+// bterms over at most STB_TERMS_CHUNK restaurants (sampleb's usual case: a restaurant per document group): ONE launch --
+// the partial sum of k_terms_partial's only block and the final step of k_reduce_final_host, same operations in the same
+// order, so the same bits as the two-launch form; the value goes straight to pinned host memory
+__global__ __launch_bounds__(256) void k_bterms_one(terms_args A, base_args B, const uint32_t *T, uint64_t I, double *out, double *out_host) {
+  __shared__ dd_t lds[4];
+  const int d = blockIdx.x;
+  const double lg = A.p[d], xa = A.q[d];
+  dd_t acc{0.0, 0.0};
+  for (uint64_t i = threadIdx.x; i < I; i += 256) dd_add(acc, lgamma((double)T[i] + xa) - lg);  // lib/sampleb.c:38-39
+  const dd_t r = block_reduce_dd(acc, lds);
+  if (threadIdx.x == 0) {
+    dd_t v{0.0, 0.0};
+    dd_merge(v, r);
+    dd_add(v, B.base[d]);
+    const double res = v.hi + v.lo;
+    out[d] = res;
+    out_host[d] = res;
+  }
+}
+
 static int terms_blocks(uint64_t I) { return (int)((I + STB_TERMS_CHUNK - 1) / STB_TERMS_CHUNK); }
 
 extern "C" size_t stb_terms_workspace_bytes(uint64_t I, int D) {
@@ -404,9 +424,13 @@ extern "C" int stb_bterms_eval(stb_bctx_t *c, const double *x_host, int J, doubl
   int nb = terms_blocks(c->I);
   if (nb < 1) nb = 1;
   dd_t *partial = (dd_t *)((char *)c->d_ws + stb_align_up((size_t)STB_TERMS_DMAX * sizeof(double), 256));
-  hipLaunchKernelGGL(k_terms_partial, dim3(nb, J), dim3(256), 0, c->st, A, c->d_T, (const double *)nullptr, c->I, partial, nb,
-                     (double *)nullptr);
-  hipLaunchKernelGGL(k_reduce_final_host, dim3(J), dim3(256), 0, c->st, partial, nb, c->d_out, B, c->h_out_dev);
+  if (nb == 1 && stb_env_int("STB_BTERMS_ONE", 1)) {
+    hipLaunchKernelGGL(k_bterms_one, dim3(J), dim3(256), 0, c->st, A, B, c->d_T, c->I, c->d_out, c->h_out_dev);
+  } else {
+    hipLaunchKernelGGL(k_terms_partial, dim3(nb, J), dim3(256), 0, c->st, A, c->d_T, (const double *)nullptr, c->I, partial, nb,
+                       (double *)nullptr);
+    hipLaunchKernelGGL(k_reduce_final_host, dim3(J), dim3(256), 0, c->st, partial, nb, c->d_out, B, c->h_out_dev);
+  }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)
     rc = stb_fail("stb_bterms_eval: %s", hipGetErrorString(hipGetLastError()));
   else

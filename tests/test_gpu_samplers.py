@@ -375,3 +375,23 @@ def test_samplea2_vs_reference(golden_dir, run):
     L.stb_hist_free(h)
     assert orc.close(out, [fh(p["y"]) for p in rec["aterms2"]], 1e-10)
     tab.free()
+
+
+def test_bterms_in_one_launch_has_the_bits_of_two(monkeypatch):
+    """sampleb's posterior over at most 2048 restaurants is ONE launch (k_bterms_one) since round 5: the same operations in
+    the same order as the partial-sum + final-reduce pair, so the same bits (STB_BTERMS_ONE=0 is the pair)"""
+    L = capi.lib()
+    g = synth.groups(1000, 10, 4000, "realistic")
+    x = np.ascontiguousarray(np.linspace(0.5, 900.0, 23))
+    outs = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("STB_BTERMS_ONE", one)
+        c = L.stb_bterms_create(orc.u32p(g.T), g.I)
+        assert c, capi.last_error()
+        try:
+            o = np.zeros(len(x))
+            capi.check(L.stb_bterms_eval(c, capi.dp(x), len(x), 0.05, 1.1, 0.37, capi.dp(o)))
+            outs.append(o)
+        finally:
+            L.stb_bterms_free(c)
+    assert np.all(np.isfinite(outs[0])) and np.array_equal(outs[0], outs[1])
