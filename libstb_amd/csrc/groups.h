@@ -107,15 +107,43 @@ struct stb_groups {
   size_t scan_tmp_bytes;
   size_t ent_cap[STB_NLISTS];  // entries the list buffers of a layout hold (0: sized exactly by the sort-based builder)
   size_t dense_cap[STB_NLISTS];
-  unsigned *d_tnw[STB_NLISTS], *d_twords[STB_NLISTS], *d_toff[STB_NLISTS];  // [3], [4]: scratch of the dense layout, kept
-  unsigned *h_nw;              // pinned [n_tiles + 2]: words per tile, read back for the helper jobs
-  size_t h_nw_cap;
+  unsigned *d_tnw[STB_NLISTS], *d_toff[STB_NLISTS];  // [3] .. [5]: words per group and first word of every tile (the dense layout), kept
 };
 
 // the list layout of the grid form with C columns per lane, and back; a position is row << stb_pos_bits(C) | element of the wave
 static inline int stb_grid_which(int C) { return C == 2 ? 3 : (C == 4 ? 4 : 5); }
 static inline int stb_which_C(int which) { return which == 3 ? 2 : (which == 4 ? 4 : 8); }
 static inline int stb_pos_bits(int C) { return C == 8 ? 9 : 8; }
+
+#if defined(__HIPCC__)
+// exclusive prefix sum of one value per thread over a workgroup of 1024 threads (16 waves): shuffles inside a wave, the
+// waves' totals through LDS (`lds`: 17 words); *total receives the sum over the workgroup.  Two barriers.
+__device__ __forceinline__ unsigned stb_block_exclusive_1024(unsigned mine, unsigned *lds, unsigned *total) {
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned v = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned u = __shfl_up(v, o, 64);
+    if ((int)lane >= o) v += u;
+  }
+  if (lane == 63) lds[wave] = v;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned run = 0;
+    for (int w = 0; w < 16; w++) {
+      const unsigned t = lds[w];
+      lds[w] = run;
+      run += t;
+    }
+    lds[16] = run;
+  }
+  __syncthreads();
+  const unsigned ex = lds[wave] + v - mine;
+  if (total) *total = lds[16];
+  __syncthreads();
+  return ex;
+}
+#endif
 
 // lists.hip
 int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H, const grid_geom &gg);  // 0 built (queued), 1 error, 2 not applicable

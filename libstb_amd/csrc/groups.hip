@@ -79,7 +79,7 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
                               g->d_cnt, g->d_n2, g->d_t2, g->d_dotp, g->d_slab, g->d_icnt, g->d_ninf, g->d_scan_tmp};
   for (int w = 0; w < STB_NLISTS; w++)
     for (void *q : {(void *)g->d_item_ptr[w], (void *)g->d_ent_pos[w], (void *)g->d_ent_cnt[w], (void *)g->d_tile_off[w], (void *)g->d_dense[w],
-                    (void *)g->d_tinfo[w], (void *)g->d_jobs[w], (void *)g->d_tjob[w], (void *)g->d_tnw[w], (void *)g->d_twords[w], (void *)g->d_toff[w]})
+                    (void *)g->d_tinfo[w], (void *)g->d_jobs[w], (void *)g->d_tjob[w], (void *)g->d_tnw[w], (void *)g->d_toff[w]})
       ptrs.push_back(q);
   if (g->st) (void)hipStreamSynchronize(g->st);  // nothing may still be using the buffers
   for (void *p : ptrs) stb_pool_free(p);
@@ -88,7 +88,6 @@ extern "C" void stb_groups_free(stb_groups_t *g) {
   stb_pool_free(g->h_pt);
   stb_pool_free(g->h_T);
   stb_pool_free(g->h_bpar);
-  stb_pool_free(g->h_nw);
   if (g->ev_dep) (void)hipEventDestroy(g->ev_dep);
   if (g->ev_done) (void)hipEventDestroy(g->ev_done);
   for (auto &e : g->ev)
@@ -498,39 +497,30 @@ int stb_groups_alloc_dotp(stb_groups_t *g) {
   return 0;
 }
 
-// the dense layout of the grid form from the CSR lists, on the set's stream: stage 0 the words per tile and their
-// prefix sum, stage 1 the words themselves (lists.hip asks for the words per tile in between)
-void stb_lists_dense_kernels(stb_groups_t *g, int which, unsigned n_tiles, unsigned NQ, unsigned nitems, unsigned *tnw, unsigned *twords, unsigned *toff,
-                             int stage) {
-  if (!n_tiles) return;
-  if (stage == 0) {
-    const int wbits = stb_pos_bits(stb_which_C(which)) + 5;
-    hipLaunchKernelGGL(k_tile_words, dim3((n_tiles + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_cnt[which], n_tiles, NQ, wbits, tnw, twords);
-    size_t tb = g->scan_tmp_bytes;
-    (void)rocprim::exclusive_scan(g->d_scan_tmp, tb, twords, toff, 0u, (size_t)n_tiles, rocprim::plus<unsigned>(), g->st);
-  } else if (nitems) {
-    hipLaunchKernelGGL(k_dense_fill, dim3((nitems + 3) / 4), dim3(256), 0, g->st, g->d_item_ptr[which], g->d_ent_pos[which], g->d_ent_cnt[which], nitems, NQ,
-                       stb_pos_bits(stb_which_C(which)) + 5, tnw, toff, g->d_dense[which], g->d_tinfo[which]);
-  }
-}
-
 // The same choice made ON the device (round 5: a set whose pairs are new gets its lists without a host round trip): one
 // workgroup; the tiles' words per group in, the job list in the layout of grid_hb.hip out (queue starts, number of jobs,
 // jobs in tile order = strip after strip, a strip's by block) together with every tile's place in it.
 __global__ __launch_bounds__(1024) void k_jobs_build(const unsigned *tnw, unsigned n_tiles, const unsigned *tile_off, int JW, int jlim, int R, int UC, int NB,
                                                      unsigned cap, unsigned nwh0, unsigned *jobs, unsigned *tjob) {
-  __shared__ unsigned hist[64], s_nwh, s_scan[1024], s_total;
+  __shared__ unsigned hist[64], s_nwh, s_scan[17], s_off[1024];
   const unsigned tid = threadIdx.x;
   if (tid < 64) hist[tid] = 0;
+  // (the strips' first tiles, looked at a dozen times per tile below: in LDS where they fit)
+  const bool off_lds = JW + 2 <= 1024;
+  if (off_lds)
+    for (int i = (int)tid; i < JW + 2; i += 1024) s_off[i] = tile_off[i];
   __syncthreads();
+  const unsigned *toffp = off_lds ? s_off : tile_off;
   for (unsigned t = tid; t < n_tiles; t += 1024) atomicAdd(&hist[min(tnw[t], 63u)], 1u);
   __syncthreads();
   if (tid == 0) {
-    unsigned nwh = nwh0;
-    for (; nwh <= 63; nwh++) {
-      unsigned c = 0;
-      for (unsigned k = nwh; k <= 63; k++) c += hist[k];
-      if (c <= cap) break;
+    // the smallest threshold from nwh0 on whose tiles fit (the tiles at or above a threshold grow as it falls): one pass
+    // from the top; 64 = none fits
+    unsigned nwh = 64, c = 0;
+    for (int k = 63; k >= (int)nwh0; k--) {
+      c += hist[k];
+      if (c > cap) break;
+      nwh = (unsigned)k;
     }
     s_nwh = nwh;
   }
@@ -541,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_jobs_build(const unsigned *tnw, unsign
     int lo = 0, hi = JW - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) / 2;
-      if (tile_off[mid + 1] <= t) lo = mid;
+      if (toffp[mid + 1] <= t) lo = mid;
       else hi = mid - 1;
     }
     return lo;
@@ -551,23 +541,13 @@ __global__ __launch_bounds__(1024) void k_jobs_build(const unsigned *tnw, unsign
   unsigned mine = 0;
   if (nwh <= 63)
     for (unsigned t = t0; t < t1; t++) mine += (tnw[t] >= nwh && strip_of(t) < jend) ? 1u : 0u;
-  s_scan[tid] = mine;
-  __syncthreads();
-  for (unsigned o = 1; o < 1024; o <<= 1) {  // inclusive scan over the threads' counts
-    const unsigned v = (tid >= o) ? s_scan[tid - o] : 0u;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
-  unsigned k = s_scan[tid] - mine;
-  if (tid == 1023) s_total = s_scan[1023];
-  __syncthreads();
-  const unsigned total = s_total;
+  unsigned total = 0;
+  unsigned k = stb_block_exclusive_1024(mine, s_scan, &total);
   for (unsigned t = t0; t < t1; t++) {
     const int j = strip_of(t);
-    if (t == tile_off[j + 1] && j <= GH_JQ_HOST) jobs[j] = (j < jend) ? k : total;  // the first tile of strip j: its queue starts here
+    if (t == toffp[j + 1] && j <= GH_JQ_HOST) jobs[j] = (j < jend) ? k : total;  // the first tile of strip j: its queue starts here
     if (nwh <= 63 && tnw[t] >= nwh && j < jend) {
-      const int b = (int)(((long long)j * UC) / R) + (int)(t - tile_off[j + 1]);
+      const int b = (int)(((long long)j * UC) / R) + (int)(t - toffp[j + 1]);
       jobs[128 + k] = (unsigned)j | ((unsigned)b << 16);
       tjob[t] = k;
       k++;
@@ -712,7 +692,7 @@ static int groups_fused_setup_sparse(stb_groups_t *g, int which, int D) {
       (void)hipStreamSynchronize(g->st);
       void **olds[] = {(void **)&g->d_item_ptr[which], (void **)&g->d_ent_pos[which], (void **)&g->d_ent_cnt[which], (void **)&g->d_tile_off[which],
                        (void **)&g->d_dense[which],    (void **)&g->d_tinfo[which],   (void **)&g->d_jobs[which],    (void **)&g->d_tjob[which],
-                       (void **)&g->d_tnw[which],      (void **)&g->d_twords[which],  (void **)&g->d_toff[which]};
+                       (void **)&g->d_tnw[which],      (void **)&g->d_toff[which]};
       for (void **q : olds) {
         stb_pool_free(*q);
         *q = nullptr;

@@ -158,9 +158,118 @@ __global__ __launch_bounds__(256) void k_emit_cells(unsigned *slab, const unsign
   }
 }
 
-// (in groups.hip: the dense layout of the grid form, from the CSR lists)
-void stb_lists_dense_kernels(stb_groups_t *g, int which, unsigned n_tiles, unsigned NQ, unsigned nitems, unsigned *tnw, unsigned *twords, unsigned *toff,
-                             int stage);
+// ---- the grid form: CSR lists AND the dense words the walk reads, in one pass over the slab ----
+#define STB_DENSE_NWMAX 40  // (as in groups.hip)
+
+// One workgroup: the exclusive scan of the items' distinct cells (the CSR row pointer) and, per tile, the words per lane
+// its groups get in the dense layout (the most any of them needs; 63: more than the layout takes, the tile is read from
+// the CSR lists), their prefix sum and the tile's entry -- what two library scans, k_tile_words and a launch gap did.
+__global__ __launch_bounds__(1024) void k_scan_lists(const unsigned *icnt, unsigned nitems, unsigned n_tiles, unsigned NQ, unsigned *item_ptr, unsigned *tnw,
+                                                     unsigned *toff, unsigned *tinfo) {
+  __shared__ unsigned s_scan[17];
+  const unsigned tid = threadIdx.x;
+  auto block_exclusive = [&](unsigned mine) -> unsigned { return stb_block_exclusive_1024(mine, s_scan, nullptr); };
+  {
+    const unsigned per = (nitems + 1 + 1023u) / 1024u, i0 = tid * per, i1 = min(i0 + per, nitems + 1);
+    unsigned sum = 0;
+    for (unsigned i = i0; i < i1; i++) sum += (i < nitems) ? icnt[i] : 0u;
+    unsigned run = block_exclusive(sum);
+    for (unsigned i = i0; i < i1; i++) {
+      item_ptr[i] = run;
+      run += (i < nitems) ? icnt[i] : 0u;
+    }
+  }
+  {
+    const unsigned per = (n_tiles + 1023u) / 1024u, t0 = tid * per, t1 = min(t0 + per, n_tiles);
+    unsigned sum = 0;
+    for (unsigned t = t0; t < t1; t++) {
+      unsigned nw = 0;
+      for (unsigned q = 0; q < NQ; q++) nw = max(nw, (icnt[(size_t)t * NQ + q] + 63u) / 64u);
+      if (nw > STB_DENSE_NWMAX) nw = 63u;
+      tnw[t] = nw;
+      sum += (nw == 63u) ? 0u : nw * NQ;
+    }
+    unsigned run = block_exclusive(sum);
+    for (unsigned t = t0; t < t1; t++) {
+      const unsigned nw = tnw[t];
+      toff[t] = run;
+      tinfo[t] = (run << 6) | nw;
+      run += (nw == 63u) ? 0u : nw * NQ;
+    }
+  }
+}
+
+// a wave per item, as k_emit_cells; every entry also goes to its place among the tile's dense words (position | count <<
+// wbits, group q of the tile at words [first + q NW, first + (q + 1) NW) x 64 lanes, filled from the front, zeros behind).
+// A count that does not fit a word marks its tile as one read from the CSR lists (NW := 63).
+__global__ __launch_bounds__(256) void k_emit_both(unsigned *slab, const unsigned *item_ptr, unsigned nitems, slab_info H, unsigned short *ent_pos, unsigned *ent_cnt,
+                                                   unsigned NQ, int wbits, unsigned *tnw, const unsigned *toff, unsigned *tinfo, unsigned *dense) {
+  const unsigned item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (item >= nitems) return;
+  const unsigned tile = item / NQ, q = item - tile * NQ;
+  const unsigned first = item_ptr[item], end = item_ptr[item + 1];
+  const unsigned nw = tinfo[tile] & 63u;  // (as k_scan_lists left it: another wave's "63" for a big count comes later or never)
+  unsigned *dw = (nw != 0u && nw != 63u) ? dense + ((size_t)toff[tile] + (size_t)q * nw) * 64 : nullptr;
+  const unsigned room = nw * 64u;
+  if (first != end) {
+    unsigned out = first;
+    const unsigned len = (unsigned)H.G * H.UCp;
+    unsigned *w = slab + (size_t)item * len;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const bool wide = (((size_t)item * len) & 3u) == 0 && (len & 3u) == 0;
+    auto place = [&](unsigned o, unsigned ii, unsigned c) {
+      const unsigned r = ii / H.UCp, col = ii - r * H.UCp;
+      const unsigned pos = (r << H.PB) | ((unsigned)H.HC - 1u + col);
+      ent_pos[o] = (unsigned short)pos;
+      ent_cnt[o] = c;
+      if (dw) dw[o - first] = pos | (c << wbits);
+      if (c >= (1u << (32 - wbits))) {  // (does not fit a dense word: this tile is read from the CSR lists)
+        atomicOr(&tinfo[tile], 63u);
+        atomicMax(&tnw[tile], 63u);
+      }
+    };
+    if (wide) {
+      auto load4 = [&](unsigned i) -> uint4 { return (i + 3 < len) ? *reinterpret_cast<const uint4 *>(w + i) : uint4{0u, 0u, 0u, 0u}; };
+      uint4 nx = load4(lane * 4);
+      for (unsigned k = 0; k < len && out < end; k += 256) {
+        const unsigned i = k + lane * 4;
+        const uint4 c = nx;
+        if (k + 256 < len) nx = load4(i + 256);
+        const unsigned cc[4] = {c.x, c.y, c.z, c.w};
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned long long m = __ballot(cc[j] != 0u);
+          before += (unsigned)__popcll(m & below);
+          total += (unsigned)__popcll(m);
+        }
+        if ((cc[0] | cc[1] | cc[2] | cc[3]) != 0u) {
+          unsigned o = out + before;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (cc[j] != 0u) place(o++, i + j, cc[j]);
+          *reinterpret_cast<uint4 *>(w + i) = uint4{0u, 0u, 0u, 0u};
+        }
+        out += total;
+      }
+    } else {
+      for (unsigned k = 0; k < len && out < end; k += 64) {
+        const unsigned i = k + lane;
+        const unsigned c = (i < len) ? w[i] : 0u;
+        const unsigned long long m = __ballot(c != 0u);
+        if (c != 0u) {
+          place(out + (unsigned)__popcll(m & below), i, c);
+          w[i] = 0u;
+        }
+        out += (unsigned)__popcll(m);
+      }
+    }
+  }
+  // the words behind the group's last cell: zero (the first empty word ends a group's look-ups)
+  if (dw)
+    for (unsigned k = (end - first) + lane; k < room; k += 64) dw[k] = 0u;
+}
+
 int stb_lists_jobs_from(stb_groups_t *g, int which, int D, const grid_geom &gg, const unsigned *h_nw);
 
 static void free_z(void *&p) {
@@ -185,7 +294,6 @@ void stb_lists_drop(stb_groups_t *g, bool keep_capacity) {
     FREE_Z(g->d_jobs[w]);
     FREE_Z(g->d_tjob[w]);
     FREE_Z(g->d_tnw[w]);
-    FREE_Z(g->d_twords[w]);
     FREE_Z(g->d_toff[w]);
     g->ent_cap[w] = 0;
     g->dense_cap[w] = 0;
@@ -293,21 +401,23 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
   HIPCHK(hipMemsetAsync(g->d_ninf, 0, 8, st));
   hipLaunchKernelGGL(k_count_cells, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, g->d_n, g->d_t, G, N, M, S, g->d_slab, g->d_ninf);
   hipLaunchKernelGGL(k_item_count, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, nitems, (unsigned)H.G * S.UCp, g->d_icnt);
-  size_t tb = g->scan_tmp_bytes;
-  if (rocprim::exclusive_scan(g->d_scan_tmp, tb, g->d_icnt, g->d_item_ptr[which], 0u, (size_t)nitems + 1, rocprim::plus<unsigned>(), st) != hipSuccess)
-    return stb_fail("stb_groups_aterms: exclusive_scan failed");
-  hipLaunchKernelGGL(k_emit_cells, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, g->d_item_ptr[which], nitems, S, g->d_ent_pos[which],
-                     g->d_ent_cnt[which]);
-  HIPCHK(hipGetLastError());
-  g->slab_clean = 1;  // (once the stream has come this far; every later use is queued behind it)
-  g->n_inf = 0;       // (counted on the device: d_ninf)
-  if (which >= 3) {
-    // the dense layout the walk reads: words per tile, their prefix sum, the words; then the tiles left to helper jobs
+  g->n_inf = 0;  // (counted on the device: d_ninf)
+  if (which < 3) {
+    size_t tb = g->scan_tmp_bytes;
+    if (rocprim::exclusive_scan(g->d_scan_tmp, tb, g->d_icnt, g->d_item_ptr[which], 0u, (size_t)nitems + 1, rocprim::plus<unsigned>(), st) != hipSuccess)
+      return stb_fail("stb_groups_aterms: exclusive_scan failed");
+    hipLaunchKernelGGL(k_emit_cells, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, g->d_item_ptr[which], nitems, S, g->d_ent_pos[which],
+                       g->d_ent_cnt[which]);
+    HIPCHK(hipGetLastError());
+    g->slab_clean = 1;  // (once the stream has come this far; every later use is queued behind it)
+  } else {
+    // the grid form: CSR lists and the dense words the walk reads in ONE pass over the slab, the scans by one workgroup,
+    // then the tiles left to helper jobs -- all on the device, the evaluation queued right behind
     const unsigned n_tiles = H.n_tiles, NQ = (unsigned)H.NQ;
     const size_t words_cap = (size_t)NQ * ((size_t)(G / 64) + n_tiles + 1);  // in units of 64 words: sum over tiles of NQ * ceil(most cells of a group / 64)
     if (words_cap >= (1u << 26)) return stb_fail("stb_groups_aterms: a dense list beyond 2^32 bytes");
     {
-      unsigned **bufs[] = {&g->d_tnw[which], &g->d_twords[which], &g->d_toff[which], &g->d_tinfo[which]};
+      unsigned **bufs[] = {&g->d_tnw[which], &g->d_toff[which], &g->d_tinfo[which]};
       for (unsigned **q : bufs)
         if (!*q && stb_pool_malloc((void **)q, 4 * (size_t)(n_tiles + 2)) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
     }
@@ -317,10 +427,12 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
       if (stb_pool_malloc((void **)&g->d_dense[which], 256 * words_cap) != hipSuccess) return stb_fail("stb_groups_aterms: out of device memory");
       g->dense_cap[which] = words_cap;
     }
-    stb_lists_dense_kernels(g, which, n_tiles, NQ, nitems, g->d_tnw[which], g->d_twords[which], g->d_toff[which], 0);
-    stb_lists_dense_kernels(g, which, n_tiles, NQ, nitems, g->d_tnw[which], g->d_twords[which], g->d_toff[which], 1);
+    hipLaunchKernelGGL(k_scan_lists, dim3(1), dim3(1024), 0, st, g->d_icnt, nitems, n_tiles, NQ, g->d_item_ptr[which], g->d_tnw[which], g->d_toff[which],
+                       g->d_tinfo[which]);
+    hipLaunchKernelGGL(k_emit_both, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, g->d_item_ptr[which], nitems, S, g->d_ent_pos[which],
+                       g->d_ent_cnt[which], NQ, S.PB + 5, g->d_tnw[which], g->d_toff[which], g->d_tinfo[which], g->d_dense[which]);
     HIPCHK(hipGetLastError());
-    // the tiles left to helper jobs: chosen on the device too (no host round trip anywhere in a set's lists)
+    g->slab_clean = 1;
     if (stb_lists_jobs_device(g, which, D, gg, g->d_tnw[which])) return 1;
   }
   if (!g->d_dotp && stb_groups_alloc_dotp(g)) return 1;
