@@ -580,6 +580,7 @@ struct put_job {
   std::atomic<int> next;  // the next slice nobody has taken
 };
 struct put_pool {
+  std::mutex use;  // one hand-over at a time has the workers; another thread's meanwhile is copied by that thread itself
   std::mutex mu;
   std::condition_variable cv;
   std::vector<std::thread> th;
@@ -703,13 +704,25 @@ static int put_all(stb_groups_t *g, int I, const int *K, uint32_t *const *n, uin
   J.nslices = ns;
   J.next.store(0);
   put_pool *P = nullptr;
+  std::unique_lock<std::mutex> use_lk;
   if (W > 0 && J.nslices > 1) {
     std::call_once(g_put_once, [W] {
-      g_put_pool = new put_pool;
-      for (int w = 0; w < W; w++) g_put_pool->th.emplace_back(put_worker, g_put_pool);
-      for (auto &th : g_put_pool->th) th.detach();
+      put_pool *np = new put_pool;
+      try {
+        for (int w = 0; w < W; w++) np->th.emplace_back(put_worker, np);
+      } catch (...) {  // (no more threads to be had: those that started serve; none: the callers copy themselves)
+      }
+      for (auto &th : np->th) th.detach();
+      g_put_pool = np;
     });
-    P = g_put_pool;
+    P = (g_put_pool && !g_put_pool->th.empty()) ? g_put_pool : nullptr;
+    if (P) {
+      // (samplers of different host threads share the workers: whoever finds them busy copies on its own thread)
+      use_lk = std::unique_lock<std::mutex>(P->use, std::try_to_lock);
+      if (!use_lk.owns_lock()) P = nullptr;
+    }
+  }
+  if (P) {
     {
       std::lock_guard<std::mutex> lk(P->mu);
       P->job = &J;

@@ -134,3 +134,52 @@ def test_device_resident_result_equals_the_blocking_call():
             assert np.array_equal(doubled.cpu().numpy(), 2.0 * want), D
     finally:
         L.stb_groups_free(h)
+
+
+def test_host_threads_hand_new_pairs_over_at_the_same_time():
+    """three host threads, each with a set of 10^6 pairs of its own, replace their pairs (stb_groups_update_pairs) and
+    evaluate, over and over and at the same time: the staging copy's worker threads are the library's and serve one
+    hand-over at a time -- a thread that finds them busy copies on its own -- and every value is what a set created from
+    those pairs gives"""
+    L = capi.lib()
+    N = M = 2000
+    x = np.array([0.27, 0.55, 0.8])
+    packs = []
+    for k in range(3):
+        g = synth.groups(1000, 1000, N, "wide", seed=synth.SEED + 10 + k)
+        variants = []
+        for v in range(3):
+            n, t = g.n.copy(), g.t.copy()
+            n[1000 * v:1000 * v + 50] = np.minimum(n[1000 * v:1000 * v + 50] + 1, N - 1)
+            h0 = L.stb_groups_create(g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(n), orc.u16p(t), orc.dp(g.bpar), N, M, 3)
+            assert h0, capi.last_error()
+            want = np.zeros(3)
+            capi.check(L.stb_groups_aterms(h0, capi.dp(x), 3, capi.dp(want)))
+            L.stb_groups_free(h0)
+            variants.append((n, t, want))
+        packs.append((g, variants, make_set(L, g, N, M, 3)))
+    errors = []
+
+    def work(k):
+        g, variants, h = packs[k]
+        out = np.zeros(3)
+        try:
+            for it in range(40):
+                n, t, want = variants[(it + k) % 3]
+                capi.check(L.stb_groups_update_pairs(h, orc.u32p(n), orc.u16p(t)))
+                capi.check(L.stb_groups_aterms(h, capi.dp(x), 3, capi.dp(out)))
+                if not np.array_equal(out, want):
+                    errors.append((k, it, out.copy(), want))
+                    return
+        except Exception as e:  # noqa: BLE001 -- reported below
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=120)
+    assert not any(t_.is_alive() for t_ in th), "a hand-over never finished"
+    for _, _, h in packs:
+        L.stb_groups_free(h)
+    assert not errors, errors[:2]
