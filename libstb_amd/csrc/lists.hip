@@ -9,16 +9,23 @@
 // ragged arrays twice (flat, then to the device through the runtime's own staging): 3.1-3.8 ms a call where an
 // unchanged set took 1.57.  Here:
 //
-//   * stb_groups_pairs_begin / _put / _commit: the caller's arrays are copied ONCE, into pinned memory, a restaurant at
-//     a time (the maxima of n and t -- the table bounds of lib/samplea.c:186-208 -- fall out of the same pass), and
-//     every 256 K pairs go to the device while the host copies the next ones.
+//   * stb_groups_pairs_begin / _put / _put_ragged / _commit: the caller's arrays are copied ONCE, into pinned memory (the
+//     maxima of n and t -- the table bounds of lib/samplea.c:186-208 -- fall out of the same pass); a whole set at once is
+//     copied by a few host threads of the library's own while the calling thread hands the finished pieces to the DMA
+//     engine (one core of the GPU box's host moves the 6 MB of 10^6 pairs in 0.41 ms, four in 0.18).
 //   * the lists come from a COUNT SLAB: one word per cell of every (tile, group of rows) item in the order the walk
-//     looks cells up, i.e. the table's cells once over (33 MB for N = M = 4000, 205 MB for 10^4).  k_count_cells adds
-//     every pair to its word (an integer atomic: the result does not depend on the order) and counts the item's
-//     distinct cells when a word leaves zero; an exclusive scan of those counts is the CSR row pointer; k_emit_cells
-//     has a wave per item compact the item's words -- in position order, the order the sort produced, so the lists are
-//     THE SAME BYTES as the sort-based builder's -- and puts every word it read back to zero: the slab is clean for
-//     the next set without a memset.  Four launches, no host synchronisation; an evaluation is queued right behind.
+//     looks cells up, i.e. the table's cells once over (33 MB for N = M = 4096, 205 MB for 10^4), zero between builds.
+//     k_count_cells adds every pair to its word -- ONE device-scope atomic per pair: this part hands out 24 G of them a
+//     second whatever they return and however large the slab (tools/ubench/scatter.hip: 42 us for 10^6), an integer, so
+//     the result does not depend on the order of the pairs; k_item_count reads the slab for every item's distinct cells;
+//     a prefix sum of those is the CSR row pointer; k_emit_cells has a wave per item compact the item's words -- in position
+//     order, the order the sort produced, so the lists are THE SAME BYTES as the sort-based builder's -- and puts every
+//     word it read back to zero: the slab is clean for the next set without a memset.  For the grid form the prefix sums and
+//     the tiles' entries are one single-workgroup kernel (k_scan_lists), the compaction writes the dense words the walk
+//     reads along with the CSR entries (k_emit_both), and the tiles left to helper jobs are chosen by k_jobs_build
+//     (groups.hip), which leaves their number in the list for the kernels to read.  No host synchronisation anywhere: the
+//     evaluation is queued right behind (N = 4096, halo-block form: 75 us; N = 10^4, grid form: 166 us; the radix sort +
+//     run-length encoding they replace: 330-600 us and four host round trips).
 //   * pairs are no longer sorted by (n,t) when a set is made: the fused evaluation does not read them, and the gather
 //     over a stored table of 4000 x 4000 (64 MB: it lives in the Infinity Cache) is as fast on unsorted pairs
 //     (0.035 ms either way, profiles/r05_fresh_before.txt).  The sort is made on first need by the evaluations through
