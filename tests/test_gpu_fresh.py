@@ -323,3 +323,58 @@ def test_a_cell_with_a_huge_count_and_an_empty_set(monkeypatch):
         assert R.ref_trace_count() == L.stb_sampler_trace_count()
         assert abs(a - want) <= 1e-12
     L.stb_sampler_cache_clear()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_lists_from_the_slab_equal_the_sorted_lists(monkeypatch, seed):
+    """random table bounds (N from 520, M anywhere up to N), random ragged restaurants, pairs anywhere -- on the diagonal,
+    beyond the bounds, t = 0, n = 1 among them --, a random number of discounts, whatever form is picked: the lists from the
+    count slab give the bits of the sorted lists; a hand-over of the same pairs in another order too; stored tables agree"""
+    L = capi.lib()
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(520, 3200))
+    M = int(rng.integers(10, N + 1))
+    I = int(rng.integers(1, 40))
+    K = rng.integers(0, 400, I).astype(np.int32)
+    G = int(K.sum())
+    if G == 0:
+        K[0] = 5
+        G = 5
+    n = rng.integers(1, N + 3, G).astype(np.uint32)
+    t = np.minimum(rng.integers(0, M + 3, G), 65535).astype(np.uint16)
+    ok = rng.random(G) < 0.9                       # most pairs inside the support: 1 <= t <= n <= N, t <= M
+    n[ok] = np.clip(n[ok], 2, N)
+    t[ok] = np.minimum(np.maximum(t[ok], 1), np.minimum(n[ok], M)).astype(np.uint16)
+    finite = bool(np.all((n <= 1) | ((t >= 1) & (t <= n) & (t <= M) & (n <= N))))
+    T = np.array([int(t[K[:i].sum():K[:i + 1].sum()].sum()) for i in range(I)], dtype=np.uint32)
+    bpar = rng.uniform(0.5, 50.0, I)
+    D = int(rng.integers(1, 9))
+    x = np.sort(rng.uniform(0.02, 0.97, D))
+    if seed % 3 == 1:
+        monkeypatch.setenv("STB_ATERMS_GRID", "1")
+
+    def make(nn, tt):
+        h = L.stb_groups_create(I, orc.i32p(K), orc.u32p(T), orc.u32p(nn), orc.u16p(tt), orc.dp(bpar), N, M, D)
+        assert h, capi.last_error()
+        return h
+
+    outs = {}
+    for slab in ("1", "0"):
+        monkeypatch.setenv("STB_LISTS_SLAB", slab)
+        h = make(n, t)
+        try:
+            outs[slab] = aterms(L, h, x)
+            if slab == "1":
+                want = np.zeros(D)
+                capi.check(L.stb_groups_aterms_tables(h, capi.dp(np.ascontiguousarray(x)), D, capi.dp(want)))
+                p = rng.permutation(G)
+                capi.check(L.stb_groups_update_pairs(h, orc.u32p(n[p].copy()), orc.u16p(t[p].copy())))
+                again = aterms(L, h, x)
+        finally:
+            L.stb_groups_free(h)
+    assert np.array_equal(outs["1"], outs["0"], equal_nan=True), (N, M, G, D, outs)
+    assert np.array_equal(again, outs["1"], equal_nan=True)
+    if finite:
+        assert np.all(np.isfinite(outs["1"])) and orc.close(outs["1"], want, 1e-12), (outs["1"], want)
+    else:
+        assert np.all(np.isneginf(outs["1"])) and np.all(np.isneginf(want))
