@@ -422,15 +422,18 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
         unsigned idle = 0;
         while (__hip_atomic_load(X.jflag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(8);
-          // (a timeout of 0 means "give up at once" in EVERY wait of this kernel and of k_fill_hb -- the fetcher's, the
-          // spine's, the tile workers' and this one: what STB_CHAIN_TIMEOUT_MS=0 is for, the tests of the fallback)
-          if ((++idle & 31) != 0 && X.timeout != 0) continue;
+          // (A timeout of 0 means "give up at once" in every wait of this kernel and of k_fill_hb -- what
+          // STB_CHAIN_TIMEOUT_MS=0 is for, the tests of the fallback.  This wait never sees it: a launch with a timeout of 0
+          // has no helper jobs, stb_launch_grid.  Written with the test in the loop head like the others, this loop took the
+          // kernel from 124 to 145 registers and the 64-discount evaluation from 1.29 to 1.42 ms: found by building the
+          // round's commits side by side, tools/ab_grid.py with STB_LIB_PATH.)
+          if ((++idle & 31) != 0) continue;
           if (!timing) {
             timing = true;
             t_begin = wall_clock64();
           }
           const unsigned err = __hip_atomic_load(X.hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (err != 0 || (unsigned long long)wall_clock64() - t_begin >= X.timeout) {
+          if (err != 0 || (X.timeout != 0 && (unsigned long long)wall_clock64() - t_begin >= X.timeout)) {
             if (err == 0 && lane == 0) {
               __hip_atomic_store(X.hdr + 2, (unsigned)(jj | (dd << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_store(X.hdr + 1, 0xA00u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -896,7 +899,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
   X.jobs = dot->jobs;
   X.tjob = dot->tjob;
   X.job_cap = g.job_cap;
-  if (!g.job_cap) X.jobs = nullptr;
+  if (!g.job_cap || X.timeout == 0) X.jobs = nullptr;  // (a timeout of 0: every wait gives up at once -- and the wait for a job's record is not entered)
   X.jticket = X.hdr + 64 + 16 * GH_MAXPH;  // (GH_JQ lines)
   X.jflag = (unsigned *)(ws + g.off_jflag);
   X.jrec_e = (int *)(ws + g.off_jrec_e);
