@@ -1250,10 +1250,18 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
     HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
   }
-  if (!dot || dot->ws_zero < g.zero_bytes) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+  {
+    const bool need_zero = !dot || dot->ws_zero < g.zero_bytes;
+    const bool need_s1 = !(dot && dot->no_s1) && !(out_kind & 2);  // (the V table has no column 1)
+    if (need_zero && need_s1 && !(g.zero_bytes & 15) && !((uintptr_t)ws & 15) && stb_env_int("STB_HB_PREP", 1)) {
+      if (stb_launch_prep(A, D, ws, g.zero_bytes, st)) return 1;
+    } else {
+      if (need_zero) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
+      if (need_s1 && stb_launch_s1(A, D, st)) return 1;
+    }
+  }
   if (dot) const_cast<dot_request *>(dot)->zero_bytes = g.zero_bytes;
   *hdr_out = X.hdr;
-  if (!(dot && dot->no_s1) && !(out_kind & 2) && stb_launch_s1(A, D, st)) return 1;  // (the V table has no column 1)
   // every workgroup is generic: the first B*D tickets walk the spine, the others work on tiles
   const int cus = stb_cu_count();
   // A storing fill takes the whole chip: idle workers cost nothing any more (they wait on progress words that have

@@ -198,6 +198,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
+int stb_launch_prep(const fill_args &A, int D, void *ws, size_t zero_bytes, hipStream_t st);  // k_s1 + a zeroed workspace, one launch
 #define STB_ROWS_LOGDOM 1
 #define STB_ROWS_VRATIO 2
 int stb_launch_rows(fill_args &A, int D, int C, int what, hipStream_t st);
