@@ -417,10 +417,14 @@ def main():
     gathered = torch.empty(Dg, dtype=torch.float64, device=dev)
     fb0 = L.stb_fill_fallbacks()
 
+    # (one rank: the probes ARE the gathered values -- index_select writes them there, nothing is exchanged or copied)
+    probes = gathered.view(Dg, 1) if world == 1 else torch.empty((Dl, 1), dtype=torch.float64, device=dev)
+
     def step():
         T.fill(mine, args.variant)
-        probes = T.tables.index_select(1, probe_idx).reshape(-1)  # log S^N_{M/2} per discount
-        gathered.copy_(shard.gather_scalars(probes, Dg, dist))
+        torch.index_select(T.tables, 1, probe_idx, out=probes)  # log S^N_{M/2} per discount
+        if world > 1:
+            shard.gather_scalars(probes.view(-1), Dg, dist, out=gathered)
 
     for _ in range(args.warmup):
         step()

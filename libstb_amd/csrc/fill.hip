@@ -309,6 +309,31 @@ static bool hb_takes_kind(unsigned N, unsigned M, int D, int kind) {
 
 extern "C" int stb_fill_takes_kind(unsigned N, unsigned M, int D, int kind) { return hb_takes_kind(N, M, D, kind) ? 1 : 0; }
 
+static thread_local stb_a64 g_a_vals;
+static thread_local int g_a_D = 0;  // > 0: that many discounts of this thread's fill are not on the device yet
+__global__ void k_set_a(stb_a64 av, double *a, int D) {
+  if ((int)threadIdx.x < D) a[threadIdx.x] = av.v[threadIdx.x];
+}
+void stb_a_defer(const double *a_host, int D) {
+  for (int d = 0; d < D; d++) g_a_vals.v[d] = a_host[d];
+  g_a_D = D;
+}
+bool stb_a_take(stb_a64 *out, int *D_out) {
+  if (g_a_D <= 0) return false;
+  *out = g_a_vals;
+  *D_out = g_a_D;
+  g_a_D = 0;
+  return true;
+}
+int stb_a_flush(const fill_args &A, hipStream_t st) {
+  stb_a64 av;
+  int D = 0;
+  if (!stb_a_take(&av, &D)) return 0;
+  hipLaunchKernelGGL(k_set_a, dim3(1), dim3(64), 0, st, av, const_cast<double *>(A.a), D);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static thread_local bool g_fillv_exact = false;  // stb_fill_V_exact: this call walks the reference's own V recurrence
 
 // kind: 0 log S (double), 1 log S (float), 2 V (double), 3 V (float); d_tables is the slab of that type
@@ -319,6 +344,10 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   const char *who = vtable ? "stb_fill_V" : "stb_fill_S";
   g_last.hdr = nullptr;  // whatever this thread filled before is no longer "the last fill"
   g_last.fell_back = false;
+  struct a_guard {  // (discounts still on their way when this call ends -- an error before the launch -- go nowhere)
+    a_guard() { g_a_D = 0; }
+    ~a_guard() { g_a_D = 0; }
+  } a_guard_;
   if (D < 1) return stb_fail("%s: D=%d", who, D);
   if (N < 2 || M < 2) return stb_fail("%s: bounds N=%u M=%u too small", who, N, M);
   if (!a_host || !d_tables || !d_ws || (!vtable && !d_S1)) return stb_fail("%s: null pointer", who);
@@ -347,7 +376,11 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   A.N = N;
   A.M = M;
   if (stb_logtab(&A.lt)) return 1;
-  HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+  if (D <= 64 && stb_env_int("STB_A_BY_VALUE", 1)) {
+    stb_a_defer(a_host, D);  // (the launcher's first kernel writes them, or stb_a_flush below)
+  } else {
+    HIPCHK(hipMemcpyAsync((void *)A.a, a_host, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+  }
 
   if (kind != 0 && !(kind == 2 && (g_fillv_exact || stb_env_int("STB_FILLV_EXACT", 0) || !hb_takes_kind(N, M, D, kind)))) {
     // floats, and the V table from the S recurrence's own cells (one division per cell, off the serial path: 1e-10 of
@@ -366,6 +399,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     return 0;
   }
   if (vtable) {
+    if (stb_a_flush(A, st)) return 1;
     if (stb_env_int("STB_FILLV_CHAIN", 1)) {
       unsigned *hdr = nullptr;
       if (stb_launch_vchain(A, D, ws, ws_left, &hdr, st)) return 1;
@@ -385,6 +419,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   }
 
   const int form = pick_form(variant, N, M, D);
+  if (form != FORM_HB && stb_a_flush(A, st)) return 1;  // (stb_launch_hb hands them to its k_prep)
   if (g_dot_req && form != FORM_CHAIN && form != FORM_CK && form != FORM_HB)
     return stb_fail("%s: the fused evaluation needs the chain or the checkpointed form", who);
   switch (form) {

@@ -1256,6 +1256,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     if (need_zero && need_s1 && !(g.zero_bytes & 15) && !((uintptr_t)ws & 15) && stb_env_int("STB_HB_PREP", 1)) {
       if (stb_launch_prep(A, D, ws, g.zero_bytes, st)) return 1;
     } else {
+      if (stb_a_flush(A, st)) return 1;
       if (need_zero) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
       if (need_s1 && stb_launch_s1(A, D, st)) return 1;
     }

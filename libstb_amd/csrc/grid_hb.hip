@@ -914,6 +914,7 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
     HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
     HIPCHK(hipMemsetAsync(X.dbg, 0, dbg_words * 8, st));
   }
+  if (stb_a_flush(A, st)) return 1;
   if (!dot || dot->ws_zero < g.zero_bytes) HIPCHK(hipMemsetAsync(ws, 0, g.zero_bytes, st));
   if (dot) const_cast<dot_request *>(dot)->zero_bytes = g.zero_bytes;
   *hdr_out = X.hdr;

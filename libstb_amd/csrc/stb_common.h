@@ -198,7 +198,14 @@ int stb_launch_grid(fill_args &A, int D, char *ws, size_t ws_left, const dot_req
 
 int stb_launch_pc(fill_args &A, int D, hipStream_t st);
 int stb_launch_s1(const fill_args &A, int D, hipStream_t st);
-int stb_launch_prep(const fill_args &A, int D, void *ws, size_t zero_bytes, hipStream_t st);  // k_s1 + a zeroed workspace, one launch
+// The discounts of a fill on their way to A.a (device): a copy of a few bytes from pageable host memory is a 4.4 us copy
+// kernel of its own behind a staging buffer; up to 64 discounts travel as kernel arguments instead -- of k_prep when the
+// launcher has one (stb_a_take), else of a kernel of their own (stb_a_flush; no-ops when nothing is on its way).
+struct stb_a64 { double v[64]; };
+void stb_a_defer(const double *a_host, int D);
+bool stb_a_take(stb_a64 *out, int *D_out);
+int stb_a_flush(const fill_args &A, hipStream_t st);
+int stb_launch_prep(const fill_args &A, int D, void *ws, size_t zero_bytes, hipStream_t st);  // k_s1 + a zeroed workspace (+ the discounts on their way), one launch
 #define STB_ROWS_LOGDOM 1
 #define STB_ROWS_VRATIO 2
 int stb_launch_rows(fill_args &A, int D, int C, int what, hipStream_t st);
