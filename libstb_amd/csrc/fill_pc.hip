@@ -266,16 +266,17 @@ __global__ __launch_bounds__(256) void k_s1(const double *a, double *S1, uint64_
 
 // ... and, in the same launch, a workspace zeroed (the halo-block form's records are their own flags: 0 = not written yet).
 // One launch instead of a memset and k_s1: a launch and the gap before the next are ~10 us of a 0.3 ms step.
-// blocks 0 .. nz-1 zero `bytes` (a multiple of 16) from `ws` (16-byte aligned); the nb * D blocks after them are k_s1's.
+// the first nb * D blocks are k_s1's; the nz blocks after them zero n16 x 16 bytes from `ws` (16-byte aligned).
 // (av, Da: the discounts themselves when they are still on their way to `a` -- written there for the fill that follows)
 __global__ __launch_bounds__(256) void k_prep(double *a, double *S1, uint64_t s1stride, unsigned N, unsigned nz, unsigned nb,
-                                              uint4 *ws, uint64_t n16, stb_a64 av, int Da) {
-  if (blockIdx.x < nz) {
+                                              uint4 *ws, uint64_t n16, stb_a64 av, int Da, unsigned ns) {
+  // (the ns = nb * D blocks of S1 come first: a chain of lgamma evaluations is latency, the zeroing bandwidth -- they overlap)
+  if (blockIdx.x >= ns) {
     const uint4 z = {0u, 0u, 0u, 0u};
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)nz * 256) ws[i] = z;
+    for (uint64_t i = (uint64_t)(blockIdx.x - ns) * 256 + threadIdx.x; i < n16; i += (uint64_t)nz * 256) ws[i] = z;
     return;
   }
-  const unsigned bi = blockIdx.x - nz, d = bi / nb, bx = bi % nb;
+  const unsigned bi = blockIdx.x, d = bi / nb, bx = bi % nb;
   const double ad = Da > 0 ? av.v[d] : a[d];
   if (Da > 0 && bx == 0 && threadIdx.x == 0) a[d] = ad;
   const double lg1 = lgamma(1.0 - ad);
@@ -295,7 +296,7 @@ int stb_launch_prep(const fill_args &A, int D, void *ws, size_t zero_bytes, hipS
   if (!stb_a_take(&av, &Da)) Da = 0;
   if (Da != 0 && Da != D) return stb_fail("stb_fill: %d discounts on their way, %d tables", Da, D);
   hipLaunchKernelGGL(k_prep, dim3(nz + nb * (unsigned)D), dim3(256), 0, st, const_cast<double *>(A.a), A.S1, A.s1stride, A.N, nz, nb, (uint4 *)ws, n16,
-                     av, Da);
+                     av, Da, nb * (unsigned)D);
   return 0;
 }
 
