@@ -83,12 +83,14 @@ struct hb_args {
   unsigned long long *ck_v;    // [D][n_rec][U*C]  records: significands of the own lanes at the start of a block
   unsigned *ck_e;              // [D][n_rec][U]    ... and their lane exponents + HB_EOFF32
   unsigned *progress;          // [D][JW][HB_PROG_STRIDE]  blocks whose record a spine wave has written (scheduling hint)
-  const unsigned *order;       // [n_tiles] j | b << 16, in the order the tiles become ready
+  const unsigned *order;       // [n_order] j | b << 16 (split: j | quarter << 14 | b << 16), in the order the tiles become ready
   const unsigned *rec_off;     // [JW + 2]  first record of strip s (s = j + 1; s = 0: the halo of strip 0), per table
   unsigned n_rec;              // records per table
   int D, B, JW, NB;            // tables, spine workgroups per table, strips per table, blocks
   int P, R, HL, U;             // spine waves per workgroup, rows per block, halo lanes, own lanes
   unsigned n_tiles;            // per table
+  unsigned n_order;            // entries of `order`: the tiles, those of a strip's last `split` blocks four times (a quarter of the rows each)
+  int split;                   // see hb_order_list; 0: no tile is split (and j has 16 bits in `order`)
   unsigned n_spine;            // spine workgroups in all (B * D)
   unsigned long long timeout;  // wall_clock64 ticks a wait may last
   int poll_nap;                // s_sleep argument between two polls of a fetcher
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   }
   const bool order_in_lds = X.order_lds != 0;
   if (order_in_lds)
-    for (unsigned i = tid; i < X.n_tiles; i += blockDim.x) s_order[i] = X.order[i];
+    for (unsigned i = tid; i < X.n_order; i += blockDim.x) s_order[i] = X.order[i];
   for (int i = tid; i < HB_MAXCNT; i += blockDim.x) s_done[i] = 0;
   const bool recoff_in_lds = X.JW + 2 <= HB_RECOFF_LDS;
   if (recoff_in_lds)
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         __builtin_amdgcn_s_setprio(3);
         if (dbg) dbg[0] = HB_STAMP();
 #ifdef HB_TL_FINE
-        unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_tiles * 4 + (size_t)jw * NB * 8 : nullptr;
+        unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_order * 4 + (size_t)jw * NB * 8 : nullptr;
 #define HB_FINE(k) if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP()
 #else
 #define HB_FINE(k)
@@ -561,7 +563,7 @@ for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
       }
       const unsigned grp = cur % Dg, part = cur / Dg;          // tiles part, part + S, part + 2 S, .. of the order list
       const unsigned Tg = ((unsigned)X.D - grp + Dg - 1) / Dg;  // tables grp, grp + Dg, ..
-      const unsigned mine = (X.n_tiles + S - 1 - part) / S * Tg;  // how many tickets this counter hands out
+      const unsigned mine = (X.n_order + S - 1 - part) / S * Tg;  // how many tickets this counter hands out
       unsigned k = 0;
       if (lane == 0) k = atomicAdd(X.hdr + HB_CNT0 + cur * HB_PROG_STRIDE, 1u);
       k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
@@ -575,7 +577,12 @@ for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
       const int d = (int)(grp + Dg * (k % Tg));
       const unsigned oi = (k / Tg) * S + part;
       const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane((int)(order_in_lds ? s_order[oi] : X.order[oi]));
-      const int jw = (int)(ord & 0xffffu), b = (int)(ord >> 16);
+      const int jw = (int)(ord & (X.split ? 0x3fffu : 0xffffu)), b = (int)(ord >> 16);
+      // The tiles of a strip's last blocks come as four tickets, a quarter of the rows each (the rows before it are walked
+      // without logs and stores, an eighth of a tile's cost): what the fill waits for at its very end is the last tiles'
+      // latency -- 8-10 us a whole tile, all other workers idle -- not throughput.
+      const bool quartered = X.split != 0 && b >= NB - X.split;
+      const int r_lo = quartered ? (int)((ord >> 14) & 3u) * (R >> 2) : 0, r_hi = quartered ? r_lo + (R >> 2) : R;
       const unsigned who = (unsigned)jw | ((unsigned)d << 16);
       unsigned long long *wdbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)oi * 4 : nullptr;
       if (wdbg) wdbg[0] = wall_clock64();
@@ -824,7 +831,7 @@ for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
           tc[NG - 1] = fma(ra, z1, rb * s[1]);
         }
       }
-      for (int r = 0; r < R; r += RS) {
+      for (int r = 0; r < r_hi; r += RS) {
         double x[8], val[8], xl[VT ? 8 : 1];
 #pragma unroll
         for (int u = 0; u < RS; u++) {
@@ -871,7 +878,7 @@ for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
         }
         // (rows none of whose cells lies in the strip's own columns, and rows outside the table, are only walked)
         const unsigned nl = n + RS - 1;
-        if (nl >= NMIN && n <= N && e0 < rlen(min(nl, N))) {
+        if (r >= r_lo && nl >= NMIN && n <= N && e0 < rlen(min(nl, N))) {
           if constexpr (VT) {
             // V^n_m = S^n_m / S^n_{m-1}: both under the lane's exponent (cells right of the diagonal: 0 / 0 or x / 0 --
             // they land in the row's slack, which nobody reads)
@@ -1074,7 +1081,8 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
 struct hb_order_entry {
   int dev;
   unsigned N, M;
-  int C, P, R, NB, JW, U;
+  int C, P, R, NB, JW, U, split;
+  unsigned n_order;
   int r_ns, L_ns, lag_ns;
   unsigned *d_buf;  // [JW + 2] rec_off, then [n_tiles] order
   unsigned long long used;  // the look-up that last handed it out
@@ -1083,7 +1091,10 @@ static std::mutex g_hb_mu;
 static std::vector<hb_order_entry> g_hb_orders;
 static unsigned long long g_hb_lookups = 0;
 
-static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigned **rec_off, const unsigned **order) {
+// split: the tiles of every strip's last `split` blocks are listed four times, with a quarter of the rows each (storing
+// fills of blocks of 48 rows, 2 or 4 columns per lane, fewer than 2^14 strips; 0 for everything else)
+static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigned **rec_off, const unsigned **order, int split = 0,
+                         unsigned *n_order_out = nullptr) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   const int r_ns = stb_env_int("STB_HB_ORDER_R", 30), L_ns = stb_env_int("STB_HB_ORDER_L", 3000),
@@ -1092,10 +1103,11 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   g_hb_lookups++;
   for (hb_order_entry &e : g_hb_orders)
     if (e.dev == dev && e.N == N && e.M == M && e.C == g.C && e.P == g.P && e.R == g.R && e.NB == g.NB && e.JW == g.JW && e.U == g.U &&
-        e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
+        e.split == split && e.r_ns == r_ns && e.L_ns == L_ns && e.lag_ns == lag_ns) {
       e.used = g_hb_lookups;
       *rec_off = e.d_buf;
       *order = e.d_buf + g.JW + 2;
+      if (n_order_out) *n_order_out = e.n_order;
       return 0;
     }
   struct item {
@@ -1103,9 +1115,9 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
     unsigned code;
   };
   const int UC = g.U * g.C;
-  std::vector<unsigned> buf((size_t)g.JW + 2 + g.n_tiles);
+  std::vector<unsigned> buf((size_t)g.JW + 2);
   std::vector<item> v;
-  v.reserve(g.n_tiles);
+  v.reserve(g.n_tiles + (size_t)3 * split * g.JW);
   unsigned off = 0;
   buf[0] = off;  // strip index 0: the halo of strip 0, blocks 0 .. NB - 1
   off += (unsigned)g.NB;
@@ -1118,11 +1130,17 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
       it.key = (long)b * g.R * r_ns + (long)(j / g.P) * L_ns + (long)(j % g.P) * lag_ns;
       it.code = (unsigned)j | ((unsigned)b << 16);
       v.push_back(it);
+      if (split && b >= g.NB - split)
+        for (unsigned q = 1; q < 4; q++) {
+          it.code = (unsigned)j | (q << 14) | ((unsigned)b << 16);
+          v.push_back(it);
+        }
     }
   }
   buf[g.JW + 1] = off;
-  if (off != g.n_rec || v.size() != g.n_tiles) return stb_fail("stb_fill_S: record count %u != %u", off, g.n_rec);
+  if (off != g.n_rec || (!split && v.size() != g.n_tiles)) return stb_fail("stb_fill_S: record count %u != %u", off, g.n_rec);
   std::stable_sort(v.begin(), v.end(), [](const item &x, const item &y) { return x.key < y.key; });
+  buf.resize((size_t)g.JW + 2 + v.size());
   for (size_t i = 0; i < v.size(); i++) buf[(size_t)g.JW + 2 + i] = v[i].code;
   hb_order_entry e;
   e.dev = dev;
@@ -1134,6 +1152,8 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   e.NB = g.NB;
   e.JW = g.JW;
   e.U = g.U;  // (the V table's strips have a halo lane more than the S table's: other first blocks for the same N, M)
+  e.split = split;
+  e.n_order = (unsigned)v.size();
   e.r_ns = r_ns;
   e.L_ns = L_ns;
   e.lag_ns = lag_ns;
@@ -1156,6 +1176,7 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
   g_hb_orders.push_back(e);
   *rec_off = e.d_buf;
   *order = e.d_buf + g.JW + 2;
+  if (n_order_out) *n_order_out = e.n_order;
   return 0;
 }
 
@@ -1239,12 +1260,20 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     const_cast<dot_request *>(dot)->parts_per_table = (int)g.n_tiles;
     if (dot->dotp_cap && (size_t)D * g.n_tiles > dot->dotp_cap) return stb_fail("stb_groups_aterms: partial-sum buffer too small");
   }
-  if (hb_order_list(g, N, M, &X.rec_off, &X.order)) return 1;
+  // (quartered last tiles: see the workers; the V table's blocks may be a row group out of step with a quarter -- 48 rows are
+  // 12 groups of 4 or 24 of 2 either way)
+  // Only where the spine decides (strips of 2 columns per lane: a table or two): with 8 tables the workers are busy to the end
+  // and the rows walked twice cost more than the shorter tail saves (MI355X, N = M = 10^4, ms: one table, floats 0.289 against
+  // 0.302, V 0.303 against 0.314, N = 4000 0.134 against 0.137; 8 tables 0.826-0.850 against 0.811; the last 4, 6 or 10 blocks: alike).
+  X.split = (!dot && g.R == 48 && g.C >= 2 && g.JW < (1 << 14)) ? std::min(stb_env_int("STB_HB_SPLIT", g.C == 2 ? 6 : 0), g.NB) : 0;
+  if (X.split < 0) X.split = 0;
+  X.n_order = g.n_tiles;
+  if (hb_order_list(g, N, M, &X.rec_off, &X.order, X.split, &X.n_order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");
 #ifdef HB_TL_FINE
-  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4 + (size_t)g.JW * g.NB * 8;
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)X.n_order * 4 + (size_t)g.JW * g.NB * 8;
 #else
-  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)g.n_tiles * 4;
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)X.n_order * 4;
 #endif
   if (tl_file && *tl_file) {
     HIPCHK(hipMalloc((void **)&X.dbg, dbg_words * 8));
@@ -1281,12 +1310,12 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   if (stb_env_int("STB_HB_GRID", 0) > 0) grid = (unsigned)stb_env_int("STB_HB_GRID", 0);  // (diagnostic: spine alone)
   // the tile order goes to LDS when it fits beside the rest (a storing kernel's ~80 KB; a summing kernel's staging
   // rows leave no room for it)
-  X.order_lds = (!dot && g.n_tiles <= HB_ORDER_LDS) ? 1 : 0;
+  X.order_lds = (!dot && X.n_order <= HB_ORDER_LDS) ? 1 : 0;
   {
     // at least 8 counters when the tables are few; every counter's part of the order list keeps hundreds of tiles
     const int Dg = D < HB_MAXCNT ? D : HB_MAXCNT;
     int Sn = stb_env_int("STB_HB_TICKET_PARTS", Dg >= 8 ? 1 : (8 + Dg - 1) / Dg);
-    while (Sn > 1 && ((unsigned)Sn * 64 > g.n_tiles || Sn * Dg > HB_MAXCNT)) Sn--;
+    while (Sn > 1 && ((unsigned)Sn * 64 > X.n_order || Sn * Dg > HB_MAXCNT)) Sn--;
     if (Sn < 1) Sn = 1;
     X.n_cnt = Sn * Dg;
   }
@@ -1299,7 +1328,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
     }
   } else {
-    const size_t shm = X.order_lds ? (size_t)g.n_tiles * sizeof(unsigned) : 0;
+    const size_t shm = X.order_lds ? (size_t)X.n_order * sizeof(unsigned) : 0;
     if (out_kind && g.C == 1) return stb_fail("stb_fill: the halo-block form narrows or divides with 2 or 4 columns per lane");
     switch (g.C * 4 + out_kind) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<1, 0>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
@@ -1321,11 +1350,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
     (void)hipFree(X.dbg);
     FILE *f = fopen(tl_file, "wb");
     if (f) {
-      const int hd[8] = {g.JW, g.NB, (int)g.n_tiles, g.C, g.P, g.R, g.U, D};
+      const int hd[8] = {g.JW, g.NB, (int)X.n_order, g.C, g.P, g.R, g.U, D | (X.split << 16)};
       fwrite(hd, sizeof(int), 8, f);
-      std::vector<unsigned> ord(g.n_tiles);
-      HIPCHK(hipMemcpy(ord.data(), X.order, (size_t)g.n_tiles * sizeof(unsigned), hipMemcpyDeviceToHost));
-      fwrite(ord.data(), sizeof(unsigned), g.n_tiles, f);
+      std::vector<unsigned> ord(X.n_order);
+      HIPCHK(hipMemcpy(ord.data(), X.order, (size_t)X.n_order * sizeof(unsigned), hipMemcpyDeviceToHost));
+      fwrite(ord.data(), sizeof(unsigned), X.n_order, f);
       fwrite(h.data(), 8, dbg_words, f);
       fclose(f);
     }

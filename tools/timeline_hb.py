@@ -47,6 +47,7 @@ else:
 
 buf = open(raw, "rb").read()
 JW, NB, NT, C, P, R, U, Dd = np.frombuffer(buf, dtype=np.int32, count=8)
+split, Dd = int(Dd) >> 16, int(Dd) & 0xffff   # (the tiles of a strip's last `split` blocks are listed four times, a quarter of the rows each)
 order = np.frombuffer(buf, dtype=np.uint32, count=NT, offset=32)
 words = np.frombuffer(buf, dtype=np.uint64, offset=32 + 4 * NT).astype(np.int64)
 S = words[: JW * (NB + 2)].reshape(JW, NB + 2)
@@ -110,7 +111,7 @@ if len(w):
                  f"compute median {np.median(cp):.1f} us (p10 {np.percentile(cp, 10):.1f} p90 {np.percentile(cp, 90):.1f}); sum of compute {cp.sum() / 1000:.2f} ms")
     lines.append(f"last tile done {(w[:, 2].max() - t0) * tick:.1f} us; last spine end {(S[:, NB + 1].max() - t0) * tick:.1f} us")
     # how long after its record was written was a tile done
-    jj = (order & 0xffff).astype(np.int64)
+    jj = (order & (0x3fff if split else 0xffff)).astype(np.int64)
     bb = (order >> 16).astype(np.int64)
     rec_t = S[jj, 1 + bb]
     okm = (W[:, 2] > 0) & (rec_t > 0)
