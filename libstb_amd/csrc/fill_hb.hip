@@ -668,7 +668,11 @@ for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
           for (;;) {
             const unsigned done = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done >= (unsigned)(b + 1)) break;
-            const int missing = min((int)((unsigned)(b + 1) - done), 32);
+            // (a strip that has not started yet -- done = 0 -- will start at its first block bO, not at block 0: counting
+            // from 0, a worker with one of a right-hand strip's first tiles slept through 32 blocks' time and then, finding
+            // the strip still not started, through 32 more -- the fill's last tiles were noticed 13-20 us after their
+            // records were written, profiles/r05_tail_before.txt)
+            const int missing = min((int)((unsigned)(b + 1) - (done ? done : (unsigned)bO)) + (done ? 0 : 2), 32);
             for (int i = 0; i < missing; i++)
               for (int q = 0; q < X.nap_block; q++) __builtin_amdgcn_s_sleep(8);
             if ((++spins & 3u) != 0 && X.timeout != 0) continue;

@@ -117,6 +117,10 @@ if len(w):
     okm = (W[:, 2] > 0) & (rec_t > 0)
     late = (W[okm, 2] - rec_t[okm]) * tick
     lines.append(f"tile done after its block's record: median {np.median(late):.1f} us, p90 {np.percentile(late, 90):.1f}, max {late.max():.1f}")
+    last = np.argsort(W[:, 2])[-10:][::-1]
+    lines.append("the last tiles done (us: claimed, inputs loaded, done; strip, block, quarter; its record written): " + "; ".join(
+        f"{(W[i, 0] - t0) * tick:.1f} {(W[i, 1] - t0) * tick:.1f} {(W[i, 2] - t0) * tick:.1f} j{int(jj[i])} b{int(bb[i])} q{(int(order[i]) >> 14) & 3 if split else 0} rec {(rec_t[i] - t0) * tick:.1f}"
+        for i in last))
     lines.append(f"distinct (xcc, hw id sans wave) values among workers: {len(set((int(x) >> 4) for x in w[:, 3]))}")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
