@@ -1250,7 +1250,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   // for a block (48 rows x 22 ns with 2 columns per lane, x 32-45 ns with 4), so that it looks again well before
   // the tile is due -- longer and it oversleeps (one table: 0.33 ms with 6 against 0.31 with 3; a table of 4000
   // rows 0.166 against 0.148), much shorter and the looks of thousands of waiting waves get in the spine's way
-  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", dot ? 6 : (g.C == 4 ? 4 : 3));
+  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C == 4 ? (dot ? 6 : 4) : 3);
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   X.spare_work = stb_env_int("STB_HB_SPARE", 0);
   // (measured, MI355X, N = M = 10^4: one table 0.365 ms with it against 0.321 without -- a late start is never made up,

@@ -71,6 +71,7 @@ struct stb_groups {
   double *h_out_dev;           // the device's address of it
   size_t ws_zero;              // bytes from the start of d_ws_fill + STB_WS_FORM known to be zero (lean flow)
   int pend_lean;               // the queued evaluation took the lean flow
+  double seq, pend_seq;        // one-discount lean evaluations: the word k_eval_tail writes last to pinned memory (0: the host waits for the event)
   double *pend_user;           // stb_groups_aterms_device: where the totals go on the device (or null)
   double pend_host[STB_TERMS_DMAX];  // ... and where stb_groups_wait puts them on the host meanwhile
   hipEvent_t ev_done;

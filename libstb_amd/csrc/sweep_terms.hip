@@ -234,7 +234,10 @@ __global__ __launch_bounds__(256) void k_terms_partial(terms_args A, const uint3
 // bterms over at most STB_TERMS_CHUNK restaurants (sampleb's usual case: a restaurant per document group): ONE launch --
 // the partial sum of k_terms_partial's only block and the final step of k_reduce_final_host, same operations in the same
 // order, so the same bits as the two-launch form; the value goes straight to pinned host memory
-__global__ __launch_bounds__(256) void k_bterms_one(terms_args A, base_args B, const uint32_t *T, uint64_t I, double *out, double *out_host) {
+// (flag_host: a word of the same pinned memory that takes `seq` once the value is there -- the host of a one-abscissa
+// evaluation spins on it instead of waiting for the stream: the launch's completion signal reaches it microseconds later)
+__global__ __launch_bounds__(256) void k_bterms_one(terms_args A, base_args B, const uint32_t *T, uint64_t I, double *out, double *out_host,
+                                                    double *flag_host, double seq) {
   __shared__ dd_t lds[4];
   const int d = blockIdx.x;
   const double lg = A.p[d], xa = A.q[d];
@@ -248,6 +251,10 @@ __global__ __launch_bounds__(256) void k_bterms_one(terms_args A, base_args B, c
     const double res = v.hi + v.lo;
     out[d] = res;
     out_host[d] = res;
+    if (flag_host) {
+      __threadfence_system();
+      __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -331,7 +338,8 @@ struct stb_bctx {
   int dev;
   uint64_t I, cap;  // restaurants now, and at most
   uint32_t *d_T;
-  double *d_out, *h_out, *h_out_dev;
+  double *d_out, *h_out, *h_out_dev;  // (h_out: STB_TERMS_DMAX values, then the flag word of k_bterms_one)
+  double seq;
   void *d_ws;
   size_t ws_bytes;
   hipStream_t st;
@@ -369,7 +377,7 @@ extern "C" stb_bctx_t *stb_bterms_create(const uint32_t *T, int I) {
   ok = ok && stb_pool_malloc((void **)&c->d_T, sizeof(uint32_t) * (c->I ? c->I : 1)) == hipSuccess;
   ok = ok && stb_pool_malloc((void **)&c->d_out, sizeof(double) * STB_TERMS_DMAX) == hipSuccess;
   ok = ok && stb_pool_malloc(&c->d_ws, c->ws_bytes) == hipSuccess;
-  ok = ok && stb_pool_malloc((void **)&c->h_out, sizeof(double) * STB_TERMS_DMAX, 1) == hipSuccess;
+  ok = ok && stb_pool_malloc((void **)&c->h_out, sizeof(double) * (STB_TERMS_DMAX + 8), 1) == hipSuccess;
   ok = ok && hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0) == hipSuccess;
   if (ok && c->I) ok = hipMemcpyAsync(c->d_T, T, sizeof(uint32_t) * c->I, hipMemcpyHostToDevice, c->st) == hipSuccess &&
                        hipStreamSynchronize(c->st) == hipSuccess;
@@ -424,14 +432,29 @@ extern "C" int stb_bterms_eval(stb_bctx_t *c, const double *x_host, int J, doubl
   int nb = terms_blocks(c->I);
   if (nb < 1) nb = 1;
   dd_t *partial = (dd_t *)((char *)c->d_ws + stb_align_up((size_t)STB_TERMS_DMAX * sizeof(double), 256));
+  bool spun = false;
   if (nb == 1 && stb_env_int("STB_BTERMS_ONE", 1)) {
-    hipLaunchKernelGGL(k_bterms_one, dim3(J), dim3(256), 0, c->st, A, B, c->d_T, c->I, c->d_out, c->h_out_dev);
+    const bool spin = J == 1 && stb_env_int("STB_SPIN_WAIT", 1);
+    volatile double *flag = c->h_out + STB_TERMS_DMAX;
+    if (spin) {
+      c->seq += 1.0;
+      *flag = 0.0;
+    }
+    hipLaunchKernelGGL(k_bterms_one, dim3(J), dim3(256), 0, c->st, A, B, c->d_T, c->I, c->d_out, c->h_out_dev,
+                       spin ? c->h_out_dev + STB_TERMS_DMAX : (double *)nullptr, c->seq);
+    if (spin && hipGetLastError() == hipSuccess) {
+      // (bounded: ~a millisecond of looks; whatever happens, the stream is waited for below when the word has not come)
+      for (unsigned n = 0; n < 400000u && *flag != c->seq; n++) __builtin_ia32_pause();
+      spun = *flag == c->seq;
+    }
   } else {
     hipLaunchKernelGGL(k_terms_partial, dim3(nb, J), dim3(256), 0, c->st, A, c->d_T, (const double *)nullptr, c->I, partial, nb,
                        (double *)nullptr);
     hipLaunchKernelGGL(k_reduce_final_host, dim3(J), dim3(256), 0, c->st, partial, nb, c->d_out, B, c->h_out_dev);
   }
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)
+  if (spun) {
+    out_host[0] = ((volatile double *)c->h_out)[0];
+  } else if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)
     rc = stb_fail("stb_bterms_eval: %s", hipGetErrorString(hipGetLastError()));
   else
     for (int j = 0; j < J; j++) out_host[j] = c->h_out[j];
