@@ -232,3 +232,61 @@ def test_10000_batch_every_table_vs_oracle(D):
             err = np.abs(got - w) / np.maximum(1.0, np.abs(w))
             assert np.all(np.isfinite(got)) and float(err.max()) <= TOL, (d, n, float(err.max()))
         assert abs(float(T.S1[d, N - 1]) - want[d][1]) <= TOL * abs(want[d][1])
+
+
+@pytest.mark.parametrize("split", [0, 1, 6, 1000])
+@pytest.mark.parametrize("C", [2, 4])
+def test_quartered_last_tiles(monkeypatch, C, split):
+    """the tiles of every strip's last `split` blocks are handed out as four tickets of 12 rows each (STB_HB_SPLIT; the
+    default takes 6 where strips have 2 columns per lane): the same cells whatever the number, for log S in double and
+    in float and for the V table, several strips and workgroups, tables ending in the middle of a block"""
+    monkeypatch.setenv("STB_HB_C", str(C))
+    monkeypatch.setenv("STB_HB_SPLIT", str(split))
+    L = capi.lib()
+    before = L.stb_fill_fallbacks()
+    for N, M in ((1531, 1400), (1000, 333)):
+        a = np.array([0.11, 0.77])
+        T = capi.DeviceTables(N, M, D=2)
+        T.tables.fill_(float("nan"))
+        T.fill(a, capi.FILL_HB)
+        T.status()
+        _check_tables(T, a, N, M)
+        F = capi.DeviceFloatTables(N, M, D=2)
+        F.tables.fill_(float("nan"))
+        F.fill(a)
+        F.status()
+        for d in range(2):
+            assert np.array_equal(F.packed_host(d), T.packed_host(d).astype(np.float32))
+        V = capi.DeviceVTables(N, M, D=2)
+        V.tables.fill_(float("nan"))
+        V.fill(a)
+        capi.check(L.stb_fill_status())
+        for d in range(2):
+            got = V.packed_host(d)
+            assert np.all(np.isfinite(got)) and orc.max_err(got, orc.fill_V(float(a[d]), N, M)) <= TOL
+    assert L.stb_fill_fallbacks() == before
+
+
+@pytest.mark.parametrize("prep,by_value", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")])
+def test_prep_launch_and_discounts_by_value(monkeypatch, prep, by_value):
+    """k_prep (the workspace zeroed, the S1 vector and the discounts written in one launch) against a memset, k_s1 and a
+    host-to-device copy: the same tables and S1 vectors bit for bit; 64 tables still travel by value, 65 by copy"""
+    ref = {}
+    for mode in (("1", "1"), (prep, by_value)):
+        monkeypatch.setenv("STB_HB_PREP", mode[0])
+        monkeypatch.setenv("STB_A_BY_VALUE", mode[1])
+        outs = []
+        for N, M, D in ((1200, 900, 3), (700, 80, 64), (700, 80, 65)):
+            a = np.linspace(0.02, 0.97, D)
+            T = capi.DeviceTables(N, M, D=D)
+            T.tables.fill_(float("nan"))
+            T.S1.fill_(float("nan"))
+            T.fill(a, capi.FILL_HB)
+            T.status()
+            outs.append((T.tables[:, :T.elems].cpu().numpy().copy(), T.S1.cpu().numpy().copy()))
+        ref[mode] = outs
+    for (t0, s0), (t1, s1) in zip(ref[("1", "1")], ref[(prep, by_value)]):
+        assert np.all(np.isfinite(s0)) and np.array_equal(s0, s1)
+        assert np.array_equal(t0, t1, equal_nan=True)
+    S1, tab = orc.fill_S(0.02, 1200, 900)
+    assert orc.close(ref[(prep, by_value)][0][1][0], S1, TOL)

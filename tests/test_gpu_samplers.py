@@ -395,3 +395,37 @@ def test_bterms_in_one_launch_has_the_bits_of_two(monkeypatch):
         finally:
             L.stb_bterms_free(c)
     assert np.all(np.isfinite(outs[0])) and np.array_equal(outs[0], outs[1])
+
+
+def test_spin_wait_and_stream_wait_give_the_same_samplers(monkeypatch):
+    """one-abscissa evaluations return through a word the last kernel writes to pinned memory (the host spins on it,
+    STB_SPIN_WAIT=1, the default) or through a wait for the stream (0): the same draws, abscissae and evaluation counts
+    of sampleb and samplea"""
+    import ctypes as C
+    L = capi.lib()
+    g = synth.groups(60, 50, 900, "wide")
+    nn = (C.POINTER(C.c_uint32) * g.I)()
+    tt = (C.POINTER(C.c_uint16) * g.I)()
+    off = 0
+    for i in range(g.I):
+        nn[i] = C.cast(g.n.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+        tt[i] = C.cast(g.t.ctypes.data + 2 * off, C.POINTER(C.c_uint16))
+        off += int(g.K[i])
+    runs = {}
+    for spin in ("1", "0"):
+        monkeypatch.setenv("STB_SPIN_WAIT", spin)
+        L.stb_sampler_cache_clear()
+        orc.seed_libc(777, 12345)
+        b = L.sampleb(10.0, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), 0.3, None, 1, 0)
+        nb = L.stb_sampler_trace_count()
+        orc.seed_libc(777, 12345)
+        a = L.samplea(0.5, g.I, orc.i32p(g.K), orc.u32p(g.T), nn, tt, None, orc.dp(g.bpar), None, 1, 0)
+        xs = []
+        for i in range(L.stb_sampler_trace_count()):
+            x, y = C.c_double(), C.c_double()
+            L.stb_sampler_trace_get(i, C.byref(x), C.byref(y))
+            xs.append((x.value, y.value))
+        runs[spin] = (b, nb, a, xs)
+    assert runs["1"] == runs["0"], runs
+    assert 0.0 < runs["1"][2] < 1.0 and runs["1"][0] > 0.0 and len(runs["1"][3]) >= 4
+    L.stb_sampler_cache_clear()
