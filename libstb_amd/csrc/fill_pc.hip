@@ -26,7 +26,8 @@
 #endif
 
 template <int NCW>
-__global__ __launch_bounds__(64 * (1 + NCW), PC_MINW) void k_fill_pc(fill_args A, int k, int P) {
+// (three consumer waves: 90 registers, five waves a SIMD -- asking for six only made the compiler say it could not)
+__global__ __launch_bounds__(64 * (1 + NCW), NCW == 3 ? PC_MINW - 1 : PC_MINW) void k_fill_pc(fill_args A, int k, int P) {
   constexpr int C = 4;
   constexpr int OW = 64 * NCW;      // owned (stored) columns per block
   constexpr int H = 256 - OW;       // halo columns recomputed per block
