@@ -100,6 +100,16 @@ struct hb_args {
   int order_lds;               // 1: the tile order fits the dynamic LDS segment
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
   int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
+  int n_cnt;                   // ticket counters: a multiple of D
+  int order_lds;               // 1: the tile order fits the dynamic LDS segment
+  int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
+  int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
+  int lead_nap;                // 1: the strips of a table's first workgroup sleep 64 cycles per block.  Every spine wave runs the same
+                               // instructions at the same pace, so a workgroup that once fell behind its left neighbour -- at its start,
+                               // or when a look at the records came back late -- stays that far behind for good: the hop it
+                               // shows at the end is the worst it ever had (~2 us), not what a hop costs (0.8 us, tools/hop_hb.py).
+                               // With the leftmost workgroup 3 % slower than the others everybody else has that much slack per block
+                               // to close up to what the hand-over really takes.
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
   // per item = (record index of the tile) * HB_DOT_NQ + (group of HB_DOT_GR rows of the block), and where the sums go
   const unsigned *item_ptr;        // [n_rec * HB_DOT_NQ + 1] first entry of every item
@@ -452,11 +462,19 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
       unsigned long long t_begin = 0;
       bool timing = false;
       unsigned idle = 0;
+#ifdef HB_TL_FINE
+      // (diagnostic build: when the look that found block b complete was sent and when it was back, per block of this
+      // workgroup's first strip -- behind the spine's fine stamps: [JW][NB][2])
+      unsigned long long *hopdbg = (X.dbg && d == 0) ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_order * 4 + (size_t)X.JW * NB * 8 + (size_t)jw0 * NB * 2 : nullptr;
+#endif
       while (bb < NB) {
         const int mb = bb + grp;
         const bool want = act && mb < NB;
         unsigned long long bv[C];
         unsigned be = 1;
+#ifdef HB_TL_FINE
+        const unsigned long long t_sent = HB_STAMP();
+#endif
 #pragma unroll
         for (int i = 0; i < C; i++) bv[i] = 1;
         if (want) {
@@ -475,6 +493,12 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         k = min(k, NB - bb);
         k = min(k, tk + HB_FSLOTS - bb);
         if (k > 0) {
+#ifdef HB_TL_FINE
+          if (hopdbg && sub == 0 && grp < k && mb < NB) {
+            hopdbg[(size_t)mb * 2] = t_sent;
+            hopdbg[(size_t)mb * 2 + 1] = HB_STAMP();
+          }
+#endif
           if (want && grp < k) {
             double *dst = &fv[mb & (HB_FSLOTS - 1)][sub * C];
 #pragma unroll
@@ -1275,7 +1299,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   if (hb_order_list(g, N, M, &X.rec_off, &X.order, X.split, &X.n_order)) return 1;
   const char *tl_file = getenv("STB_HB_TIMELINE");
 #ifdef HB_TL_FINE
-  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)X.n_order * 4 + (size_t)g.JW * g.NB * 8;
+  const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)X.n_order * 4 + (size_t)g.JW * g.NB * 8 + (size_t)g.JW * g.NB * 2;
 #else
   const size_t dbg_words = (size_t)g.JW * (g.NB + 2) + (size_t)X.n_order * 4;
 #endif
