@@ -100,16 +100,6 @@ struct hb_args {
   int order_lds;               // 1: the tile order fits the dynamic LDS segment
   int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
   int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
-  int n_cnt;                   // ticket counters: a multiple of D
-  int order_lds;               // 1: the tile order fits the dynamic LDS segment
-  int spare_work;              // 1: waves of a spine workgroup that have no strip work on tiles meanwhile
-  int doze;                    // 1: a spine wave sleeps until its left neighbour in the workgroup reaches its first block
-  int lead_nap;                // 1: the strips of a table's first workgroup sleep 64 cycles per block.  Every spine wave runs the same
-                               // instructions at the same pace, so a workgroup that once fell behind its left neighbour -- at its start,
-                               // or when a look at the records came back late -- stays that far behind for good: the hop it
-                               // shows at the end is the worst it ever had (~2 us), not what a hop costs (0.8 us, tools/hop_hb.py).
-                               // With the leftmost workgroup 3 % slower than the others everybody else has that much slack per block
-                               // to close up to what the hand-over really takes.
   // DOT kernels (aterms without a table, lib/samplea.c:68-80): the cells that occur among the (n,t) pairs, grouped
   // per item = (record index of the tile) * HB_DOT_NQ + (group of HB_DOT_GR rows of the block), and where the sums go
   const unsigned *item_ptr;        // [n_rec * HB_DOT_NQ + 1] first entry of every item
