@@ -317,9 +317,55 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
         unsigned *rec_e = X.ck_e + rec_base * U + slot;
         unsigned *prog = X.progress + ((size_t)d * X.JW + jw) * HB_PROG_STRIDE;
         double s = 1.0;
-        // Everything is set up (the loads above included) before the wave dozes until the fetcher has the first
+#ifdef HB_TL_FINE
+        unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_order * 4 + (size_t)jw * NB * 8 : nullptr;
+#define HB_FINE(k) if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP()
+#else
+#define HB_FINE(k)
+#endif
+        // what a block begins with and needs no halo for: the hand-over to the right neighbour in the workgroup and the
+        // block's record, both of the wave as it stands
+        auto block_top = [&](const int b) {
+          // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
+            if (has_next && (HB_ABL & 2)) lds_post(&posted[w], b + 1);
+            if (HB_LIKELY(has_next) && !(HB_ABL & 2)) {
+              // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
+              // but the last 4, which covers this block and the next three)
+              if (HB_UNLIKELY((b & 3) == 0 || b == b0)) wait_ge(&taken[w + 1], b - 4, 0x400u);
+              if (lane >= U) {
+                double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
+#pragma unroll
+                for (int i = 0; i < C; i++) dst[i] = v[i];
+                xe[w][b & (HB_SLOTS - 1)][lane - U] = ep;
+              }
+              lds_post(&posted[w], b + 1);
+            }
+            HB_FINE(2);
+            // ---- the record of the block: the own lanes as they stand before it (the halo lanes of strip 0 are
+            // exact: they go to strip index 0 at the place a left neighbour's rightmost lanes would have).
+            // (A publisher wave that takes the row from LDS and stores it in the spine's stead was tried: the spine
+            // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
+            if (HB_LIKELY(own || jw == 0) && !(HB_DIAG & 1) && !(HB_ABL & 8)) {
+              unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
+              if constexpr (C == 1) {
+                __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+              } else {
+#pragma unroll
+                for (int i = 0; i < C; i += 2)
+                  hb_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN,
+                                (unsigned long long)__double_as_longlong(v[i + 1]) | HB_WRITTEN);
+              }
+              __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0 && !(HB_ABL & 16)) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // Everything is set up (the loads above included) -- and the first block's top done: its record and hand-over are
+        // the wave as it stands, nothing of the halo -- before the wave dozes until the fetcher has the first
         // halo: a strip can never make up for a late start -- its neighbours walk at the same pace -- so what a
-        // workgroup loses at its start is added to the end of the fill, once per workgroup of the table.
+        // workgroup loses at its start is added to the end of the fill, once per workgroup of the table
+        // (tools/hop_hb.py: a hop is 0.8 us of hand-over and as much again of never-recovered start).
+        block_top(b0);
         while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
         // ... and until its left neighbour in the workgroup is about to hand over the first halo: a wave that spins on
         // the counter inside the block loop (every 64 cycles) takes issue slots from the spine wave it shares a SIMD
@@ -328,49 +374,13 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_s_setprio(3);
         if (dbg) dbg[0] = HB_STAMP();
-#ifdef HB_TL_FINE
-        unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_order * 4 + (size_t)jw * NB * 8 : nullptr;
-#define HB_FINE(k) if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP()
-#else
-#define HB_FINE(k)
-#endif
         for (int b = b0; b < NB; b++) {
           HB_FINE(0);
-          if (HB_LIKELY(b > b0) && !(HB_ABL & 4)) hb_renorm<C>(v, ep);
-          HB_FINE(1);
-          // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
-          if (has_next && (HB_ABL & 2)) lds_post(&posted[w], b + 1);
-          if (HB_LIKELY(has_next) && !(HB_ABL & 2)) {
-            // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
-            // but the last 4, which covers this block and the next three)
-            if (HB_UNLIKELY((b & 3) == 0 || b == b0)) wait_ge(&taken[w + 1], b - 4, 0x400u);
-            if (lane >= U) {
-              double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
-#pragma unroll
-              for (int i = 0; i < C; i++) dst[i] = v[i];
-              xe[w][b & (HB_SLOTS - 1)][lane - U] = ep;
-            }
-            lds_post(&posted[w], b + 1);
+          if (HB_LIKELY(b > b0)) {
+            if (!(HB_ABL & 4)) hb_renorm<C>(v, ep);
+            HB_FINE(1);
+            block_top(b);
           }
-          HB_FINE(2);
-          // ---- the record of the block: the own lanes as they stand before it (the halo lanes of strip 0 are
-          // exact: they go to strip index 0 at the place a left neighbour's rightmost lanes would have).
-          // (A publisher wave that takes the row from LDS and stores it in the spine's stead was tried: the spine
-          // got slower, 36 against 32.5 ns a row alone and 53 against 48 beside eight tables' workers.) ----
-          if (HB_LIKELY(own || jw == 0) && !(HB_DIAG & 1) && !(HB_ABL & 8)) {
-            unsigned long long *dst = rec_v + (size_t)b * (size_t)(U * C);
-            if constexpr (C == 1) {
-              __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-#pragma unroll
-              for (int i = 0; i < C; i += 2)
-                hb_store_wt16(dst + i, (unsigned long long)__double_as_longlong(v[i]) | HB_WRITTEN,
-                              (unsigned long long)__double_as_longlong(v[i + 1]) | HB_WRITTEN);
-            }
-            __hip_atomic_store(rec_e + (size_t)b * (size_t)U, (unsigned)ep + HB_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (lane == 0 && !(HB_ABL & 16)) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           HB_FINE(3);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
           if (jw > 0 && (HB_ABL & 1)) lds_post(&taken[w], b + 1);
@@ -505,9 +515,10 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
           idle = 0;
           continue;
         }
-for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
-        if (!woke) __builtin_amdgcn_s_sleep(4);  // (the left strip may be a long way from this one's first block; polling
-                                                 // without a pause until the first record has come: measured no gain)
+        // (until the first record has come the looks follow each other as fast as they return: what is lost before a
+        // strip's first block is lost for the whole fill -- 0.272 against 0.274 ms with a pause of 0.25 us between them)
+        if (woke)
+          for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
         if ((++idle & 31) != 0 && X.timeout != 0) continue;
         if (!timing) {
           timing = true;
