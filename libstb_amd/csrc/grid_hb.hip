@@ -489,13 +489,9 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
     unsigned wcur = 0;
     if ((ti & 63u) != 0 && (ti & 63u) != 63u) wcur = X.dense[(size_t)(ti >> 6) * 64 + lane];
     unsigned pend = 0xffffffffu;  // a job whose record has been stored and whose "written" word is still to be set
-    while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
-    if (w > 0)
-      while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_s_setprio(3);
-    if (dbg) dbg[0] = wall_clock64();
-    for (int b = b0; b < bE; b++) {
-      if (b > b00) gh_renorm<C>(v, ep);
+    // what a block begins with and needs no halo for: the hand-over to the right neighbour in the workgroup and, for the
+    // next workgroup, the block's record -- both of the wave as it stands
+    auto block_top = [&](const int b) {
       // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
       if (has_next) {
         if ((b & (SLH - 1)) == 0 || b == b0) wait_ge(&taken[w + 1], b - SLH, 0x400u);
@@ -516,6 +512,19 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
                         (unsigned long long)__double_as_longlong(v[i + 1]) | GH_WRITTEN);
         __hip_atomic_store(rec_e + (size_t)b * (size_t)HL, (unsigned)ep + GH_EOFF32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    };
+    // (the first block's top before the wave dozes for its first halo: what a strip loses at its start it never makes up
+    // -- its neighbours walk at the same pace -- see k_fill_hb; a phase that continues a strip renormalises first)
+    const bool top_done = b0 == b00 && b0 < bE;
+    if (top_done) block_top(b0);
+    while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
+    if (w > 0)
+      while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_setprio(3);
+    if (dbg) dbg[0] = wall_clock64();
+    for (int b = b0; b < bE; b++) {
+      if (b > b00) gh_renorm<C>(v, ep);
+      if (b > b0 || !top_done) block_top(b);
       // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
       if (jw > 0) {
         double hv[C];
@@ -636,8 +645,8 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
         idle = 0;
         continue;
       }
-      for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
-      if (!woke) __builtin_amdgcn_s_sleep(4);
+      if (woke)  // (until the first record has come the looks follow each other as fast as they return)
+        for (int i = 0; i < X.poll_nap; i++) __builtin_amdgcn_s_sleep(1);
       if ((++idle & 31) != 0 && X.timeout != 0) continue;
       if (!timing) {
         timing = true;
