@@ -1277,7 +1277,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   // rows 0.166 against 0.148), much shorter and the looks of thousands of waiting waves get in the spine's way
   X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C == 4 ? (dot ? 6 : 4) : 3);
   X.diag = stb_env_int("STB_HB_DIAG", 0);
-  X.spare_work = stb_env_int("STB_HB_SPARE", 0);
+  // (the waves of a spine workgroup that have no strip work on tiles from the start in the SUMMING form, whose tile workers
+  // are what it waits for from 8 discounts on -- N = M = 10^4, kernel ms with / without: 3 discounts at N = 4000 0.125 / 0.134,
+  // 8: 0.348 / 0.361, 12: 0.414 / 0.438, 16: 0.542 / 0.582, 24: 0.822 / 0.843, 1-6: alike -- not in the storing fills, where
+  // they take issue slots from a spine that decides: 8 tables 0.74-0.80 against 0.80)
+  X.spare_work = stb_env_int("STB_HB_SPARE", dot ? 1 : 0);
   // (measured, MI355X, N = M = 10^4: one table 0.365 ms with it against 0.321 without -- a late start is never made up,
   // and every strip's is up to 512 cycles late; 8 tables 0.74-0.80 against 0.80: off unless asked for)
   X.doze = stb_env_int("STB_HB_DOZE", 0);
