@@ -46,6 +46,13 @@
 #define HB_SLOTS 8       // ring of hand-overs between two spine waves of a workgroup (blocks); looked after every 4th block
 #define HB_FSLOTS 8      // ring of hand-overs from the fetcher to spine wave 0
 #define HB_MAXHL 32      // halo lanes at most
+// ... per strip shape: blocks have at most 48 rows with 2 or 4 columns per lane (+ a lane for the V table), 32 with one -- what
+// the hand-over rings in LDS are sized by (4 columns: 23 KB instead of 57)
+__host__ __device__ constexpr int hb_mhl(int C) { return C == 1 ? HB_MAXHL : (C == 2 ? 25 : 13); }
+#ifndef HB_NW_DOT4
+#define HB_NW_DOT4 14
+#endif                   // waves per workgroup of the summing form with 4 columns per lane: its tile workers are what a grid of 8-28
+                         // discounts waits for, and a workgroup has its compute unit alone (LDS) -- four more of them on it
 #define HB_EOFF32 (1u << 30)
 #define HB_WRITTEN 0x8000000000000000ull  // a record's significands (never negative) travel with the sign bit set
 #define HB_DOT_GR 8        // rows of a group of the summing form: its listed cells are looked up together, one per lane and pass
@@ -202,7 +209,7 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 #define HB_ABL 0  // timing-only builds (results wrong): the spine leaves out 1 the halo read, 2 the ring store, 4 the renormalisation, 8 the record, 16 the progress word
 #endif
 template <int C, int DOT, int OUT = 0>
-__global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args X) {
+__global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (DOT != 0 && C == 4) ? 1 : 2) void k_fill_hb(fill_args A, hb_args X) {
   static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
   static_assert(OUT == 0 || (DOT == 0 && C >= 2), "only the storing fill of 2 or 4 columns per lane narrows or divides");
   constexpr bool VT = (OUT & 2) != 0, FL = (OUT & 1) != 0;
@@ -211,17 +218,18 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
   constexpr bool LTX = (DOT == 0) && (HB_LTX != 0);  // the storing kernels hold the log table 16 times (see hb_logs8)
   __shared__ double2 lt[LTX ? 128 * 16 : 128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
-  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][HB_MAXHL * C];
-  __shared__ int xe[HB_PMAX][HB_SLOTS][HB_MAXHL];
-  __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][HB_MAXHL * C];
-  __shared__ int fe[HB_FSLOTS][HB_MAXHL];
+  constexpr int NW = (DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW, MHL = hb_mhl(C);
+  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][MHL * C];
+  __shared__ int xe[HB_PMAX][HB_SLOTS][MHL];
+  __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][MHL * C];
+  __shared__ int fe[HB_FSLOTS][MHL];
   __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
   __shared__ unsigned s_ticket;
   // dynamic segment.  Summing form: per wave four rows of the wave's 64 C significands; then, in both forms,
   // the tile order when it fits (a ticket then costs no dependent global load).
   extern __shared__ __attribute__((aligned(16))) double hb_dyn[];
-  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT ? (size_t)HB_NW * 4 * 64 * C : 0));
-  __shared__ int w_se[DOT ? HB_NW : 1][64];
+  unsigned *s_order = reinterpret_cast<unsigned *>(hb_dyn + (DOT ? (size_t)NW * 4 * 64 * C : 0));
+  __shared__ int w_se[DOT ? NW : 1][64];
   __shared__ int s_done[HB_MAXCNT];  // ticket counters this workgroup has found exhausted
   __shared__ unsigned s_recoff[HB_RECOFF_LDS];  // first record of every strip (a tile's record costs no global load)
 
@@ -392,8 +400,8 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
             // either way for one table -- the round trip is not what a block waits for)
             double hv[C];
             int he = 0;
-            const double *src = left_v + (b & left_mask) * (HB_MAXHL * C) + lane * C;
-            const int *srce = left_e + (b & left_mask) * HB_MAXHL + lane;
+            const double *src = left_v + (b & left_mask) * (MHL * C) + lane * C;
+            const int *srce = left_e + (b & left_mask) * MHL + lane;
             const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
 #ifdef HB_TL_FINE
             if (fdbg) fdbg[(size_t)b * 8 + 7] = (unsigned long long)(unsigned)(seen - b + 100);
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(64 * HB_NW, 2) void k_fill_hb(fill_args A, hb_args 
     // workgroup, so that the other waves do not ask there again).
     // (more than HB_MAXCNT tables share counters: table d asks counter d mod Dg)
     const unsigned NC = (unsigned)X.n_cnt, Dg = min((unsigned)X.D, (unsigned)HB_MAXCNT), S = NC / Dg;
-    unsigned cur = ((unsigned)blockIdx.x * HB_NW + (unsigned)wave) % NC, misses = 0;
+    unsigned cur = ((unsigned)blockIdx.x * NW + (unsigned)wave) % NC, misses = 0;
     for (;;) {
       if (lds_peek(&s_done[cur])) {
         if (++misses >= NC) break;
@@ -1007,7 +1015,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int sum_C = 0, bool vt
   if (Penv > 0 && Penv < Pc) Pc = Penv;
   int R = stb_env_int("STB_HB_ROWS", 48);
   if (R > Pc) R = Pc;
-  if (R > HB_MAXHL * g.C) R = HB_MAXHL * g.C;
+  if (R > (hb_mhl(g.C) - 1) * g.C) R = (hb_mhl(g.C) - 1) * g.C;
   R = R / 8 * 8;
   if (R < 8) return g;
   g.R = R;
@@ -1015,7 +1023,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int sum_C = 0, bool vt
   // a block.  The V table divides an own cell by its left neighbour IN THE SAME ROW, which for a strip's first own
   // column is the last halo column: one lane more keeps that one exact in the block's last row too.)
   g.HL = R / g.C + (vt ? 1 : 0);
-  if (g.HL > HB_MAXHL) return g;
+  if (g.HL > hb_mhl(g.C)) return g;
   g.U = 64 - g.HL;
   const int UC = g.U * g.C;
   const unsigned cmax = vt ? ((M < N) ? M : N) : ((M < N - 1) ? M : N - 1);  // columns 2..cmax hold stored cells: elements 0 .. cmax - 2
@@ -1089,7 +1097,7 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
   int Pc = stb_period_rows(N);
   for (int c : shapes)
     for (int r0 : rows) {
-      int R = std::min(std::min(r0, Pc), HB_MAXHL * c) / 8 * 8;
+      int R = std::min(std::min(r0, Pc), (hb_mhl(c) - 1) * c) / 8 * 8;
       if (R < 8) continue;
       const int HL = R / c + 1, U = 64 - HL, UC = U * c;  // (the V table's strips: a halo lane more, see hb_geometry)
       const unsigned cmax = (M < N) ? M : N;  // (the V table's: one column more than the S table's)
@@ -1354,9 +1362,10 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   }
   if (X.n_cnt < 1 || X.n_cnt > HB_MAXCNT) return stb_fail("stb_fill_S: %d ticket counters", X.n_cnt);
   if (dot) {
-    const size_t shm = (size_t)HB_NW * 4 * 64 * g.C * sizeof(double);
+    const int nw = g.C == 4 ? HB_NW_DOT4 : HB_NW;
+    const size_t shm = (size_t)nw * 4 * 64 * g.C * sizeof(double);
     switch (g.C) {
-      case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
+      case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * nw), shm, st, A, X); break;
       case 2: STB_LAUNCH_SHM((k_fill_hb<2, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
     }
