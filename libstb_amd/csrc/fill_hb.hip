@@ -48,7 +48,7 @@
 #define HB_MAXHL 32      // halo lanes at most
 // ... per strip shape: blocks have at most 48 rows with 2 or 4 columns per lane (+ a lane for the V table), 32 with one -- what
 // the hand-over rings in LDS are sized by (4 columns: 23 KB instead of 57)
-__host__ __device__ constexpr int hb_mhl(int C) { return C == 1 ? HB_MAXHL : (C == 2 ? 25 : 13); }
+__host__ __device__ constexpr int hb_mhl(int C) { return C == 1 ? HB_MAXHL : (C == 2 ? 25 : (C == 3 ? 17 : 13)); }
 #ifndef HB_NW_DOT4
 #define HB_NW_DOT4 14
 #endif                   // waves per workgroup of the summing form with 4 columns per lane: its tile workers are what a grid of 8-28
@@ -209,8 +209,8 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 #define HB_ABL 0  // timing-only builds (results wrong): the spine leaves out 1 the halo read, 2 the ring store, 4 the renormalisation, 8 the record, 16 the progress word
 #endif
 template <int C, int DOT, int OUT = 0>
-__global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (DOT != 0 && C == 4) ? 1 : 2) void k_fill_hb(fill_args A, hb_args X) {
-  static_assert(C == 1 || C == 2 || C == 4, "columns per lane");
+__global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (DOT != 0 && C >= 3) ? 1 : 2) void k_fill_hb(fill_args A, hb_args X) {
+  static_assert(C == 1 || C == 2 || C == 4 || (C == 3 && DOT != 0), "columns per lane (3: the summing form only)");
   static_assert(OUT == 0 || (DOT == 0 && C >= 2), "only the storing fill of 2 or 4 columns per lane narrows or divides");
   constexpr bool VT = (OUT & 2) != 0, FL = (OUT & 1) != 0;
   // a worker lane's groups of adjacent elements (see the workers; a float row of 4 columns per lane is one 16-byte store)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (
   constexpr bool LTX = (DOT == 0) && (HB_LTX != 0);  // the storing kernels hold the log table 16 times (see hb_logs8)
   __shared__ double2 lt[LTX ? 128 * 16 : 128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
-  constexpr int NW = (DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW, MHL = hb_mhl(C);
+  constexpr int NW = (DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW, MHL = hb_mhl(C);
   __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][MHL * C];
   __shared__ int xe[HB_PMAX][HB_SLOTS][MHL];
   __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][MHL * C];
@@ -358,6 +358,9 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (
               if constexpr (C == 1) {
                 __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+              } else if constexpr (C == 3) {
+                hb_store_wt16(dst, (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, (unsigned long long)__double_as_longlong(v[1]) | HB_WRITTEN);
+                __hip_atomic_store(dst + 2, (unsigned long long)__double_as_longlong(v[2]) | HB_WRITTEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               } else {
 #pragma unroll
                 for (int i = 0; i < C; i += 2)
@@ -802,6 +805,11 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (
                   *reinterpret_cast<hb_double2 *>(stage + (u >> 1) * WS + lane * 4 + 2) = hb_double2{v[0][2], v[0][3]};
                 } else if constexpr (C == 2) {
                   *reinterpret_cast<hb_double2 *>(stage + (u >> 1) * WS + lane * 2) = hb_double2{v[0][0], v[0][1]};
+                } else if constexpr (C == 3) {
+                  double *st3 = stage + (u >> 1) * WS + lane * 3;
+                  st3[0] = v[0][0];
+                  st3[1] = v[0][1];
+                  st3[2] = v[0][2];
                 } else {
                   stage[(u >> 1) * WS + lane] = v[0][0];
                 }
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C == 4) ? HB_NW_DOT4 : HB_NW), (
                   // (rows 1 and 3 of the group: n - 1 - m a times the cell above, plus the cell above and to the left
                   // -- under the left lane's exponent where that is another lane: the walk's own operations)
                   const int dl = (ln > 0 ? se[ln - 1] : e) - e;
-                  const double xl = row[cw - 1 < 0 ? 0 : cw - 1] * (((cw & (C - 1)) == 0) ? ldexp(1.0, min(max(dl, -1100), 220)) : 1.0);
+                  const double xl = row[cw - 1 < 0 ? 0 : cw - 1] * (((cw % C) == 0) ? ldexp(1.0, min(max(dl, -1100), 220)) : 1.0);
                   const double c1 = fma(-(double)(mE0 + cw), a, (double)(1 + b * R + q * HB_DOT_GR + r));
                   if (r & 1) x = fma(c1, x, xl);
                   const double val = bfp_log(x, e, lt);
@@ -1007,7 +1015,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int sum_C = 0, bool vt
   }
   if (g.C != 1 && g.C != 2 && g.C != 4) g.C = 2;
   // (a summing fill's cell lists are laid out for one strip shape, whatever the number of discounts: stb_hb_sum_C)
-  if (summing) g.C = (sum_C == 2) ? 2 : 4;
+  if (summing) g.C = (sum_C == 2 || sum_C == 3) ? sum_C : 4;
   g.P = 4;  // (one spine wave per SIMD: two on one slow each other by a third; see below)
   // a block is a renormalisation period (or less): rows in eights, halo lanes R / C <= 32
   int Pc = stb_period_rows(N);
@@ -1017,6 +1025,7 @@ static hb_geom hb_geometry(unsigned N, unsigned M, int D, int sum_C = 0, bool vt
   if (R > Pc) R = Pc;
   if (R > (hb_mhl(g.C) - 1) * g.C) R = (hb_mhl(g.C) - 1) * g.C;
   R = R / 8 * 8;
+  if (g.C == 3) R = R / 24 * 24;  // (halo lanes R / 3)
   if (R < 8) return g;
   g.R = R;
   // (halo: R columns -- a halo column k from the left is exact for k rows, so the own columns are through all R rows of
@@ -1092,12 +1101,13 @@ size_t stb_hb_workspace(unsigned N, unsigned M, int D) {
   // blocks of 8 rows, strips of 32 lanes -- is too much to ask for; size for the shapes the defaults and
   // the tests use, and let stb_launch_hb refuse what does not fit)
   size_t need = g0.bytes;
-  static const int shapes[3] = {1, 2, 4};
+  static const int shapes[4] = {1, 2, 3, 4};
   static const int rows[4] = {16, 24, 32, 48};
   int Pc = stb_period_rows(N);
   for (int c : shapes)
     for (int r0 : rows) {
       int R = std::min(std::min(r0, Pc), (hb_mhl(c) - 1) * c) / 8 * 8;
+      if (c == 3) R = R / 24 * 24;
       if (R < 8) continue;
       const int HL = R / c + 1, U = 64 - HL, UC = U * c;  // (the V table's strips: a halo lane more, see hb_geometry)
       const unsigned cmax = (M < N) ? M : N;  // (the V table's: one column more than the S table's)
@@ -1224,14 +1234,20 @@ static int hb_order_list(const hb_geom &g, unsigned N, unsigned M, const unsigne
 // SIMD each with room to spare for the tile workers (MI355X, kernel ms, 2 against 4 columns: N = 10^4, 2 discounts 0.296
 // against 0.331, 4: 0.337 against 0.333; N = 4000, 2: 0.156 against 0.164, 3: 0.137 against 0.145); 4 beyond
 int stb_hb_sum_C(unsigned N, unsigned M, int Dmax) {
+  // 2 columns per lane while the spine waves of Dmax tables get a SIMD each with room to spare; 3 -- strips of 144 columns
+  // behind 16 halo lanes, a row of 9 instructions instead of 11 -- while theirs fit on ~140 compute units; 4 beyond.
+  // (MI355X, kernel ms with 2 / 3 / 4 columns, N = M = 10^4: 3 discounts 0.283 / 0.301 / 0.320, 4: 0.338 / 0.301 / 0.323,
+  // 5: 0.347 / 0.305 / 0.327, 6: - / 0.305 / 0.331, 8: 0.59 / 0.310 / 0.327, 9-10: - / 0.335 / 0.336, 12: - / 0.96 / 0.354;
+  // N = 4000: 8 discounts 0.153 / 0.136 / 0.144, 16: - / 0.150 / 0.156.)
   const unsigned cmax = (M < N - 1) ? M : N - 1;
-  const uint64_t waves2 = (uint64_t)(Dmax > 0 ? Dmax : 1) * ((cmax - 1 + 79) / 80);
-  const int c = stb_env_int("STB_HB_DOT_C", waves2 <= (uint64_t)stb_cu_count() * 5 / 4 ? 2 : 4);
-  return c == 2 ? 2 : 4;
+  const uint64_t D = (uint64_t)(Dmax > 0 ? Dmax : 1), cus = (uint64_t)stb_cu_count();
+  const uint64_t waves2 = D * ((cmax - 1 + 79) / 80), waves3 = D * ((cmax - 1 + 143) / 144);
+  const int c = stb_env_int("STB_HB_DOT_C", waves2 <= cus * 3 / 2 ? 2 : (waves3 <= cus * 9 / 4 ? 3 : 4));
+  return (c == 2 || c == 3) ? c : 4;
 }
 
 int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int sum_C) {
-  const hb_geom g = hb_geometry(N, M, D, sum_C == 2 ? 2 : 4);
+  const hb_geom g = hb_geometry(N, M, D, (sum_C == 2 || sum_C == 3) ? sum_C : 4);
   if (!g.ok || g.R % HB_DOT_GR != 0 || g.R / HB_DOT_GR > HB_DOT_NQ) return 1;
   const unsigned *rec_off = nullptr, *order = nullptr;
   if (hb_order_list(g, N, M, &rec_off, &order)) return 1;
@@ -1253,7 +1269,7 @@ int stb_hb_dot_info(unsigned N, unsigned M, int D, hb_dot_info *out, int sum_C) 
 int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_request *dot, unsigned **hdr_out, hipStream_t st, int out_kind) {
   const unsigned N = A.N, M = A.M;
   if (out_kind < 0 || out_kind > 3 || (out_kind && dot)) return stb_fail("stb_fill: output kind %d", out_kind);
-  const hb_geom g = hb_geometry(N, M, D, dot ? (dot->geom_C == 2 ? 2 : 4) : 0, (out_kind & 2) != 0);
+  const hb_geom g = hb_geometry(N, M, D, dot ? ((dot->geom_C == 2 || dot->geom_C == 3) ? dot->geom_C : 4) : 0, (out_kind & 2) != 0);
   if (!g.ok) return stb_fail("stb_fill_S: the halo-block form does not take N=%u M=%u D=%d", N, M, D);
   if (g.bytes > ws_left) return stb_fail("stb_fill_S: workspace too small for the halo-block form (%zu > %zu)", g.bytes, ws_left);
   if (dot && (!dot->item_ptr || dot->col0 != 3))
@@ -1283,7 +1299,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   // for a block (48 rows x 22 ns with 2 columns per lane, x 32-45 ns with 4), so that it looks again well before
   // the tile is due -- longer and it oversleeps (one table: 0.33 ms with 6 against 0.31 with 3; a table of 4000
   // rows 0.166 against 0.148), much shorter and the looks of thousands of waiting waves get in the spine's way
-  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C == 4 ? (dot ? 6 : 4) : 3);
+  X.nap_block = stb_env_int("STB_HB_NAP_BLOCK", g.C >= 3 ? (dot ? 6 : 4) : 3);
   X.diag = stb_env_int("STB_HB_DIAG", 0);
   // (the waves of a spine workgroup that have no strip work on tiles from the start in the SUMMING form, whose tile workers
   // are what it waits for from 8 discounts on -- N = M = 10^4, kernel ms with / without: 3 discounts at N = 4000 0.125 / 0.134,
@@ -1362,10 +1378,11 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   }
   if (X.n_cnt < 1 || X.n_cnt > HB_MAXCNT) return stb_fail("stb_fill_S: %d ticket counters", X.n_cnt);
   if (dot) {
-    const int nw = g.C == 4 ? HB_NW_DOT4 : HB_NW;
+    const int nw = g.C >= 3 ? HB_NW_DOT4 : HB_NW;
     const size_t shm = (size_t)nw * 4 * 64 * g.C * sizeof(double);
     switch (g.C) {
       case 4: STB_LAUNCH_SHM((k_fill_hb<4, 1>), dim3(grid), dim3(64 * nw), shm, st, A, X); break;
+      case 3: STB_LAUNCH_SHM((k_fill_hb<3, 1>), dim3(grid), dim3(64 * nw), shm, st, A, X); break;
       case 2: STB_LAUNCH_SHM((k_fill_hb<2, 1>), dim3(grid), dim3(64 * HB_NW), shm, st, A, X); break;
       default: return stb_fail("stb_fill_S: no summing halo-block kernel for %d columns per lane", g.C);
     }

@@ -42,7 +42,7 @@ def edgy(seed, I=60, K=50, n_max=1500):
     return g, n, t
 
 
-FORMS = [("hb2", {"STB_HB_DOT_C": "2"}, (1, 3)), ("hb4", {"STB_HB_DOT_C": "4"}, (1, 3, 8)),
+FORMS = [("hb2", {"STB_HB_DOT_C": "2"}, (1, 3)), ("hb3", {"STB_HB_DOT_C": "3"}, (1, 4, 8)), ("hb4", {"STB_HB_DOT_C": "4"}, (1, 3, 8)),
          ("grid2", {"STB_ATERMS_GRID": "1", "STB_GRID_C": "2"}, (2, 5)), ("grid4", {"STB_ATERMS_GRID": "1", "STB_GRID_C": "4"}, (3, 8)),
          ("grid4jobs", {"STB_ATERMS_GRID": "1", "STB_GRID_C": "4", "STB_GRID_HELP_NW": "1"}, (8,)),
          ("grid8", {"STB_ATERMS_GRID": "1", "STB_GRID_C": "8"}, (2, 8)),

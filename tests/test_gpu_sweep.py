@@ -255,17 +255,17 @@ def test_fused_aterms_equals_table_then_sweep(monkeypatch):
             L.stb_groups_free(h)
 
 
-@pytest.mark.parametrize("sum_C", ["2", "4"])
+@pytest.mark.parametrize("sum_C", ["2", "3", "4"])
 def test_fused_aterms_in_the_halo_block_form(monkeypatch, golden_dir, sum_C):
     """the default for a grid of discounts: the summing fill as k_fill_hb<C, DOT> (a spine that walks blocks of rows
     alone + tile workers that sum their tiles' listed cells; cell lists keyed by (tile, group of 8 rows)), with strips of
-    2 columns per lane (a set of few discounts: the faster walk) or 4.  Same
+    2 columns per lane (a set of few discounts: the faster walk), 3 or 4.  Same
     sums as the chain form to rounding -- against the reference's aterms golden values at 1e-10, against the
     chain form, run to run bit for bit -- with edge pairs, several tables, and a set whose chain-form lists are
     built later on the same object (both layouts live side by side)."""
     L = capi.lib()
     monkeypatch.setenv("STB_HB_DOT_C", sum_C)
-    UC = 208 if sum_C == "4" else 80
+    UC = {"2": 80, "3": 144, "4": 208}[sum_C]
     for name in ("mid_wide", "small_realistic"):
         spec = load(golden_dir, "aterms.json").get(name)
         if spec is None:
