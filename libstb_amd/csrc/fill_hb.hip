@@ -555,7 +555,8 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
     // free compute unit, this one must give its place up, or its waves would sit on tiles of strips whose
     // spine cannot start.  Waves without a part (no strip, no fetching) sleep until the spine is through:
     // a worker on the spine's compute unit takes issue slots from it.
-    if (X.spare_work && (wave > P || (wave == P && j == 0) || (wave < P && jw0 + wave >= X.JW))) {
+    // (X.spare_work: how many of them at most -- the others sleep until the spine is through, like all of them in a storing fill)
+    if (wave - P <= X.spare_work && X.spare_work && (wave > P || (wave == P && j == 0) || (wave < P && jw0 + wave >= X.JW))) {
       // (tunable: the spare waves work on tiles from the start, once every workgroup of the grid is running)
       unsigned spins = 0;
       while (__hip_atomic_load(X.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < 200000u)
@@ -1305,7 +1306,7 @@ int stb_launch_hb(fill_args &A, int D, char *ws, size_t ws_left, const dot_reque
   // are what it waits for from 8 discounts on -- N = M = 10^4, kernel ms with / without: 3 discounts at N = 4000 0.125 / 0.134,
   // 8: 0.348 / 0.361, 12: 0.414 / 0.438, 16: 0.542 / 0.582, 24: 0.822 / 0.843, 1-6: alike -- not in the storing fills, where
   // they take issue slots from a spine that decides: 8 tables 0.74-0.80 against 0.80)
-  X.spare_work = stb_env_int("STB_HB_SPARE", dot ? 1 : 0);
+  X.spare_work = stb_env_int("STB_HB_SPARE", dot ? 64 : 0);
   // (measured, MI355X, N = M = 10^4: one table 0.365 ms with it against 0.321 without -- a late start is never made up,
   // and every strip's is up to 512 cycles late; 8 tables 0.74-0.80 against 0.80: off unless asked for)
   X.doze = stb_env_int("STB_HB_DOZE", 0);
