@@ -350,6 +350,52 @@ def sampler_calls(g):
     return out
 
 
+def speedup_vs_n1(world: int, fill_ms: float, grid_ms: float, fresh_ms: float):
+    """scale_job's speed-up against the newest COMMITTED one-GPU line (profiles/r0X_bench_n1.json): ms(1) / ms(N) of the
+    same 64-discount job.  Another box, another day: the driver's own curve from back-to-back runs is the one that counts."""
+    for r in (6, 5, 4):
+        p = os.path.join(ROOT, "profiles", f"r0{r}_bench_n1.json")
+        if not os.path.exists(p):
+            continue
+        try:
+            with open(p) as f:
+                txt = f.read()
+            one = json.loads(txt[txt.index("{"):])["scale_job"]
+            base = {"fill": one["fill"]["ms"], "grid_aterms": one["grid_aterms"]["ms"], "grid_aterms_fresh": one.get("grid_aterms_fresh", {}).get("ms")}
+        except (ValueError, KeyError, TypeError):
+            continue
+        now = {"fill": fill_ms, "grid_aterms": grid_ms, "grid_aterms_fresh": fresh_ms}
+        return {"n1_source": os.path.relpath(p, ROOT), "ranks": world, "n1_ms": base,
+                **{k: (base[k] / now[k] if base[k] and now[k] else None) for k in now}}
+    return None
+
+
+def launcher_command(gpus: int, argv, port: int):
+    """the child that `python bench.py --gpus N` (no launcher in the environment) starts: one rank per GPU
+    under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container's host name may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(gpus: int, argv) -> int:
+    """run the N-rank job as a child process, pass its stdout / stderr through, return its exit code"""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")
+    port = int(env.get("MASTER_PORT", 0)) or free_port()
+    return subprocess.run(launcher_command(gpus, list(argv), port), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,6 +411,12 @@ def main():
     ap.add_argument("--batch-steps", type=int, default=50, help="timed steps of the 64-discount batch (scale_job)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher starts its own N ranks: a FRESH child process
+    # (python -m torch.distributed.run ... bench.py <the same arguments>), started before this process
+    # has made any GPU call -- never an exec of a process that has touched the GPU -- whose rank 0
+    # prints the line; this process only relays the child's output and exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -585,6 +637,7 @@ def main():
                             "log_posterior_d0_d63": [float(allpost[0]), float(allpost[63])],
                             "what": "steady state: the set's pairs unchanged between steps (lists built once)"},
             "grid_aterms_fresh": fresh_grid,
+            "speedup_vs_n1": speedup_vs_n1(world, dt64 * 1e3, dtg * 1e3, fresh_grid["ms"]),
             "note": "strong scaling: the same 64 tables / 64 x 10^6 grid-evals at every --gpus N; speed-up(N) = ms(1) / ms(N); "
                     "ms = mean over all steps (slowest rank, barriers outside), first5 / last5 = medians of single steps",
         }

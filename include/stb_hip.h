@@ -63,7 +63,7 @@ void stb_extend_policy(unsigned usedN, unsigned usedM, unsigned maxN, unsigned m
                        unsigned *newN, unsigned *newM);
 
 /* ---- K1/K2: fill D log-Stirling tables (D=1: S_remake; D>1: the batched-discount mode) ----
- * a_host[D]            discounts (host memory), 0 < a < 1
+ * a_host[D]            discounts (host memory), 0 <= a < 1 (a = 0: the unsigned Stirling numbers of the first kind)
  * d_tables             D slabs of stb_elems(N,M) doubles, slab d at d_tables + d*table_stride
  * d_S1                 D vectors of N doubles (S1[n-1] = log S^n_{1,a}), vector d at + d*s1_stride
  * d_ws / ws_bytes      scratch of at least stb_fill_workspace_bytes(N,M,D)
@@ -245,12 +245,11 @@ size_t stb_samplea2_partition(const uint16_t **m);
  * the log-posterior evaluations of the most recent samplea()/sampleb() call on this process:
  * how many, ARMS' return code (ignored by the samplers themselves, as in the reference), and the
  * i-th (abscissa, value) pair */
-/* samplea() keeps the device copy of the (n,t) pairs of its last call (sorted, 6 bytes a pair, plus
- * the tables' scratch) and reuses it when the next call brings the same pairs -- the reference's
- * callers resample a many times over unchanged counts; only T and bpar are refreshed.  The set is
- * kept per calling thread (its device memory stays allocated until the thread's next samplea with
- * other pairs, or this call) and recognised by a 64-bit hash of K, n, t and the shapes.  This drops
- * the calling thread's kept set (STB_SAMPLEA_CACHE=0 in the environment never keeps one). */
+/* samplea() keeps, per calling thread, ONE group set as a container (device buffers, pinned staging, stream, count
+ * slab) and hands every call's pairs over into it (stb_groups_pairs_*): a call of the same shape allocates nothing.
+ * The pairs themselves are NOT assumed to be the last call's: that reuse is opt-in (STB_SAMPLEA_CACHE=1 skips the
+ * hand-over when a 128-bit fingerprint of K, n, t and the shapes equals the last call's; INTEGRATION.md section 7 has the
+ * failure mode).  This call frees the calling thread's kept set and its device memory. */
 void stb_sampler_cache_clear(void);
 int stb_sampler_trace_count(void);
 int stb_sampler_trace_code(void);
