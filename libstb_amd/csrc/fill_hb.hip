@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "fill_chain.h"
@@ -138,6 +139,33 @@ __device__ __forceinline__ void hb_store_wt16(unsigned long long *p, unsigned lo
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v2) : "memory");
 }
 
+// the record of a spine block: C words per lane (each with the sign bit set) behind `p`, written through, by the lanes of
+// `mask` only -- the mask goes into exec and comes out again inside the statement: no branch round the stores (the
+// compiler's own masked region moved them out of line, two taken branches a block on the lone wave's path)
+template <int C>
+__device__ __forceinline__ void hb_store_record(unsigned long long mask, unsigned long long *p, const double (&v)[C]) {
+  typedef unsigned long long hb_u64x2 __attribute__((ext_vector_type(2)));
+  unsigned long long saved;
+  if constexpr (C == 1) {
+    const unsigned long long a = (unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(p), "v"(a) : "memory");
+  } else if constexpr (C == 2) {
+    const hb_u64x2 a = {(unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, (unsigned long long)__double_as_longlong(v[1]) | HB_WRITTEN};
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\ts_nop 0\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(p), "v"(a) : "memory");
+  } else if constexpr (C == 3) {
+    const hb_u64x2 a = {(unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, (unsigned long long)__double_as_longlong(v[1]) | HB_WRITTEN};
+    const unsigned long long c = (unsigned long long)__double_as_longlong(v[2]) | HB_WRITTEN;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\tglobal_store_dwordx2 %2, %4, off offset:16 sc1\n\ts_nop 0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "s"(mask), "v"(p), "v"(a), "v"(c) : "memory");
+  } else {
+    static_assert(C == 4, "columns per lane");
+    const hb_u64x2 a = {(unsigned long long)__double_as_longlong(v[0]) | HB_WRITTEN, (unsigned long long)__double_as_longlong(v[1]) | HB_WRITTEN};
+    const hb_u64x2 c = {(unsigned long long)__double_as_longlong(v[2]) | HB_WRITTEN, (unsigned long long)__double_as_longlong(v[3]) | HB_WRITTEN};
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\tglobal_store_dwordx4 %2, %4, off offset:16 sc1\n\ts_nop 0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "s"(mask), "v"(p), "v"(a), "v"(c) : "memory");
+  }
+}
+
 // ---- the log of a block-floating cell, eight cells at a time, stage-major (as in k_fill_chain) ----
 // (LTX: the table is held 16 times, entry e of copy c at lt[e * 16 + c], and a lane reads copy lane & 15: the sixteen lanes
 // a 16-byte LDS read serves per cycle then sit on sixteen different slots whatever their entries -- no bank conflicts,
@@ -184,6 +212,26 @@ __device__ __forceinline__ void hb_renorm(double (&v)[C], int &ep) {
   ep += sh;
 }
 
+// ... in two steps: the shift (from the lane as it stands) and its application (possibly to the lane a few rows later: any
+// shift that keeps the significands in range is as good as any other -- the arithmetic is scale-free and the logs are taken
+// from exponent field + lane exponent together)
+template <int C>
+__device__ __forceinline__ int hb_renorm_shift(const double (&v)[C]) {
+  // (v_max_f64 as written: fmax() first quiets its operands, an instruction each -- nothing here is a NaN)
+  double vmax = v[0];
+#pragma unroll
+  for (int i = 1; i < C; i++) asm("v_max_f64 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[i]));
+  int sh = (vmax != 0.0) ? __builtin_amdgcn_frexp_exp(vmax) + PC_BIAS : 0;
+  asm volatile("" : "+v"(sh));  // (here, not where it is used)
+  return sh;
+}
+template <int C>
+__device__ __forceinline__ void hb_renorm_apply(double (&v)[C], int &ep, int sh) {
+#pragma unroll
+  for (int i = 0; i < C; i++) v[i] = ldexp(v[i], -sh);
+  ep += sh;
+}
+
 // eight rows of the recurrence: lane l takes the last column of lane l - 1 (lane 0: nothing), scaled
 // by s = 2^(exponent of lane l-1 - exponent of lane l), frozen for the block
 template <int C>
@@ -205,6 +253,10 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 // one division away from it), 3 that ratio as float (lib/stable.c:483-537).
 #define HB_LIKELY(x) __builtin_expect(!!(x), 1)
 #define HB_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#ifndef HB_LEAN
+#define HB_LEAN 1  // 0: the block top as rounds 3-5 had it (a masked region per step, two waits for LDS; kept for A/B runs: make variant DEFS=-DHB_LEAN=0)
+#endif
+#define HB_EB (HB_LEAN ? HB_EOFF32 : 0u)
 #ifndef HB_ABL
 #define HB_ABL 0  // timing-only builds (results wrong): the spine leaves out 1 the halo read, 2 the ring store, 4 the renormalisation, 8 the record, 16 the progress word
 #endif
@@ -219,11 +271,15 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
   __shared__ double2 lt[LTX ? 128 * 16 : 128];
   // what a spine wave hands to its right neighbour at the start of a block: its rightmost HL lanes
   constexpr int NW = (DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW, MHL = hb_mhl(C);
-  __shared__ __attribute__((aligned(16))) double xv[HB_PMAX][HB_SLOTS][MHL * C];
-  __shared__ int xe[HB_PMAX][HB_SLOTS][MHL];
-  __shared__ __attribute__((aligned(16))) double fv[HB_FSLOTS][MHL * C];
-  __shared__ int fe[HB_FSLOTS][MHL];
-  __shared__ int posted[HB_NW], taken[HB_NW], fetched, s_abort, s_awake;
+  // Ring r (r = 0 .. P) is what spine wave r READS its halo from: ring 0 is filled by the fetcher (the left workgroup's last
+  // strip), ring w + 1 by spine wave w; ring HB_PMAX + 1 takes the writes of lanes that hand nothing over (no lane is
+  // masked off for a hand-over).  c_posted[r]: blocks below it are in ring r; c_taken[r]: blocks below it are in wave r's
+  // registers; c_huge: what a lane with nothing to check looks at.
+  constexpr int SLOTV = MHL * C, RINGV = HB_SLOTS * SLOTV, RINGE = HB_SLOTS * MHL;
+  __shared__ __attribute__((aligned(16))) double rgv[(HB_PMAX + 2) * RINGV];
+  __shared__ int rge[(HB_PMAX + 2) * RINGE];
+  __shared__ int c_posted[HB_NW + 1], c_taken[HB_NW + 1], c_huge, c_never, s_abort, s_awake;
+  static_assert(HB_FSLOTS == HB_SLOTS, "one ring shape");
   __shared__ unsigned s_ticket;
   // dynamic segment.  Summing form: per wave four rows of the wave's 64 C significands; then, in both forms,
   // the tile order when it fits (a ticket then costs no dependent global load).
@@ -264,11 +320,14 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
     if (tid < HB_NW) {
       const int jw = jw0 + tid;
       const int b0 = (jw < X.JW) ? hb_first_block(jw, UC, R) : NB;
-      posted[tid] = b0;  // hand-overs for blocks below it are nobody's business
-      taken[tid] = b0;
+      c_posted[tid + 1] = b0;  // hand-overs for blocks below it are nobody's business
+      c_taken[tid] = b0;
     }
     if (tid == 0) {
-      fetched = hb_first_block(jw0, UC, R);
+      c_posted[0] = hb_first_block(jw0, UC, R);  // (the fetcher's)
+      c_taken[HB_NW] = 0x7fffffff;
+      c_huge = 0x7fffffff;
+      c_never = -0x7fffffff;
       s_abort = 0;
       s_awake = (j == 0) ? 1 : 0;
     }
@@ -307,13 +366,10 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           v[i] = 0.0;
           coef[i] = (double)(1 + b0 * R) - (double)(m0 + i) * a;
         }
-        int ep = 1 + PC_BIAS;
+        int ep = 1 + PC_BIAS + (int)HB_EB;  // (HB_EB: what the lean spine's exponents carry, in registers and in the rings: a record's own offset)
         if (jw == 0 && lane == HL - 1) v[C - 1] = ldexp(1.0, -1 - PC_BIAS);  // row 1: S^1_1 = 1
         const bool has_next = (w + 1 < P) && (jw + 1 < X.JW);
-        const int *left_cnt = (w == 0) ? &fetched : &posted[w > 0 ? w - 1 : 0];
-        const double *left_v = (w == 0) ? &fv[0][0] : &xv[w > 0 ? w - 1 : 0][0][0];
-        const int *left_e = (w == 0) ? &fe[0][0] : &xe[w > 0 ? w - 1 : 0][0][0];
-        const int left_mask = (w == 0) ? HB_FSLOTS - 1 : HB_SLOTS - 1;
+        const int *left_cnt = &c_posted[w];
         unsigned long long *dbg = (X.dbg && d == 0 && lane == 0) ? X.dbg + (size_t)jw * (NB + 2) : nullptr;
         // own records: strip index jw + 1, blocks from b0; the halo of strip 0: strip index 0, blocks from 0
         // (nothing is loaded from global memory inside the block loop: a load is waited for with vmcnt(0), i.e.
@@ -327,26 +383,203 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
         double s = 1.0;
 #ifdef HB_TL_FINE
         unsigned long long *fdbg = dbg ? X.dbg + (size_t)X.JW * (NB + 2) + (size_t)X.n_order * 4 + (size_t)jw * NB * 8 : nullptr;
-#define HB_FINE(k) if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP()
+#ifndef HB_FINE_SET
+#define HB_FINE_SET 0x7f   // which of the seven stamps are made (a stamp waits for LDS and costs ~100 cycles: fewer stamps, truer blocks)
+#endif
+#define HB_FINE(k) if (((HB_FINE_SET) >> (k)) & 1) { if (fdbg) fdbg[(size_t)b * 8 + (k)] = HB_STAMP(); }
 #else
 #define HB_FINE(k)
 #endif
+#if HB_LEAN
+        // ---- the lean block top (round 6).  A block's 48 rows are ~1500 cycles of a lone wave; what the compiler made of
+        // the hand-over, the record and the halo between two blocks' rows was ~125 instructions and ~800 cycles more (masked
+        // regions with their branches, three waits for LDS, address products).  Here nothing is masked and nothing is
+        // multiplied: every lane writes its significands to a ring (the lanes that hand nothing over into a spare one),
+        // ONE word per lane carries both counters (lane 63: blocks posted to the right, lane 62: blocks taken from the left
+        // -- the latter one block late, which the rings' depth pays for), ONE word per lane is looked at (lane 63: what the
+        // left neighbour has posted, lane 61: what the right one has taken) and compared with the lane's own counter, and the
+        // halo is asked for straight after the hand-over, a record's stores ahead of its use.  Waves of a workgroup settle a
+        // round trip apart (the first look of a wave that is too close fails once and its wait puts it there).
+        const bool hand = lane >= U;
+        const bool halo = lane < HL && jw > 0;
+        const int wv_idx = hand ? (w + 1) * RINGV + (lane - U) * C : (HB_PMAX + 1) * RINGV + (lane % MHL) * C;
+        const int we_idx = hand ? (w + 1) * RINGE + (lane - U) : (HB_PMAX + 1) * RINGE + (lane % MHL);
+        const int rv_idx = w * RINGV + (lane < HL ? lane : 0) * C;
+        const int re_idx = w * RINGE + (lane < HL ? lane : 0);
+        int *const post_p = lane == 63 ? &c_posted[w + 1] : (lane == 62 ? &c_taken[w] : &rge[(HB_PMAX + 1) * RINGE + (lane % MHL)]);
+        const int *chk_p = (lane == 63 && jw > 0) ? &c_posted[w] : ((lane == 61 && has_next) ? &c_taken[w + 1] : (lane == 60 ? &c_never : &c_huge));
+        // (lane 63: b + 1 once block b is posted; lane 62: b, the blocks taken; lane 61: b - 6, what the right neighbour must
+        // have taken before the NEXT block's hand-over goes into its slot of the ring of 8; these are never halo lanes)
+        // (every other lane counts like lane 63: the halo lanes' b + 1 is the strip's progress word, see the record)
+        int vcnt = lane == 62 ? b0 - 1 : (lane == 61 ? b0 - 7 : b0);
+        // records: the own lanes' (every lane's in strip 0, whose halo is exact and stands for a left neighbour); the other
+        // lanes of a strip write the progress word with the store that carries the exponents
+        const bool rec_lane = own || jw == 0;
+        const unsigned long long rec_mask = __ballot(rec_lane);
+        unsigned long long *rvp = rec_v + (size_t)b0 * (size_t)(U * C);
+        unsigned *rep = rec_lane ? rec_e + (size_t)b0 * (size_t)U : prog;
+        const unsigned rep_step = rec_lane ? (unsigned)U : 0u;
+        const bool tl_on = X.dbg != nullptr;
+        auto spine_loop = [&](auto r48) {
+        constexpr bool R48 = decltype(r48)::value;
+        int b = b0;
+        for (;;) {
+          HB_FINE(1);
+          const int so = b & (HB_SLOTS - 1);
+          // ---- hand-over to the right: significands and exponent of every lane, then the counters ----
+          {
+            double *dst = &rgv[wv_idx + so * SLOTV];
+            if constexpr (C == 1) {
+              dst[0] = v[0];
+            } else if constexpr (C == 3) {
+              dst[0] = v[0];
+              dst[1] = v[1];
+              dst[2] = v[2];
+            } else {
+#pragma unroll
+              for (int i = 0; i < C; i += 2) *reinterpret_cast<hb_double2 *>(dst + i) = hb_double2{v[i], v[i + 1]};
+            }
+            rge[we_idx + so * MHL] = ep;
+          }
+          asm volatile("" ::: "memory");
+          vcnt += 1;
+          __hip_atomic_store(post_p, vcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          // ---- the halo is asked for: the counters first (LDS serves a wave's requests in order) ----
+          int seen = __hip_atomic_load(chk_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          double hv[C];
+          int he;
+          {
+            const double *src = &rgv[rv_idx + so * SLOTV];
+            if constexpr (C == 1) {
+              hv[0] = src[0];
+            } else if constexpr (C == 3) {
+              hv[0] = src[0];
+              hv[1] = src[1];
+              hv[2] = src[2];
+            } else {
+#pragma unroll
+              for (int i = 0; i < C; i += 2) {
+                const hb_double2 t2 = *reinterpret_cast<const hb_double2 *>(src + i);
+                hv[i] = t2.x;
+                hv[i + 1] = t2.y;
+              }
+            }
+            he = rge[re_idx + so * MHL];
+          }
+          HB_FINE(2);
+          // ---- the record of the block ----
+          hb_store_record<C>(rec_mask, rvp, v);
+          rvp += U * C;
+          __hip_atomic_store(rep, rec_lane ? (unsigned)ep : (unsigned)vcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rep += rep_step;
+          if (HB_UNLIKELY(jw == 0)) {
+            if (lane == 0) __hip_atomic_store(prog, (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          HB_FINE(3);
+          // ---- is the halo there, and has the right neighbour room for the next hand-over?  (Not in a strip's first block,
+          // whose lane 60 looks at a word that says no.) ----
+#ifdef HB_TL_FINE
+          if (fdbg) fdbg[(size_t)b * 8 + 7] = 101;  // (there at the first look)
+#endif
+          if (HB_UNLIKELY(__any(seen < vcnt))) {
+#ifdef HB_TL_FINE
+            if (fdbg) fdbg[(size_t)b * 8 + 7] = 99;
+#endif
+            if (b == b0) {
+              // Everything is set up -- and the first block's hand-over and record are out: they are the wave as it stands,
+              // nothing of the halo -- before the wave dozes until the fetcher has the first halo: a strip can never make up
+              // for a late start -- its neighbours walk at the same pace -- so what a workgroup loses at its start is added to
+              // the end of the fill, once per workgroup of the table (tools/hop_hb.py).
+              while (!lds_peek(&s_awake) && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(2);
+              if (w > 0 && X.doze)
+                while (lds_peek(left_cnt) < b0 + 1 && !lds_peek(&s_abort)) __builtin_amdgcn_s_sleep(8);
+              __builtin_amdgcn_s_setprio(3);
+              if (dbg) dbg[0] = HB_STAMP();
+              if (lane == 60) chk_p = &c_huge;
+            }
+            // (one LDS round trip per look: the counters and, behind them, the halo they guard -- a strip's first hand-over
+            // decides how far behind its left neighbour it walks for the rest of the fill)
+            bool there = false;
+            const double *src = &rgv[rv_idx + so * SLOTV];
+            for (int k = 0; k < HB_SPIN && !aborted; k++) {
+              const int seen2 = __hip_atomic_load(chk_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int i = 0; i < C; i++) hv[i] = src[i];
+              he = rge[re_idx + so * MHL];
+              if (!__any(seen2 < vcnt)) {
+                there = true;
+                break;
+              }
+            }
+            if (!there) {
+              if (jw > 0) wait_ge(left_cnt, b + 1, 0x100u);
+              if (has_next) wait_ge(&c_taken[w + 1], b - 6, 0x400u);
+#pragma unroll
+              for (int i = 0; i < C; i++) hv[i] = src[i];
+              he = rge[re_idx + so * MHL];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < C; i++) v[i] = halo ? hv[i] : v[i];
+          ep = halo ? he : ep;
+          if (HB_UNLIKELY(tl_on)) {
+            if (dbg) dbg[1 + b] = HB_STAMP();
+          }
+          HB_FINE(4);
+          // ---- R rows alone ----
+          {
+            const int dl = wave_shr1(ep, ep) - ep;
+            s = ldexp(1.0, min(max(dl, -1100), 220));
+          }
+          HB_FINE(5);
+          // (the next block's renormalisation shift is taken from the lane four rows before the block's end -- the rows hide
+          // its dependent steps; what the significands grow by in four rows, at most 2^(4 (2 log2 N + 1)), is inside the
+          // slack stb_period_rows leaves -- and applied after the last row: two ldexp and an add on the block top's path)
+          int sh;
+          if constexpr (R48) {
+#pragma unroll
+            for (int u = 0; u < 44; u++) hb_row<C>(v, coef, s);
+            sh = hb_renorm_shift<C>(v);
+#pragma unroll
+            for (int u = 44; u < 48; u++) hb_row<C>(v, coef, s);
+          } else {
+            for (int r = 0; r < R; r += 8) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) hb_row<C>(v, coef, s);
+            }
+            sh = hb_renorm_shift<C>(v);
+          }
+          HB_FINE(6);
+          if (HB_UNLIKELY(++b >= NB)) break;
+          HB_FINE(0);
+          hb_renorm_apply<C>(v, ep, sh);
+        }
+        };
+        // (the 48 rows of a block in line: a taken branch costs a lone wave most of a row)
+        if (HB_LIKELY(R == 48))
+          spine_loop(std::true_type{});
+        else
+          spine_loop(std::false_type{});
+#else
         // what a block begins with and needs no halo for: the hand-over to the right neighbour in the workgroup and the
         // block's record, both of the wave as it stands
         auto block_top = [&](const int b) {
           // ---- the rightmost HL lanes, for the right neighbour in this workgroup ----
-            if (has_next && (HB_ABL & 2)) lds_post(&posted[w], b + 1);
+            if (has_next && (HB_ABL & 2)) lds_post(&c_posted[w + 1], b + 1);
             if (HB_LIKELY(has_next) && !(HB_ABL & 2)) {
               // (the ring holds 8 blocks: every 4th block it is made sure that the right neighbour has taken all
               // but the last 4, which covers this block and the next three)
-              if (HB_UNLIKELY((b & 3) == 0 || b == b0)) wait_ge(&taken[w + 1], b - 4, 0x400u);
+              if (HB_UNLIKELY((b & 3) == 0 || b == b0)) wait_ge(&c_taken[w + 1], b - 4, 0x400u);
               if (lane >= U) {
-                double *dst = &xv[w][b & (HB_SLOTS - 1)][(lane - U) * C];
+                double *dst = &rgv[(w + 1) * RINGV + (b & (HB_SLOTS - 1)) * SLOTV + (lane - U) * C];
 #pragma unroll
                 for (int i = 0; i < C; i++) dst[i] = v[i];
-                xe[w][b & (HB_SLOTS - 1)][lane - U] = ep;
+                rge[(w + 1) * RINGE + (b & (HB_SLOTS - 1)) * MHL + lane - U] = ep;
               }
-              lds_post(&posted[w], b + 1);
+              lds_post(&c_posted[w + 1], b + 1);
             }
             HB_FINE(2);
             // ---- the record of the block: the own lanes as they stand before it (the halo lanes of strip 0 are
@@ -394,7 +627,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           }
           HB_FINE(3);
           // ---- the halo: the left neighbour's rightmost HL lanes as they stand before the block ----
-          if (jw > 0 && (HB_ABL & 1)) lds_post(&taken[w], b + 1);
+          if (jw > 0 && (HB_ABL & 1)) lds_post(&c_taken[w], b + 1);
           if (HB_LIKELY(jw > 0) && !(HB_ABL & 1)) {
             // (the counter and the data are asked for together -- LDS serves a wave's requests in order, so data
             // read after a counter that says "there" is there -- and only if the counter says "not yet" is it
@@ -403,8 +636,8 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
             // either way for one table -- the round trip is not what a block waits for)
             double hv[C];
             int he = 0;
-            const double *src = left_v + (b & left_mask) * (MHL * C) + lane * C;
-            const int *srce = left_e + (b & left_mask) * MHL + lane;
+            const double *src = &rgv[w * RINGV + (b & (HB_SLOTS - 1)) * SLOTV + lane * C];
+            const int *srce = &rge[w * RINGE + (b & (HB_SLOTS - 1)) * MHL + lane];
             const int seen = aborted ? 0x7fffffff : lds_peek(left_cnt);
 #ifdef HB_TL_FINE
             if (fdbg) fdbg[(size_t)b * 8 + 7] = (unsigned long long)(unsigned)(seen - b + 100);
@@ -429,7 +662,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
               ep = he;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slot is in registers: it may be written again)
-            lds_post(&taken[w], b + 1);
+            lds_post(&c_taken[w], b + 1);
           }
           if (dbg) dbg[1 + b] = HB_STAMP();
           HB_FINE(4);
@@ -452,6 +685,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           }
           HB_FINE(6);
         }
+#endif
         if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[NB + 1] = HB_STAMP();
         if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
@@ -494,7 +728,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           for (int i = 0; i < C; i++) bv[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           be = __hip_atomic_load(X.ck_e + (rec_left + mb) * U + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const int tk = lds_peek(&taken[0]);
+        const int tk = lds_peek(&c_taken[0]);
         bool have = be != 0;
 #pragma unroll
         for (int i = 0; i < C; i++) have = have && bv[i] != 0;
@@ -511,13 +745,13 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           }
 #endif
           if (want && grp < k) {
-            double *dst = &fv[mb & (HB_FSLOTS - 1)][sub * C];
+            double *dst = &rgv[(mb & (HB_FSLOTS - 1)) * SLOTV + sub * C];
 #pragma unroll
             for (int i = 0; i < C; i++) dst[i] = __longlong_as_double((long long)(bv[i] & ~HB_WRITTEN));
-            fe[mb & (HB_FSLOTS - 1)][sub] = (int)(be - HB_EOFF32);
+            rge[(mb & (HB_FSLOTS - 1)) * MHL + sub] = (int)(be - HB_EOFF32 + HB_EB);
           }
           bb += k;
-          lds_post(&fetched, bb);
+          lds_post(&c_posted[0], bb);
           if (!woke) {
             woke = true;
             lds_post(&s_awake, 1);
@@ -544,7 +778,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
               __hip_atomic_store(X.hdr + 1, 0x900u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
-          lds_post(&fetched, 0x7fffffff);  // release the spine: it runs on with stale halos
+          lds_post(&c_posted[0], 0x7fffffff);  // release the spine: it runs on with stale halos
           lds_post(&s_awake, 1);
           break;
         }
