@@ -96,6 +96,17 @@ int stb_fill_status(void);
  * producer/consumer form (no waits between workgroups) before it returns 0; this counts how often
  * that happened on this thread.  STB_CHAIN_NO_FALLBACK=1 turns the repeat off (status then fails). */
 unsigned stb_fill_fallbacks(void);
+/* A GPU shared with other processes.  The one-launch forms have workgroups that wait for each other; when other
+ * processes hold the compute units those waits burn scheduler quanta (a 1.4 ms evaluation was measured at 725 ms with
+ * four processes on one GPU).  Every such launch is timed on the device; stb_slow_launches() counts those that took more
+ * than 20 x what their geometry should (the first one is reported through yaps_message).  After two of them -- or from
+ * the start with STB_SHARED_GPU=1 in the environment / stb_set_shared_gpu(1) -- fills take the producer/consumer form and
+ * evaluations go through stored tables: no waits between workgroups, results within 1e-10 as ever.  STB_SHARED_GPU=0 /
+ * stb_set_shared_gpu(0) never switches; stb_set_shared_gpu(-1) is the automatic rule again. */
+unsigned stb_slow_launches(void);
+int stb_shared_gpu_mode(void);           /* 1: the forms without waits are being taken */
+void stb_set_shared_gpu(int mode);
+void stb_note_launch_span(double span_ms, double expect_ms);   /* (what the launches report; for tests of the rule) */
 /* 1 when the library carries the superseded fill forms (STB_FILL_SCALED_STEP / _SPLIT / _FUSED /
  * _CHAINX; tools/ablation); the default build refuses those variants with a message */
 int stb_has_ablation(void);

@@ -112,6 +112,10 @@ def lib() -> C.CDLL:
     sig("stb_fill_status", i, [])
     sig("stb_fill_fallbacks", C.c_uint, [])
     sig("stb_has_ablation", i, [])
+    sig("stb_slow_launches", C.c_uint, [])
+    sig("stb_shared_gpu_mode", i, [])
+    sig("stb_set_shared_gpu", None, [i])
+    sig("stb_note_launch_span", None, [C.c_double, C.c_double])
     sig("stb_fill_profile_begin", None, [])
     sig("stb_fill_profile_end", i, [c_double_p, c_int_p])
     sig("stb_fill_profile_span", C.c_double, [])

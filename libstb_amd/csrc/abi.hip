@@ -24,6 +24,59 @@ int stb_fail(const char *fmt, ...) {
 extern "C" const char *stb_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------------
+// A GPU that is not ours alone.  The one-launch forms (halo blocks, grid, chain) have workgroups that wait for other
+// workgroups of the same launch; that is safe on any device (a waiter only ever waits for a workgroup with a smaller
+// ticket, which is resident or done) but not cheap on a shared one: when other processes' kernels hold the compute units
+// the waiters cannot all be resident at once, each spins through whole scheduler quanta, and a 1.4 ms evaluation was seen
+// to take 725 ms (four processes x 16 discounts on one MI355X, MEASUREMENTS section R6.3) -- with no time-out firing,
+// because every single wait ends.  So: every such launch stamps its start and (its spine's) end, the host compares the
+// span with what the geometry should take, counts the launches that took more than 20 x that (stb_slow_launches) and
+// says so once; after two of them -- or at once with STB_SHARED_GPU=1 -- fills go to the producer/consumer form and
+// evaluations through stored tables and the gather, which have no waits between workgroups and degrade in proportion.
+// STB_SHARED_GPU=0 never switches.  The results of either route are within 1e-10 of the reference; they are not the
+// same bits (a fused evaluation sums in the order of its tiles, the gather in the order of the sorted pairs).
+#include <atomic>
+static std::atomic<unsigned> g_slow_launches{0};
+static std::atomic<int> g_shared_mode{-2};  // -2: not read from the environment yet; -1: automatic; 0 / 1: fixed
+extern "C" void yaps_message(const char *fmt, ...);
+
+static int shared_mode_now() {
+  int m = g_shared_mode.load(std::memory_order_relaxed);
+  if (m == -2) {
+    m = stb_env_int("STB_SHARED_GPU", -1);
+    if (m < -1 || m > 1) m = -1;
+    g_shared_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+
+bool stb_shared_gpu() {
+  const int m = shared_mode_now();
+  if (m >= 0) return m == 1;
+  return g_slow_launches.load(std::memory_order_relaxed) >= (unsigned)stb_env_int("STB_SHARED_AFTER", 2);
+}
+
+void stb_note_span(double span_ms, double expect_ms, const char *what) {
+  if (!(span_ms > 0.0) || !(expect_ms > 0.0)) return;
+  if (span_ms <= 20.0 * expect_ms || span_ms < 2.0) return;
+  const unsigned n = g_slow_launches.fetch_add(1u) + 1u;
+  if (n == 1u)
+    yaps_message("libstb_amd: %s took %.1f ms on the device where about %.2f ms are expected -- the GPU is shared or throttled; "
+                 "after %d such launches the library takes the forms without waits between workgroups (STB_SHARED_GPU=1 does so "
+                 "from the start, =0 never)\n", what, span_ms, expect_ms, stb_env_int("STB_SHARED_AFTER", 2));
+}
+
+extern "C" unsigned stb_slow_launches(void) { return g_slow_launches.load(); }
+extern "C" int stb_shared_gpu_mode(void) { return stb_shared_gpu() ? 1 : 0; }
+// mode: 1 on, 0 off, -1 automatic (and the count of slow launches starts again)
+extern "C" void stb_set_shared_gpu(int mode) {
+  g_shared_mode.store(mode < -1 || mode > 1 ? -1 : mode);
+  if (mode < 0) g_slow_launches.store(0u);
+}
+// (what the launches report; exported so that the policy can be exercised without a crowded GPU)
+extern "C" void stb_note_launch_span(double span_ms, double expect_ms) { stb_note_span(span_ms, expect_ms, "a launch"); }
+
+// ------------------------------------------------------------------------------------------------
 // rand() guard (see stb_common.h)
 
 // The lock covers only the count and the hand-over of the state: entry points of different threads run

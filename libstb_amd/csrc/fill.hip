@@ -200,6 +200,8 @@ static int pick_form(int variant, unsigned N, unsigned M, int D) {
     default:
       // the block-floating forms bound the scale between lanes for N < 2^27 (see k_fill_pc)
       if (N >= (1u << 27)) return FORM_ROWS_LOG;
+      // (a GPU shared with other processes: the form without waits between workgroups, see abi.hip)
+      if (stb_shared_gpu() && !g_dot_req_active()) return FORM_PC;
       if (hb_wins(N, M, D)) return FORM_HB;
       if (ck_wins(N, M, D)) return FORM_CK;
       return chain_wins(N, M, D) ? FORM_CHAIN : FORM_PC;
@@ -273,9 +275,16 @@ void stb_fill_last(last_fill *out) { *out = g_last; }
 // the form that has no waits between workgroups.
 int stb_fill_status_of(last_fill *lf) {
   if (!lf->hdr) return 0;
-  unsigned h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h, lf->hdr, sizeof(h), hipMemcpyDeviceToHost, lf->st));
+  unsigned h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h, lf->hdr, lf->stamped ? sizeof(h) : 4 * sizeof(unsigned), hipMemcpyDeviceToHost, lf->st));
   HIPCHK(hipStreamSynchronize(lf->st));
+  if (lf->stamped) {
+    // (the halo-block form stamps its first workgroup's start and its spine waves' ends, 100 MHz ticks)
+    const unsigned long long t0 = (unsigned long long)h[STB_HDR_T0] | ((unsigned long long)h[STB_HDR_T0 + 1] << 32);
+    const unsigned long long t1 = (unsigned long long)h[STB_HDR_T1] | ((unsigned long long)h[STB_HDR_T1 + 1] << 32);
+    if (t0 && t1 > t0)
+      stb_note_span((double)(t1 - t0) * 1e-5, 1e-3 * (100.0 + 0.05 * (double)lf->A.N * (1.0 + (double)lf->D / 8.0)), "a table fill (stb_fill_S)");
+  }
   if (h[1] == 0) return 0;
   stb_fail("%s: the fill gave up waiting for a neighbour block (code 0x%x, block %u of table %u)",
            lf->s_table ? "stb_fill_S" : "stb_fill_V", h[1], h[2] & 0xffffu, h[2] >> 16);
@@ -301,7 +310,7 @@ extern "C" int stb_fill_status(void) {
 // The halo-block form also stores floats (S_FLOAT) and V ratios: its tile workers narrow or divide what they hold in
 // double before the store -- the only form that does.  Taken for kinds 1-3 wherever it is taken for log S in double.
 static bool hb_takes_kind(unsigned N, unsigned M, int D, int kind) {
-  if (stb_env_int("STB_HB", -1) == 0 || !stb_hb_eligible_out(N, M, D, kind)) return false;
+  if (stb_env_int("STB_HB", -1) == 0 || stb_shared_gpu() || !stb_hb_eligible_out(N, M, D, kind)) return false;
   const uint64_t cells = (uint64_t)D * stb_table_cells(N, M);
   if (N < (unsigned)stb_env_int("STB_HB_MIN_N", 512) || cells > (uint64_t)stb_env_int("STB_HB_MAX_MCELLS", 1250) * 1000000ull) return false;
   return stb_hb_spine(N, M, D) <= (unsigned)stb_env_int("STB_HB_MAX_SPINE", stb_cu_count() * 25 / 32);
@@ -344,6 +353,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   const char *who = vtable ? "stb_fill_V" : "stb_fill_S";
   g_last.hdr = nullptr;  // whatever this thread filled before is no longer "the last fill"
   g_last.fell_back = false;
+  g_last.stamped = false;
   struct a_guard {  // (discounts still on their way when this call ends -- an error before the launch -- go nowhere)
     a_guard() { g_a_D = 0; }
     ~a_guard() { g_a_D = 0; }
@@ -391,6 +401,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
     unsigned *hdr = nullptr;
     if (stb_launch_hb(A, D, ws, ws_left, nullptr, &hdr, st, kind)) return 1;
     g_last.hdr = hdr;
+    g_last.stamped = true;
     g_last.A = A;
     g_last.D = D;
     g_last.st = st;
@@ -400,7 +411,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
   }
   if (vtable) {
     if (stb_a_flush(A, st)) return 1;
-    if (stb_env_int("STB_FILLV_CHAIN", 1)) {
+    if (stb_env_int("STB_FILLV_CHAIN", 1) && !stb_shared_gpu()) {
       unsigned *hdr = nullptr;
       if (stb_launch_vchain(A, D, ws, ws_left, &hdr, st)) return 1;
       g_last.hdr = hdr;
@@ -451,6 +462,7 @@ static int fill_common(const double *a_host, int D, unsigned N, unsigned M, doub
         if (stb_launch_grid(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
       } else if (stb_launch_hb(A, D, ws, ws_left, g_dot_req, &hdr, st)) return 1;
       g_last.hdr = hdr;
+      g_last.stamped = !(g_dot_req && g_dot_req->col0 == 4);
       g_last.A = A;
       g_last.D = D;
       g_last.st = st;

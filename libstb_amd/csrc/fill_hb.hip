@@ -310,6 +310,9 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
   const unsigned N = A.N, M = A.M;
   const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
   const int UC = U * C;
+  // (when the launch started, for the host's look at what it took: stb_note_span)
+  if (ticket == 0 && tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(X.hdr + STB_HDR_T0), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   if (ticket < X.n_spine) {
     // =========================================================================================
@@ -688,7 +691,10 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
 #endif
         if (lane == 0) __hip_atomic_store(prog, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[NB + 1] = HB_STAMP();
-        if (lane == 0) atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
+        if (lane == 0) {
+          atomicAdd(X.hdr + 4, 1u);  // (spine waves that are through: diagnostics only)
+          atomicMax(reinterpret_cast<unsigned long long *>(X.hdr + STB_HDR_T1), (unsigned long long)wall_clock64());  // (... and when)
+        }
         __builtin_amdgcn_s_setprio(0);
       }
     } else if (wave == P && j > 0) {

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(64 * GH_NWMAX, (C == 8 ? GH_C8_WAVES : 2)) void k_g
   // (the number of jobs comes from device memory: the list may have been built on the device a moment ago)
   const unsigned n_jobs = X.jobs ? min((unsigned)__builtin_amdgcn_readfirstlane((int)X.jobs[GH_JNUM]), X.job_cap) : 0u;
   const unsigned ticket = s_ticket;
+  // (when the walk started -- its first launch's first workgroup -- for the host's look at what it took: stb_note_span)
+  if (ticket == 0 && tid == 0) atomicCAS(reinterpret_cast<unsigned long long *>(X.hdr + STB_HDR_T0), 0ull, (unsigned long long)wall_clock64());
   const int R = X.R, HL = X.HL, U = X.U, NB = X.NB, P = X.P;
   const int UC = U * C;
   const int bB = X.b_begin, bE = X.b_end;

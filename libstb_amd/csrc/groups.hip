@@ -174,6 +174,10 @@ __global__ __launch_bounds__(256) void k_eval_tail(const double *dotp, int parts
     if (d == 0) {
       out_host[2 * Dmax] = (double)hdr[1];
       out_host[2 * Dmax + 1] = (double)hdr[2];
+      // (what the walk took, first workgroup's start to here, in 100 MHz ticks: the host compares it with what the
+      // geometry should take -- a GPU shared with other processes shows there and nowhere else)
+      const unsigned long long t0 = *reinterpret_cast<const unsigned long long *>(hdr + STB_HDR_T0);
+      out_host[2 * Dmax + 3] = t0 ? (double)((unsigned long long)wall_clock64() - t0) : 0.0;
       // (one discount: everything the host waits for is written -- it spins on this word instead of waiting for the
       // launch's completion signal, which reaches it microseconds later; seq = 0: nobody spins)
       if (seq != 0.0 && gridDim.x == 1) {
@@ -1121,6 +1125,8 @@ static int aterms_finish(stb_groups_t *g, float *ms_fill, float *ms_sweep, float
       return 2;  // (the caller repeats the evaluation through stored tables)
     }
     for (int d = 0; d < D; d++) g->pend_out[d] = g->h_out[d];
+    // (the walk's own span against what D chains of N rows should take: stb_note_span, abi.hip)
+    stb_note_span(g->h_out[2 * g->Dmax + 3] * 1e-5, 1e-3 * (100.0 + 0.05 * (double)g->N * (1.0 + (double)D / 16.0)), "a fused evaluation (stb_groups_aterms)");
     if (ms_fill) HIPCHK(hipEventElapsedTime(ms_fill, g->ev[0], g->ev[1]));
     if (ms_sweep) HIPCHK(hipEventElapsedTime(ms_sweep, g->ev[1], g->ev[2]));
     if (ms_terms) HIPCHK(hipEventElapsedTime(ms_terms, g->ev[2], g->ev[3]));
@@ -1182,7 +1188,8 @@ static int aterms_prepare(stb_groups_t *g, int D, bool allow_fuse, bool *fuse_ou
     hb_dot_info H1;
     fuse1 = stb_env_int("STB_ATERMS_HB", 1) && stb_hb_dot_info(g->N, g->M, 1, &H1, g->hb_sum_C) == 0;
   }
-  const bool fuse = allow_fuse && g->fused && (D >= 2 || fuse1) &&
+  // (a GPU shared with other processes: stored tables and the gather, no waits between workgroups -- abi.hip)
+  const bool fuse = allow_fuse && !stb_shared_gpu() && g->fused && (D >= 2 || fuse1) &&
                     (v == STB_FILL_SCALED || v == STB_FILL_CHAIN || v == STB_FILL_CK || v == STB_FILL_HB);
   // The summing fill also exists in the checkpointed form (recurrence-only spine + tile workers that walk
   // a tile again and sum its listed cells; STB_ATERMS_CK=1, or variant STB_FILL_CK), usable while its spine

@@ -102,6 +102,7 @@ struct last_fill {
   int D = 0;
   bool s_table = false, can_fall_back = false;
   bool fell_back = false;   // out of stb_fill_status_of: the fill gave up and was repeated with k_fill_pc
+  bool stamped = false;     // the header carries the launch's start and end stamps (STB_HDR_T0 / _T1)
   hipStream_t st = nullptr;
 };
 void stb_fill_last(last_fill *out);       // the calling thread's last fill
@@ -122,6 +123,14 @@ void stb_prof_events(hipEvent_t *e0, hipEvent_t *e1);
 
 // rows per renormalisation period of the block-floating forms that start a period at 2^-700
 int stb_period_rows(unsigned N);
+
+// a GPU shared with other processes (abi.hip): true -> the forms without waits between workgroups are taken;
+// stb_note_span: what a one-launch form's stamps say it took against what its geometry should take
+bool stb_shared_gpu();
+void stb_note_span(double span_ms, double expect_ms, const char *what);
+// header words of the one-launch forms that carry the stamps (100 MHz ticks, 64 bits each): start at word 6, end at word 8
+#define STB_HDR_T0 6
+#define STB_HDR_T1 8
 
 // the forms (each in its own translation unit); all return 0 or stb_fail(...)
 struct dot_request {  // set by stb_groups_aterms around its fill: the chain form sums count * log S
