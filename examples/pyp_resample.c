@@ -171,10 +171,9 @@ int main(int argc, char **argv) {
         if (!set[s]) yaps_quit("stb_groups_create: %s\n", stb_last_error());
       }
       stb_set_device(home);
-      for (s = 0; s < nsets; s++) /* queue everything ... */
-        if (stb_groups_aterms_async(set[s], x + lo[s], lo[s + 1] - lo[s], lp2 + lo[s], NULL)) yaps_quit("grid evaluation: %s\n", stb_last_error());
-      for (s = 0; s < nsets; s++) /* ... then wait: the GPUs (or the sets of one GPU) work side by side */
-        if (stb_groups_wait(set[s])) yaps_quit("grid evaluation: %s\n", stb_last_error());
+      /* one call: contiguous blocks of the grid queued on every set, then all waited for -- the GPUs (or the sets of one
+         GPU) work side by side (what it does inside: stb_groups_aterms_async on each, then stb_groups_wait on each) */
+      if (stb_groups_aterms_multi(set, nsets, x, grid, lp2)) yaps_quit("grid evaluation: %s\n", stb_last_error());
       for (d = 0; d < grid; d++) {
         const double err = fabs(lp2[d] - lp[d]) / (fabs(lp[d]) > 1 ? fabs(lp[d]) : 1);
         if (err > 1e-12) worst++;

@@ -193,6 +193,17 @@ int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, double *out_
  * host threads at once -- one per GPU, or several on one GPU; see INTEGRATION.md.) */
 int stb_groups_aterms_async(stb_groups_t *g, const double *x_host, int D, double *out_host, void *stream);
 int stb_groups_wait(stb_groups_t *g);
+/* The node from ONE host thread, for a C caller (the reference's callers are C: lib/samplea.c:155, test/demo.c:478-480).
+ * `sets` are k group sets made from the same pairs -- one per GPU: stb_groups_create_node makes min(ndev,
+ * stb_device_count()) of them on devices 0, 1, ... and returns how many (0 on failure); or the caller's own, e.g. several
+ * on one GPU -- and the D abscissae are sharded over them in contiguous blocks whose sizes differ by at most one (each
+ * must fit its set's Dmax): all are queued before any is waited for, and out_host[0..D) comes back in the grid's order,
+ * 8 bytes a discount through pinned host memory.  This is the discount-axis sharding of SURVEY 8e without a collective;
+ * the one-process-per-GPU layout (libstb_amd/shard.py, bench.py --gpus N) keeps the values on the devices and gathers
+ * them over RCCL instead. */
+int stb_groups_aterms_multi(stb_groups_t *const *sets, int k, const double *x_host, int D, double *out_host);
+int stb_groups_create_node(int ndev, int I, const int *K, const uint32_t *T, const uint32_t *nflat, const uint16_t *tflat,
+                           const double *bpar, unsigned N, unsigned M, int Dmax, stb_groups_t **sets_out);
 /* ... with the D log-posteriors left on the DEVICE, in d_out[0..D) (a device address), for a caller that hands them to a
  * collective: the discount axis sharded over the GPUs of a node, every rank all-gathers its share.  Queued
  * like _async; `stream` then waits on the device for the values, so work queued on it afterwards sees them.

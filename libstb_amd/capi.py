@@ -141,6 +141,8 @@ def lib() -> C.CDLL:
     sig("stb_groups_aterms_tables", i, [vp, c_double_p, i, c_double_p])
     sig("stb_groups_aterms_async", i, [vp, c_double_p, i, c_double_p, vp])
     sig("stb_groups_wait", i, [vp])
+    sig("stb_groups_aterms_multi", i, [C.POINTER(vp), i, c_double_p, i, c_double_p])
+    sig("stb_groups_create_node", i, [i, i, c_int_p, c_u32_p, c_u32_p, c_u16_p, c_double_p, u, u, i, C.POINTER(vp)])
     sig("stb_groups_aterms_device", i, [vp, c_double_p, i, vp, vp])
     sig("stb_groups_update_restaurants", i, [vp, c_u32_p, c_double_p])
     sig("stb_groups_pairs_begin", i, [vp])

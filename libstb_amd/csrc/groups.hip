@@ -198,6 +198,7 @@ int stb_groups_set_bounds(stb_groups_t *g, unsigned N, unsigned M) {
   if (g->have_bounds && g->N == N && g->M == M) return 0;
   if (N < 1 || M < 1) return stb_fail("stb_groups: table bounds N=%u M=%u", N, M);
   HIPCHK(hipStreamSynchronize(g->st));
+  g->have_bounds = 0;  // (until everything below has its new size: a failed allocation must not leave a set that looks ready)
   stb_lists_drop(g, false);
   void **ptrs[] = {(void **)&g->d_tables, (void **)&g->d_S1, &g->d_ws_fill};
   for (void **p : ptrs) {
@@ -1352,6 +1353,60 @@ extern "C" int stb_groups_aterms(stb_groups_t *g, const double *x_host, int D, d
 
 // the same values through stored tables and the sorted gather whatever D is: no set-up, which is
 // what a handful of abscissae evaluated once (ARMS' three starting points) want
+// ---- the node from ONE host thread (SURVEY 8e for a C caller; the reference's callers are C: lib/samplea.c:155,
+// test/demo.c:478-480).  k group sets -- normally one per device, each made after stb_set_device(dev) from the same pairs
+// (stb_groups_create_node does that) -- take contiguous blocks of the D abscissae, sizes differing by at most one, all are
+// queued before any is waited for, and out_host[0..D) comes back in the grid's order.  No collective: a C caller's
+// "gather" is D doubles arriving in pinned host memory, 8 bytes a discount; RCCL is the transport of the one-process-per-GPU
+// layout (libstb_amd/shard.py, bench.py), where the values stay on the devices.
+extern "C" int stb_groups_aterms_multi(stb_groups_t *const *sets, int k, const double *x_host, int D, double *out_host) {
+  STB_ENTRY;
+  if (!sets || k < 1 || !x_host || !out_host || D < 1) return stb_fail("stb_groups_aterms_multi: bad argument (k=%d D=%d)", k, D);
+  if (k > D) k = D;  // (a set without a discount sits the call out)
+  for (int s = 0; s < k; s++)
+    if (!sets[s]) return stb_fail("stb_groups_aterms_multi: set %d is null", s);
+  int rc = 0, queued = 0;
+  char first_err[512] = "";
+  for (int s = 0; s < k && !rc; s++) {
+    const int lo = (int)((long long)D * s / k), hi = (int)((long long)D * (s + 1) / k);
+    rc = stb_groups_aterms_async(sets[s], x_host + lo, hi - lo, out_host + lo, nullptr);
+    if (!rc) queued++;
+  }
+  if (rc) snprintf(first_err, sizeof(first_err), "%s", stb_last_error());
+  for (int s = 0; s < queued; s++)  // (whatever was queued is waited for, error or not)
+    if (stb_groups_wait(sets[s]) && !rc) {
+      rc = 1;
+      snprintf(first_err, sizeof(first_err), "%s", stb_last_error());
+    }
+  return rc ? stb_fail("stb_groups_aterms_multi: %s", first_err) : 0;
+}
+
+// one set per device for the call above: min(ndev, stb_device_count()) sets of the same pairs on devices 0, 1, ..., each able to
+// take Dmax discounts (so that any split of a grid of k * Dmax fits); returns how many were made (0: failure, nothing is left)
+extern "C" int stb_groups_create_node(int ndev, int I, const int *K, const uint32_t *T, const uint32_t *nflat, const uint16_t *tflat,
+                                      const double *bpar, unsigned N, unsigned M, int Dmax, stb_groups_t **sets_out) {
+  STB_ENTRY;
+  const int have = stb_device_count();
+  if (!sets_out || ndev < 1 || have < 1) {
+    stb_fail("stb_groups_create_node: %s", have < 1 ? "no HIP device" : "bad argument");
+    return 0;
+  }
+  const int k = ndev < have ? ndev : have;
+  for (int s = 0; s < k; s++) {
+    const int prev = stb_device_enter(s);
+    sets_out[s] = groups_create_here(I, K, T, nflat, tflat, bpar, N, M, Dmax);
+    stb_device_leave(prev);
+    if (!sets_out[s]) {
+      char msg[512];
+      snprintf(msg, sizeof(msg), "%s", stb_last_error());
+      for (int q = 0; q < s; q++) stb_groups_free(sets_out[q]);
+      stb_fail("stb_groups_create_node: device %d: %s", s, msg);
+      return 0;
+    }
+  }
+  return k;
+}
+
 extern "C" int stb_groups_aterms_tables(stb_groups_t *g, const double *x_host, int D, double *out_host) {
   STB_ENTRY;
   return groups_aterms(g, x_host, D, out_host, false, nullptr, nullptr, nullptr);

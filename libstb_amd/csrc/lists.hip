@@ -35,6 +35,9 @@
 #include <algorithm>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "groups.h"
 
 void stb_grid_tile_offsets(const grid_geom &g, std::vector<unsigned> &off);  // grid_hb.hip
@@ -350,6 +353,9 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
   if (nitems64 >= (1ull << 31) || elems64 * 4 > slab_limit_bytes()) return 2;
   S.PB = which >= 3 ? stb_pos_bits(H.C) : 8;
   if (H.G > 32 || H.HC - 1 + (int)S.UCp > (1 << S.PB)) return 2;  // (a position is row << PB | element)
+  // (the grid form's dense words are sized for the worst case; where that is beyond a 32-bit offset the sort-based builder,
+  // which sizes exactly, takes over -- decided here, before anything is queued)
+  if (which >= 3 && (size_t)H.NQ * ((size_t)(g->G / 64) + H.n_tiles + 1) >= (1u << 26)) return 2;
   const unsigned nitems = (unsigned)nitems64;
   const size_t elems = (size_t)elems64;
   hipStream_t st = g->st;
@@ -408,7 +414,9 @@ int stb_lists_slab_build(stb_groups_t *g, int which, int D, const hb_dot_info &H
   HIPCHK(hipMemsetAsync(g->d_ninf, 0, 8, st));
   hipLaunchKernelGGL(k_count_cells, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, g->d_n, g->d_t, G, N, M, S, g->d_slab, g->d_ninf);
   hipLaunchKernelGGL(k_item_count, dim3((nitems + 3) / 4), dim3(256), 0, st, g->d_slab, nitems, (unsigned)H.G * S.UCp, g->d_icnt);
-  g->n_inf = 0;  // (counted on the device: d_ninf)
+  // (the log-0 pairs of a layout built here are counted on the device, d_ninf, and added by k_eval_tail to g->n_inf, which
+  // is what a layout built by the sort counted on the host and stays: the two may count the same pairs twice, which is
+  // still "not zero"; stb_lists_drop zeroes it with the pairs)
   if (which < 3) {
     size_t tb = g->scan_tmp_bytes;
     if (rocprim::exclusive_scan(g->d_scan_tmp, tb, g->d_icnt, g->d_item_ptr[which], 0u, (size_t)nitems + 1, rocprim::plus<unsigned>(), st) != hipSuccess)
@@ -465,8 +473,9 @@ extern "C" int stb_groups_pairs_begin(stb_groups_t *g) {
   int rc = 0;
   // (whatever still reads the device copy of the old pairs, or copies out of the staging area, must be through)
   if (hipStreamSynchronize(g->st) != hipSuccess) rc = stb_fail("stb_groups_pairs_begin: %s", hipGetErrorString(hipGetLastError()));
-  if (!rc && !g->h_pn && g->G) {
-    if (stb_pool_malloc((void **)&g->h_pn, 4 * (size_t)g->G, 1) != hipSuccess || stb_pool_malloc((void **)&g->h_pt, 2 * (size_t)g->G, 1) != hipSuccess)
+  if (!rc && g->G) {  // (each staging area for itself: one may be there from a call that failed on the other)
+    if ((!g->h_pn && stb_pool_malloc((void **)&g->h_pn, 4 * (size_t)g->G, 1) != hipSuccess) ||
+        (!g->h_pt && stb_pool_malloc((void **)&g->h_pt, 2 * (size_t)g->G, 1) != hipSuccess))
       rc = stb_fail("stb_groups_pairs_begin: out of pinned host memory");
   }
   g->put_n = g->flushed_n = 0;
@@ -598,10 +607,11 @@ struct put_pool {
 put_pool *g_put_pool = nullptr;  // (never destroyed: its threads sleep until the process ends)
 std::once_flag g_put_once;
 
-void put_run(put_job *J) {
-  for (;;) {
+// one slice, if any is left: copied by whoever calls (a worker of the pool, or the calling thread while it waits for them)
+bool put_step(put_job *J) {
+  {
     const int k = J->next.fetch_add(1);
-    if (k >= J->nslices) return;
+    if (k >= J->nslices) return false;
     put_slice &S = J->slices[k];
     unsigned mn = 0, mt = 0;
     uint64_t o = S.off, since = 0;
@@ -630,7 +640,15 @@ void put_run(put_job *J) {
     S.maxt = mt;
     S.done.store(S.count, std::memory_order_release);
   }
+  return true;
 }
+void put_run(put_job *J) {
+  while (put_step(J)) {
+  }
+}
+
+// (a fork()ed child has the pool's pointer but none of its threads: it copies on its own thread)
+void put_atfork_child() { g_put_pool = nullptr; }
 
 void put_worker(put_pool *P) {
   unsigned long long seen = 0;
@@ -666,7 +684,13 @@ static int put_all(stb_groups_t *g, int I, const int *K, uint32_t *const *n, uin
     G = g->G;
   }
   int W = stb_env_int("STB_PUT_THREADS", 4);
-  const unsigned hw = std::thread::hardware_concurrency();
+  // (the cores this process may run on, not those of the machine: under taskset to one core the calling thread copies alone)
+  unsigned hw = std::thread::hardware_concurrency();
+  {
+    cpu_set_t cs;
+    CPU_ZERO(&cs);
+    if (sched_getaffinity(0, sizeof(cs), &cs) == 0 && CPU_COUNT(&cs) > 0) hw = (unsigned)CPU_COUNT(&cs);
+  }
   if (hw && W > (int)hw - 1) W = (int)hw - 1;
   if (W > 16) W = 16;
   if (G < 131072) W = 0;  // (small sets: the calling thread is through before a worker is awake)
@@ -721,6 +745,7 @@ static int put_all(stb_groups_t *g, int I, const int *K, uint32_t *const *n, uin
       }
       for (auto &th : np->th) th.detach();
       g_put_pool = np;
+      (void)pthread_atfork(nullptr, nullptr, put_atfork_child);
     });
     P = (g_put_pool && !g_put_pool->th.empty()) ? g_put_pool : nullptr;
     if (P) {
@@ -757,7 +782,8 @@ static int put_all(stb_groups_t *g, int I, const int *K, uint32_t *const *n, uin
           rc = stb_fail("stb_groups_pairs_put_ragged: %s", hipGetErrorString(hipGetLastError()));
         flushed = upto;
       } else if (d != S.count) {
-        __builtin_ia32_pause();
+        // (nothing to hand over yet: take a slice too -- the workers may be busy, few, or, in a fork()ed child, gone)
+        if (!put_step(&J)) __builtin_ia32_pause();
       }
     }
   }

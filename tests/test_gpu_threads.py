@@ -183,3 +183,61 @@ def test_host_threads_hand_new_pairs_over_at_the_same_time():
     for _, _, h in packs:
         L.stb_groups_free(h)
     assert not errors, errors[:2]
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_a_grid_over_k_sets_from_one_call(k):
+    """stb_groups_aterms_multi: one host thread, k sets of the same pairs (here all on this box's one GPU; on a node one
+    per device, stb_groups_create_node), contiguous blocks of the grid, everything queued before anything is waited for:
+    each block has the bits of a single call with that block on a set of the same capacity, the whole grid those of the
+    reference within 1e-10, and a grid that does not fit is refused before anything is queued"""
+    L = capi.lib()
+    N = M = 2500
+    g = synth.groups(100, 1000, N, "wide", seed=synth.SEED + 31)
+    D = 13                                                   # (not a multiple of k: blocks of 4 / 5)
+    grid = np.ascontiguousarray(synth.discount_grid(64)[5:5 + D])
+    hs = [make_set(L, g, N, M, 8) for _ in range(k)]
+    ref = make_set(L, g, N, M, 8)
+    arr = (C.c_void_p * k)(*hs)
+    try:
+        out = np.full(D, np.nan)
+        if k == 1:                                           # 13 discounts on one set of 8: refused, nothing left pending
+            assert L.stb_groups_aterms_multi(arr, k, capi.dp(grid), D, capi.dp(out)) != 0
+            assert b"outside 1..8" in L.stb_last_error()
+            D = 8
+            grid = np.ascontiguousarray(grid[:8])
+            out = np.full(D, np.nan)
+        capi.check(L.stb_groups_aterms_multi(arr, k, capi.dp(grid), D, capi.dp(out)))
+        for s in range(k):
+            lo, hi = D * s // k, D * (s + 1) // k
+            one = np.zeros(hi - lo)
+            capi.check(L.stb_groups_aterms(ref, capi.dp(np.ascontiguousarray(grid[lo:hi])), hi - lo, capi.dp(one)))
+            assert np.array_equal(out[lo:hi], one), (s, out[lo:hi], one)
+        two = np.zeros(D)
+        for lo in range(0, D, 8):
+            hi = min(D, lo + 8)
+            part = np.zeros(hi - lo)
+            capi.check(L.stb_groups_aterms_tables(ref, capi.dp(np.ascontiguousarray(grid[lo:hi])), hi - lo, capi.dp(part)))
+            two[lo:hi] = part
+        assert np.all(np.abs(out - two) <= 1e-10 * np.abs(two))
+        # more sets than discounts: the sets beyond sit the call out
+        few = np.full(2, np.nan)
+        capi.check(L.stb_groups_aterms_multi(arr, k, capi.dp(grid), min(2, D), capi.dp(few)))
+        assert np.all(np.isfinite(few))
+    finally:
+        for h in hs + [ref]:
+            L.stb_groups_free(h)
+
+
+def test_create_node_makes_a_set_per_device():
+    L = capi.lib()
+    g = synth.groups(20, 50, 600, "wide", seed=3)
+    sets = (C.c_void_p * 8)()
+    k = L.stb_groups_create_node(8, g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar), 600, 600, 8, sets)
+    assert k == min(8, L.stb_device_count()) and k >= 1, capi.last_error()
+    grid = np.ascontiguousarray(synth.discount_grid(64)[:8 * k:k] if k > 1 else synth.discount_grid(64)[:8])
+    out = np.zeros(len(grid))
+    capi.check(L.stb_groups_aterms_multi(sets, k, capi.dp(grid), len(grid), capi.dp(out)))
+    assert np.all(np.isfinite(out))
+    for s in range(k):
+        L.stb_groups_free(sets[s])
