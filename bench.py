@@ -97,7 +97,7 @@ def cpu_baseline(N: int, M: int, a: float):
             for sp2 in sps:
                 if sp2:
                     R.S_free(sp2)
-            many = {"value": cells * nthr / wall, "unit": "cells/s", "cores": nthr, "tables": nthr, "seconds": wall,
+            many = {"value": cells * nthr / wall, "unit": "cells/s", "cores": nthr, "tables": nthr, "seconds": wall, "share_of_host": f"{nthr} of {os.cpu_count()} cpus: the pool gives a one-GPU job 16",
                     "cpus_in_affinity_mask": share,
                     "sample": f"{nthr} threads (the one-GPU job's share of the host), one S_remake of an N={N} M={M} table each, concurrently"}
         except Exception as e:  # never take the contract line down
@@ -114,8 +114,84 @@ def cpu_baseline(N: int, M: int, a: float):
     out = {"value": cells / best, "unit": "cells/s", "cores": 1, "kind": kind, "sample": what,
            "seconds": best, "host_cpus": os.cpu_count()}
     if many is not None:
-        out["multi_core"] = many
+        out["multi_core_job_share"] = many  # (SURVEY 8d-ii asks for all host cores on the 64-discount batch; a one-GPU job on this pool has 16)
     return out
+
+
+def dropin_section(N: int, M: int, a: float, probes: int = 1000000):
+    """SURVEY 8d metric 1 "with D2H mirror": what a caller of the reference's OWN interface pays -- S_remake of the table
+    (device fill) and then host look-ups through the pinned mirror, as the reference's Gibbs sweep does after every
+    S_remake (test/demo.c:427-428 reads S_V per customer, :487 rebuilds).  `probes` random (n, m) S_S calls in a C loop
+    (stb_table_probe), the mirror in its three modes, beside the reference's same loop on one host core; then a pass
+    over EVERY row in order (the full-table touch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+
+    rng = np.random.default_rng(20261005)
+    n = rng.integers(3, N + 1, probes).astype(np.uint32)
+    m = (2 + (rng.random(probes) * (np.minimum(n - 1, M) - 1))).astype(np.uint32)
+    rows_n = np.arange(3, N + 1, dtype=np.uint32)              # one cell of every row, top to bottom
+    rows_m = np.minimum(rows_n - 1, M).astype(np.uint32)
+    u32p = C.POINTER(C.c_uint)
+    res = {"N": N, "M": M, "probes": probes, "table_MB": 8.0 * synth.cells(N, M) / 1e6}
+    L = capi.lib()
+    outv = np.zeros(probes)
+    for mode in ("ahead", "lazy", "eager", "ahead_huge_pages"):
+        old = os.environ.get("STB_MIRROR")
+        if mode.startswith("ahead"):
+            os.environ.pop("STB_MIRROR", None)
+        else:
+            os.environ["STB_MIRROR"] = mode
+        os.environ.pop("STB_MIRROR_PAGES", None)
+        if mode == "ahead_huge_pages":   # (2 MB pages under the pinned mirror: no difference measured; on request only)
+            os.environ["STB_MIRROR_PAGES"] = "huge"
+        try:
+            t = capi.Table(N, M, N, M, a, capi.S_STABLE)
+            r = {}
+            for what, nn, mm in (("random", n, m), ("every_row", rows_n, rows_m)):
+                best = None
+                for rep in range(3):
+                    a2 = a + 0.01 * (rep + 1)
+                    t0 = time.perf_counter()
+                    t.remake(a2)
+                    t1 = time.perf_counter()
+                    L.stb_table_probe(t.sp, 0, nn.ctypes.data_as(u32p), mm.ctypes.data_as(u32p), len(nn), capi.dp(outv[: len(nn)] if len(nn) < probes else outv))
+                    t2 = time.perf_counter()
+                    cur = {"remake_ms": (t1 - t0) * 1e3, "lookups_ms": (t2 - t1) * 1e3, "total_ms": (t2 - t0) * 1e3}
+                    if best is None or cur["total_ms"] < best["total_ms"]:
+                        best = cur
+                best["mirror_blocks"] = t.mirrored()[0]
+                r[what] = best
+            res[mode] = r
+            if mode == "ahead":
+                keep = outv.copy()
+                keep_a = a + 0.03
+            t.free()
+        finally:
+            os.environ.pop("STB_MIRROR_PAGES", None)
+            if old is None:
+                os.environ.pop("STB_MIRROR", None)
+            else:
+                os.environ["STB_MIRROR"] = old
+    if orc.have_ref():
+        R = orc.ref()
+        sp = R.S_make(N, M, N, M, a, 1)
+        r = {}
+        ref_out = np.zeros(probes)
+        for what, nn, mm in (("random", n, m), ("every_row", rows_n, rows_m)):
+            t0 = time.perf_counter()
+            R.S_remake(sp, a + 0.03)
+            t1 = time.perf_counter()
+            R.ref_probe(sp, 0, nn.ctypes.data_as(u32p), mm.ctypes.data_as(u32p), len(nn), orc.dp(ref_out))
+            t2 = time.perf_counter()
+            r[what] = {"remake_ms": (t1 - t0) * 1e3, "lookups_ms": (t2 - t1) * 1e3, "total_ms": (t2 - t0) * 1e3}
+        R.S_free(sp)
+        res["cpu_reference_1core"] = r
+    res["speedup_every_row_lazy_over_ahead"] = res["lazy"]["every_row"]["total_ms"] / res["ahead"]["every_row"]["total_ms"]
+    res["what"] = ("S_remake + host look-ups through the reference's own interface (S_S in a C loop); ahead: a miss copies its block and sends "
+                   "the following >= 16 MB on their way asynchronously (default); lazy: every 128-row block a synchronous copy on first touch "
+                   "(rounds 1-5); eager: the whole mirror copied inside S_remake; best of 3, ms")
+    return res
 
 
 def cpu_sweep_baseline(g, N: int, M: int):
@@ -746,6 +822,11 @@ def main():
                     extra["sampler_sweep"]["cpu_sweep_baseline"] = cpu_sweep_baseline(g4k, s4k["N"], s4k["M"])
             except Exception as e:  # the extras must never take the contract line down
                 extra["sampler_error"] = repr(e)
+            try:
+                torch.cuda.empty_cache()
+                extra["dropin"] = {"N10000": dropin_section(10000, 10000, 0.5), "N4000": dropin_section(4000, 4000, 0.5)}
+            except Exception as e:
+                extra["dropin_error"] = repr(e)
         if extra:
             out["extra"] = extra
         print(json.dumps(out), flush=True)

@@ -114,6 +114,11 @@ void S_report(stable_t *sp, FILE *fp);
  * STB_MIRROR=eager in the environment, which makes every build do it.  Returns non-zero on a device
  * error. */
 int stb_table_sync(stable_t *sp);
+/* (round 6: a miss also sends the blocks BEHIND the touched one on their way, asynchronously, at least 16 MB of them --
+ * STB_MIRROR_AHEAD_MB -- so that a caller who goes through the table waits for the first block of a region only;
+ * STB_MIRROR=lazy is the old block-by-block behaviour) */
+/* out[g] = S_S (which = 0) or S_V (which = 1) of (n[g], m[g]): the accessors above in a loop */
+void stb_table_probe(stable_t *sp, int which, const unsigned *n, const unsigned *m, size_t G, double *out);
 /* how many 128-row blocks of the S and V mirrors have been copied from the device so far */
 void stb_table_mirrored(stable_t *sp, unsigned *s_blocks, unsigned *v_blocks);
 /* bytes this table holds on the device (slabs + fill workspace) and on the host (mirror + vectors); their sum, capped

@@ -44,9 +44,18 @@ void *stb_device_malloc(size_t bytes);                 /* hipMalloc; NULL on fai
 void stb_device_free(void *p);
 void *stb_host_malloc(size_t bytes);                   /* pinned (hipHostMalloc); NULL on failure */
 void stb_host_free(void *p);
+void *stb_host_malloc_huge(size_t bytes);              /* pinned AND on 2 MB pages (aligned_alloc + madvise + hipHostRegister); NULL on failure */
+void stb_host_free_huge(void *p);
 int stb_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int stb_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int stb_stream_sync(void *stream);
+void *stb_stream_create(void);                         /* a stream that does not synchronise with the null stream; NULL on failure */
+void stb_stream_destroy(void *stream);
+void *stb_event_create(void);
+void stb_event_destroy(void *ev);
+int stb_event_record(void *ev, void *stream);
+int stb_event_wait(void *ev);                          /* blocks the calling thread */
+int stb_event_done(void *ev);                          /* 1 done, 0 not yet, -1 error */
 
 /* ---- layout of one table slab (see libstb_amd/csrc/stb_layout.h) ---- */
 uint64_t stb_cells(unsigned N, unsigned M);        /* stored values: sum_{n=3..N} min(n-2,M-1) */
@@ -147,6 +156,16 @@ int stb_table_to_float(const double *d_src, float *d_dst, uint64_t elems, void *
 /* ---- lookups with S_S semantics (lib/stable.c:941-974, no growth): out[g] = S_S(n[g], t[g]) ---- */
 int stb_lookup_S(const double *d_table, const double *d_S1, unsigned N, unsigned M,
                  const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out, void *stream);
+
+/* ... and of the ratio table (a slab filled by stb_fill_V): out[g] = S_V / S_U / S_UV (n[g], m[g]) with the reference's
+ * identities and bounds (lib/stable.c:875-939; no growth, no asymptotic branch: outside the slab's bounds S_V is 0 as in
+ * :922).  What the table-indicator sampling step either side of the path reads (test/demo.c:405-445). */
+int stb_lookup_V(const double *d_vtable, unsigned N, unsigned M, const uint32_t *d_n, const uint32_t *d_m, uint64_t G,
+                 double *d_out, void *stream);
+int stb_lookup_U(const double *d_vtable, unsigned N, unsigned M, double a, const uint32_t *d_n, const uint32_t *d_m,
+                 uint64_t G, double *d_out, void *stream);
+int stb_lookup_UV(const double *d_vtable, unsigned N, unsigned M, double a, const uint32_t *d_n, const uint32_t *d_m,
+                  uint64_t G, double *d_out, void *stream);
 
 /* ---- K3: sweep.  out[d] = sum over pairs g with n[g]>1 of S_S_d(n[g], t[g])  (samplea.c:68-80) ---- */
 size_t stb_sweep_workspace_bytes(uint64_t G, int D);

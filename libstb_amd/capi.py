@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
     sig("S_report", None, [vp, vp])
     sig("stb_extend_policy", None, [u, u, u, u, i, i, C.POINTER(u), C.POINTER(u)])
     sig("stb_table_sync", i, [vp])
+    sig("stb_table_probe", None, [vp, i, C.POINTER(u), C.POINTER(u), sz, c_double_p])
     sig("stb_table_mirrored", None, [vp, C.POINTER(u), C.POINTER(u)])
     sig("stb_table_bytes", None, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
     # ---- include/yaps.h
@@ -130,6 +131,9 @@ def lib() -> C.CDLL:
     sig("stb_bterms_free", None, [vp])
     sig("stb_table_to_float", i, [vp, vp, u64, vp])
     sig("stb_lookup_S", i, [vp, vp, u, u, vp, vp, u64, vp, vp])
+    sig("stb_lookup_V", i, [vp, u, u, vp, vp, u64, vp, vp])
+    sig("stb_lookup_U", i, [vp, u, u, C.c_double, vp, vp, u64, vp, vp])
+    sig("stb_lookup_UV", i, [vp, u, u, C.c_double, vp, vp, u64, vp, vp])
     sig("stb_sweep_workspace_bytes", sz, [u64, i])
     sig("stb_sweep_S", i, [vp, u64, vp, u64, i, u, u, vp, vp, u64, vp, vp, sz, vp])
     sig("stb_terms_workspace_bytes", sz, [u64, i])

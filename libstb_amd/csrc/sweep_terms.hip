@@ -67,6 +67,59 @@ extern "C" int stb_lookup_S(const double *d_table, const double *d_S1, unsigned 
   return 0;
 }
 
+// ---- the ratio table's accessors on the device (lib/stable.c:875-939, no growth): what the table-indicator sampling step
+// either side of the path reads for every customer (test/demo.c:405-445: S_V / S_U / S_UV after every S_remake).
+// The V slab holds rows n = 2 .. N with m = 2 .. min(n, M) (stb_vrow_offset).  which: 0 V, 1 U, 2 UV.
+__device__ __forceinline__ double dev_S_V(const double *vtable, unsigned N, unsigned M, unsigned n, unsigned m) {
+  if (m < 2 || n < m || n > N || m > M || n < 2) return 0.0;  // (lib/stable.c:922, :929: "return 0")
+  return vtable[stb_vrow_offset(n, M) + (m - 2)];
+}
+__global__ void k_lookup_V(const double *vtable, unsigned N, unsigned M, double a, int which, const uint32_t *n, const uint32_t *m, uint64_t G,
+                           double *out) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; g < G; g += step) {
+    const unsigned nn = n[g], mm = m[g];
+    double r;
+    if (which == 0) {
+      r = dev_S_V(vtable, N, M, nn, mm);
+    } else if (which == 1) {  // S_U, lib/stable.c:875-883 (m = 0 is the caller's error there: a NaN here)
+      r = (mm == 1) ? (double)nn - a : (mm == 0 ? __longlong_as_double(0x7ff8000000000000ll) : (double)nn - (double)mm * a + 1.0 / dev_S_V(vtable, N, M, nn, mm));
+    } else {                  // S_UV, lib/stable.c:885-897
+      if (mm == 1) r = -HUGE_VAL;
+      else if (mm == nn + 1) r = 1.0;
+      else if (mm == nn) r = ((double)nn + 1.0) / ((double)nn - 1.0);
+      else r = ((double)nn - (double)mm * a) * dev_S_V(vtable, N, M, nn, mm) + 1.0;
+    }
+    out[g] = r;
+  }
+}
+
+static int lookup_v(const double *d_vtable, unsigned N, unsigned M, double a, int which, const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
+                    void *stream) {
+  if (G == 0) return 0;
+  if (!d_vtable || !d_n || !d_m || !d_out) return stb_fail("stb_lookup_V: null pointer");
+  uint64_t blocks = (G + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_lookup_V, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_vtable, N, M, a, which, d_n, d_m, G, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int stb_lookup_V(const double *d_vtable, unsigned N, unsigned M, const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out, void *stream) {
+  STB_ENTRY;
+  return lookup_v(d_vtable, N, M, 0.0, 0, d_n, d_m, G, d_out, stream);
+}
+extern "C" int stb_lookup_U(const double *d_vtable, unsigned N, unsigned M, double a, const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
+                            void *stream) {
+  STB_ENTRY;
+  return lookup_v(d_vtable, N, M, a, 1, d_n, d_m, G, d_out, stream);
+}
+extern "C" int stb_lookup_UV(const double *d_vtable, unsigned N, unsigned M, double a, const uint32_t *d_n, const uint32_t *d_m, uint64_t G, double *d_out,
+                             void *stream) {
+  STB_ENTRY;
+  return lookup_v(d_vtable, N, M, a, 2, d_n, d_m, G, d_out, stream);
+}
+
 // second stage: out[d] = base[d] + sum_b partial[d][b], one block per d, fixed order
 __global__ __launch_bounds__(256) void k_reduce_final(const dd_t *partial, int nb, double *out,
                                                       const double *base) {

@@ -101,6 +101,14 @@ double ref_trace_xl(void) { return ref_trace.xl; }
 double ref_trace_xr(void) { return ref_trace.xr; }
 
 /* ---- stable_t accessors (lib/stable.h:62-113) ---- */
+/* the reference's accessors in a loop (bench.py's drop-in leg: S_remake + host look-ups, beside the product's) */
+void ref_probe(stable_t *sp, int which, const unsigned *n, const unsigned *m, size_t G, double *out) {
+  size_t g;
+  if (which)
+    for (g = 0; g < G; g++) out[g] = S_V(sp, n[g], m[g]);
+  else
+    for (g = 0; g < G; g++) out[g] = S_S(sp, n[g], m[g]);
+}
 unsigned ref_usedN(stable_t *sp) { return sp->usedN; }
 unsigned ref_usedM(stable_t *sp) { return sp->usedM; }
 unsigned ref_usedN1(stable_t *sp) { return sp->usedN1; }

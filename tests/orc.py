@@ -207,6 +207,9 @@ def ref() -> C.CDLL:
     L.ref_copy_Sf_row.argtypes = [vp, u, c_float_p]
     L.ref_copy_Vf_row.restype = u
     L.ref_copy_Vf_row.argtypes = [vp, u, c_float_p]
+    if hasattr(L, "ref_probe"):
+        L.ref_probe.restype = None
+        L.ref_probe.argtypes = [vp, i, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_size_t, c_double_p]
     L.ref_copy_S1.restype = u
     L.ref_copy_S1.argtypes = [vp, c_double_p, u]
     L.ref_aterms_open.restype = vp

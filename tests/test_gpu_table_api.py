@@ -353,3 +353,85 @@ def test_quit_on_bound_is_fatal_like_the_reference(tmp_path):
     assert r.returncode == 1, (r.returncode, r.stdout, r.stderr)
     assert "inside True" in r.stdout and "not reached" not in r.stdout
     assert "S_S(61,5,0.500000) tagged 'bounded' hit bounds" in r.stderr
+
+
+def test_uv_lookups_on_the_device(golden_dir):
+    """stb_lookup_V / _U / _UV: the ratio table's accessors (lib/stable.c:875-939) over a device-resident V slab, against
+    the reference's recorded S_V / S_U / S_UV and against the host accessors on the same cells"""
+    import torch
+
+    L = capi.lib()
+    recs = load(golden_dir, "uv_access.json")
+    for a in sorted({fh(r["a"]) for r in recs}):
+        rs = [r for r in recs if fh(r["a"]) == a and r["n"] <= 200 and r["m"] <= 50]
+        V = capi.DeviceVTables(200, 50, D=1)
+        V.fill([a])
+        n = torch.tensor([r["n"] for r in rs] + [7, 9, 300, 40, 3], dtype=torch.int32, device="cuda")
+        m = torch.tensor([r["m"] for r in rs] + [1, 10, 5, 51, 4], dtype=torch.int32, device="cuda")   # + identities and out-of-bounds cells
+        out = [torch.empty(len(n), dtype=torch.float64, device="cuda") for _ in range(3)]
+        capi.check(L.stb_lookup_V(V.tables.data_ptr(), 200, 50, n.data_ptr(), m.data_ptr(), len(n), out[0].data_ptr(), None))
+        capi.check(L.stb_lookup_U(V.tables.data_ptr(), 200, 50, a, n.data_ptr(), m.data_ptr(), len(n), out[1].data_ptr(), None))
+        capi.check(L.stb_lookup_UV(V.tables.data_ptr(), 200, 50, a, n.data_ptr(), m.data_ptr(), len(n), out[2].data_ptr(), None))
+        v, u, uv = (o.cpu().numpy() for o in out)
+        for i, r in enumerate(rs):
+            if r["V"] is not None:
+                assert same(v[i], fh(r["V"]), 1e-13), r
+            if r["U"] is not None:
+                assert same(u[i], fh(r["U"]), 1e-13), r
+            assert same(uv[i], fh(r["UV"]), 1e-13), r
+        k = len(rs)
+        assert v[k] == 0.0 and u[k] == 7 - a and uv[k] == -np.inf          # m = 1 (lib/stable.c:876, :887)
+        assert v[k + 1] == 0.0                                             # n < m
+        assert v[k + 2] == 0.0 and v[k + 3] == 0.0                         # outside the slab's bounds: 0 (lib/stable.c:922)
+        assert uv[k + 4] == 1.0                                            # m = n + 1 (lib/stable.c:890)
+
+
+def test_mirror_look_ahead_gives_the_lazy_mirrors_values(monkeypatch):
+    import ctypes as C
+
+    """round 6: a miss copies its block and sends the blocks behind it on their way asynchronously.  Every value an accessor
+    returns is the one the block-by-block mirror (STB_MIRROR=lazy) returns; a rebuild and growth with copies still under
+    way are safe; runs of 1 MB and of 16 MB alike; the V table too"""
+    N = M = 2600
+    rng = np.random.default_rng(5)
+    n = rng.integers(3, N + 1, 4000).astype(np.uint32)
+    m = (2 + (rng.random(4000) * (np.minimum(n - 1, M) - 1))).astype(np.uint32)
+    u32p = C.POINTER(C.c_uint)
+    L = capi.lib()
+
+    def probe(t, which=0):
+        out = np.zeros(len(n))
+        L.stb_table_probe(t.sp, which, n.ctypes.data_as(u32p), m.ctypes.data_as(u32p), len(n), capi.dp(out))
+        return out
+
+    monkeypatch.setenv("STB_MIRROR", "lazy")
+    lazy = capi.Table(N, M, N, M, 0.37, capi.S_STABLE | capi.S_UVTABLE)
+    want_s, want_v = probe(lazy, 0), probe(lazy, 1)
+    lazy.remake(0.61)
+    want_s2 = probe(lazy, 0)
+    lazy.free()
+    for mb in ("1", "16"):
+        monkeypatch.delenv("STB_MIRROR")
+        monkeypatch.setenv("STB_MIRROR_AHEAD_MB", mb)
+        t = capi.Table(N, M, N, M, 0.37, capi.S_STABLE | capi.S_UVTABLE)
+        assert t.mirrored() == (0, 0)
+        first = t.S(40, 7)                                    # block 0, and a run behind it sets out
+        assert t.mirrored()[0] >= 1
+        assert np.array_equal(probe(t, 0), want_s) and np.array_equal(probe(t, 1), want_v)
+        assert t.S(40, 7) == first
+        t.remake(0.61)                                        # everything invalid again
+        assert t.mirrored() == (0, 0)
+        t.S(1500, 700)                                        # a miss in the middle: runs under way ...
+        t.remake(0.37)                                        # ... when the slabs are written again
+        t.S(2600, 1300)
+        t.remake(0.61)
+        assert np.array_equal(probe(t, 0), want_s2)
+        t.free()
+        monkeypatch.setenv("STB_MIRROR", "lazy")
+    monkeypatch.delenv("STB_MIRROR")
+    # growth with copies under way (the device slabs are replaced): values of the grown table
+    g = capi.Table(600, 200, N, M, 0.37, capi.S_STABLE)
+    g.S(100, 50)
+    got = probe(g, 0)                                         # grows on the way, several times
+    assert np.array_equal(got, want_s)
+    g.free()
