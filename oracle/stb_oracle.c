@@ -91,6 +91,86 @@ void orc_fill_S(double a, unsigned N, unsigned M, double *S1, double *table) {
   }
 }
 
+/* A few rows of a table too large to keep (N = M = 45 000 is 8 GB): the loop of orc_fill_S -- lib/stable.c:380-388, the
+ * same operations in the same order, hence the same bits -- over two row buffers, the columns shared out among `threads`
+ * threads that meet once per row (a cell needs the previous row only).  out[i * M + m - 2] = log S^{rows[i]}_m for
+ * m = 2 .. min(rows[i] - 1, M); rows ascending, each >= 3.  Pinned against orc_fill_S in tests/test_oracle_golden.py. */
+typedef struct {
+  double a;
+  unsigned N, M;
+  const unsigned *rows;
+  int k, threads, tid;
+  double *out, *buf[2];
+  const double *S1;
+  pthread_barrier_t *bar;
+} orc_rs_job;
+static void *orc_rs_worker(void *vp) {
+  orc_rs_job *J = (orc_rs_job *)vp;
+  const double a = J->a;
+  unsigned n, m;
+  int next = 0;
+  while (next < J->k && J->rows[next] < 3) next++;
+  if (J->tid == 0) {
+    J->buf[1][0] = orc_logadd(J->S1[1], log(2 - 2 * a)); /* row 3 lives in buf[3 & 1] */
+    if (next < J->k && J->rows[next] == 3) J->out[(size_t)next * J->M] = J->buf[1][0];
+  }
+  if (next < J->k && J->rows[next] == 3) next++;
+  pthread_barrier_wait(J->bar);
+  for (n = 4; n <= J->N; n++) {
+    const double *prev = J->buf[(n - 1) & 1];
+    double *cur = J->buf[n & 1];
+    const unsigned last = (n - 1 < J->M) ? n - 1 : J->M;
+    /* columns 2 .. last in contiguous shares */
+    const unsigned cnt = last - 1, lo = 2 + (unsigned)((uint64_t)cnt * (unsigned)J->tid / (unsigned)J->threads),
+                   hi = 2 + (unsigned)((uint64_t)cnt * ((unsigned)J->tid + 1) / (unsigned)J->threads);
+    for (m = lo; m < hi; m++) {
+      if (m == 2) {
+        cur[0] = orc_logadd(log(((double)(int)n - 2 * a) - 1.0) + prev[0], J->S1[n - 2]);
+      } else {
+        double up = (m < n - 1) ? prev[m - 2] : 0.0;
+        cur[m - 2] = orc_logadd(log(((double)(int)n - (double)(int)m * a) - 1.0) + up, prev[m - 3]);
+      }
+    }
+    if (next < J->k && J->rows[next] == n) {
+      for (m = lo; m < hi; m++) J->out[(size_t)next * J->M + m - 2] = cur[m - 2];
+      next++;
+    }
+    pthread_barrier_wait(J->bar);
+  }
+  return NULL;
+}
+int orc_rows_stream(double a, unsigned N, unsigned M, const unsigned *rows, int k, double *out, int threads) {
+  pthread_barrier_t bar;
+  pthread_t th[64];
+  orc_rs_job J[64];
+  double *S1, *b0, *b1;
+  unsigned n;
+  int t;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  if (N < 3 || M < 2) return 1;
+  S1 = (double *)malloc(sizeof(double) * N);
+  b0 = (double *)calloc(M, sizeof(double));
+  b1 = (double *)calloc(M, sizeof(double));
+  if (!S1 || !b0 || !b1) {
+    free(S1); free(b0); free(b1);
+    return 1;
+  }
+  S1[0] = 0;
+  for (n = 2; n <= N; n++) S1[n - 1] = S1[n - 2] + log((double)((int)n - 1) - a);
+  pthread_barrier_init(&bar, NULL, (unsigned)threads);
+  for (t = 0; t < threads; t++) {
+    J[t].a = a; J[t].N = N; J[t].M = M; J[t].rows = rows; J[t].k = k; J[t].threads = threads; J[t].tid = t;
+    J[t].out = out; J[t].buf[0] = b0; J[t].buf[1] = b1; J[t].S1 = S1; J[t].bar = &bar;
+  }
+  for (t = 1; t < threads; t++) pthread_create(&th[t], NULL, orc_rs_worker, &J[t]);
+  orc_rs_worker(&J[0]);
+  for (t = 1; t < threads; t++) pthread_join(th[t], NULL);
+  pthread_barrier_destroy(&bar);
+  free(S1); free(b0); free(b1);
+  return 0;
+}
+
 void orc_fill_V(double a, unsigned N, unsigned M, double *v) {
   unsigned n, m;
   const double *prev;

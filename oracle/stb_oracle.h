@@ -87,6 +87,9 @@ size_t orc_partition(double a, const double *table, const double *S1, unsigned N
 double orc_S_approx(int n, int m, float a);
 
 /* wall-clock helper for bench.py's cpu_baseline: seconds for `reps` fills, best-of */
+/* rows[0..k) (ascending, >= 3) of a table too large to keep: out[i * M + m - 2], the loop of orc_fill_S over two row
+ * buffers with the columns shared among `threads` threads; 0 on success */
+int orc_rows_stream(double a, unsigned N, unsigned M, const unsigned *rows, int k, double *out, int threads);
 double orc_time_fill(double a, unsigned N, unsigned M, int reps, double *S1, double *table);
 /* fills rows 3..N but only times/returns after `rows` rows (bounded sample); returns seconds and
  * writes the number of cells produced */

@@ -101,6 +101,8 @@ def oracle() -> C.CDLL:
     L.orc_partition.argtypes = [d, c_double_p, c_double_p, u, u, i, c_int_p, c_u32_p, c_u16_p, c_double_p, c_u16_p]
     L.orc_S_approx.restype = d
     L.orc_S_approx.argtypes = [i, i, C.c_float]
+    L.orc_rows_stream.restype = i
+    L.orc_rows_stream.argtypes = [d, u, u, C.POINTER(C.c_uint), i, c_double_p, i]
     L.orc_time_fill.restype = d
     L.orc_time_fill.argtypes = [d, u, u, i, c_double_p, c_double_p]
     L.orc_time_fill_rows.restype = d
@@ -281,6 +283,15 @@ def fill_V(a: float, N: int, M: int):
     v = np.zeros(int(L.orc_vcells(N, M)), dtype=np.float64)
     L.orc_fill_V(a, N, M, dp(v))
     return v
+
+
+def rows_stream(a: float, N: int, M: int, rows, threads: int = 8):
+    """rows (ascending, >= 3) of a table too large to keep on the host: {n: array of log S^n_m, m = 2 .. min(n-1, M)}"""
+    rows = np.ascontiguousarray(np.asarray(sorted(rows), dtype=np.uint32))
+    out = np.zeros((len(rows), M))
+    rc = oracle().orc_rows_stream(a, N, M, rows.ctypes.data_as(C.POINTER(C.c_uint)), len(rows), dp(out), threads)
+    assert rc == 0
+    return {int(n): out[i, : min(int(n) - 1, M) - 1].copy() for i, n in enumerate(rows)}
 
 
 def row_offset(n: int, M: int) -> int:

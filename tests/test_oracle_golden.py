@@ -282,3 +282,18 @@ def test_samplea2_partition_and_aterms2(golden_dir, run):
         got = L.orc_aterms2(fh(p["x"]), g.I, orc.i32p(g.K), orc.u32p(g.T), orc.u32p(g.n), orc.u16p(g.t), orc.dp(g.bpar),
                             orc.u16p(m))
         assert orc.close(got, fh(p["y"]), 1e-13), p
+
+
+def test_streamed_rows_are_the_stored_tables_rows():
+    """orc_rows_stream (rows of tables too large to keep: the scale tests' checker) against orc_fill_S, bit for bit, in
+    wide, narrow and one-thread shapes"""
+    import orc as _orc
+
+    for a, N, M, thr in ((0.5, 700, 700, 5), (0.23, 900, 120, 8), (0.0, 300, 300, 1), (0.9, 400, 50, 3)):
+        S1, tab = _orc.fill_S(a, N, M)
+        want_rows = [3, 4, 5, N // 3, N // 2, N - 1, N]
+        got = _orc.rows_stream(a, N, M, want_rows, threads=thr)
+        for n in want_rows:
+            ln = min(n - 1, M) - 1
+            o = _orc.row_offset(n, M)
+            assert np.array_equal(got[n], tab[o:o + ln]), (a, N, M, n)

@@ -95,6 +95,35 @@ def fuzz_fill():
     count[kind] += 1
 
 
+def fuzz_fill_big():
+    """round 6: tables past the configs -- M in [10^4, 3 x 10^4], N up to 1.5 M -- through the default dispatch; four rows
+    (the last among them) of every table against the oracle's streamed rows (the whole table is gigabytes)"""
+    M = int(rng.integers(10000, 30001))
+    N = int(min(45000, M + rng.integers(0, M // 2 + 1)))
+    D = int(rng.integers(1, 3))
+    a = pick_a(D)
+    T = capi.DeviceTables(N, M, D=D)
+    T.fill(a)
+    torch.cuda.synchronize()
+    T.status()
+    f = L.stb_fill_tuning(N, M, D, None, None, None)
+    forms[f] = forms.get(f, 0) + 1
+    rows = sorted({N, N - int(rng.integers(1, 200)), int(rng.integers(M // 2, N)), int(rng.integers(3, M // 2))})
+    for d in range(D):
+        want = orc.rows_stream(float(a[d]), N, M, rows, threads=16)
+        for r in rows:
+            o = T.rowoff(r)
+            got = T.tables[d, o:o + len(want[r])].cpu().numpy()
+            e = rel(got, want[r])
+            assert np.all(np.isfinite(got)) and e <= TOL, ("S big", N, M, float(a[d]), r, e)
+            worst["S"] = max(worst["S"], e)
+            count["cells"] += got.size
+    count["S"] += 1
+    count["big"] = count.get("big", 0) + 1
+    del T
+    torch.cuda.empty_cache()
+
+
 def fuzz_aterms():
     N = int(rng.integers(520, 3000))
     M = int(rng.integers(10, N + 1))
@@ -154,12 +183,16 @@ def fuzz_aterms():
 it = 0
 t_log = time.time()
 while time.time() < t_end:
-    (fuzz_fill if it % 3 else fuzz_aterms)()
+    if it % 40 == 17 and os.environ.get("FUZZ_BIG", "1") != "0":
+        fuzz_fill_big()
+    else:
+        (fuzz_fill if it % 3 else fuzz_aterms)()
     it += 1
     if time.time() - t_log > 30:
         t_log = time.time()
         print(f"... {it} cases, {count['cells']} cells, {count['pairs']} grid-evals", flush=True)
 assert L.stb_fill_fallbacks() == fb0 and L.stb_groups_fallbacks() == gfb0, "a one-launch form gave up"
 print(f"fuzz ok (seed {seed}, {budget:.0f} s): {count['S']} S fills, {count['Sf']} float fills, {count['V']} V fills = {count['cells']} cells; "
-      f"{count['aterms']} grid evaluations = {count['pairs']} grid-evals; forms picked {forms}")
+      f"{count['aterms']} grid evaluations = {count['pairs']} grid-evals; {count.get('big', 0)} tables with M in [10^4, 3 x 10^4] (four rows each "
+      f"against the streamed oracle); forms picked {forms}")
 print("worst deviation from the oracle, |x-y| / max(1,|y|): " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()) + "; none gave up")
