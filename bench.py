@@ -44,9 +44,9 @@ import torch
 from libstb_amd import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-TRAFFIC_DB = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
-                  os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"))
-PROFILE_ROUND = next((r for r in (5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r0{r}_sq_counters_fill1.txt"))), 4)
+TRAFFIC_DB = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(p)),
+                  os.path.join(ROOT, "profiles", "r06_hbm_traffic.json"))
+PROFILE_ROUND = next((r for r in (6, 5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r0{r}_sq_counters_fill1.txt"))), 4)
 N_SIMD = 1024           # 256 compute units x 4 SIMDs (MI355X)
 NOMINAL_CLOCK_HZ = 2.4e9
 FORM_NAMES = {2: "pc", 3: "chain", 4: "ck", 6: "hb"}

@@ -59,7 +59,10 @@ def lib() -> C.CDLL:
     # entry points added in round 5: an older build loaded through STB_LIB_PATH (tools/ab_lib.py, A/B against an
     # earlier round's library) simply lacks them; everything else must be there
     ROUND5 = {"stb_groups_pairs_begin", "stb_groups_pairs_put", "stb_groups_pairs_put_ragged", "stb_groups_pairs_commit",
-              "stb_groups_update_pairs", "stb_groups_fallbacks", "stb_grid_shape", "stb_bterms_update"}
+              "stb_groups_update_pairs", "stb_groups_fallbacks", "stb_grid_shape", "stb_bterms_update",
+              # ... and in round 6
+              "stb_table_probe", "stb_slow_launches", "stb_shared_gpu_mode", "stb_set_shared_gpu", "stb_note_launch_span",
+              "stb_lookup_V", "stb_lookup_U", "stb_lookup_UV", "stb_groups_aterms_multi", "stb_groups_create_node"}
 
     def sig(name, res, args):
         try:

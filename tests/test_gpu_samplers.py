@@ -285,17 +285,49 @@ def test_samplea_slice_branch_vs_reference(golden_dir, monkeypatch, run):
     assert got == fh(rec["a_out"])
 
 
-def test_sampleb_slice_variant_runs_on_device(monkeypatch):
+def test_sampleb_slice_variant_equals_the_host_slice_sampler_on_the_oracles_posterior(monkeypatch):
     """STB_SAMPLER=slice routes sampleb through SliceSimple too.  The reference's own slice branch of sampleb
     (lib/sampleb.c:141-153) starts from bmax(), which needs digammaInv -- compiled out in the shipped configuration
-    (lib/digamma.h:25) -- so there is nothing to record: this variant starts from b_in (DESIGN deviation 7) and is checked
-    for its range only"""
+    (lib/digamma.h:25) -- so nothing can be recorded from it: this variant starts from b_in (DESIGN deviation 7).  What CAN
+    be pinned: the run must be SliceSimple (bit-exact against the reference on the CPU, tests/test_host_logic.py) driven by
+    bterms.  So the run is repeated on the host -- the same libc streams, Q from the same Beta draws (lib/sampleb.c:90-100),
+    the library's SliceSimple with the ORACLE's bterms as its posterior -- and must give the same abscissae, one for one, the
+    same draw, and posterior values within 1e-10."""
     L = capi.lib()
+    O = orc.oracle()
     monkeypatch.setenv("STB_SAMPLER", "slice")
-    g = synth.groups(20, 30, 300, "realistic")
-    orc.seed_libc(777, 12345)
-    b = L.sampleb(10.0, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), 0.5, None, 2, 0)
-    assert 0.01 <= b <= 2000
+    L.gsl_rng_beta.restype = C.c_double
+    L.gsl_rng_beta.argtypes = [C.c_double, C.c_double]
+    POST = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+    L.SliceSimple.restype = C.c_int
+    L.SliceSimple.argtypes = [C.POINTER(C.c_double), POST, C.POINTER(C.c_double), C.c_void_p, C.c_int, C.c_void_p]
+    for seed, (I, K, nmax, prof), b_in, apar, loops in ((12345, (20, 30, 300, "realistic"), 10.0, 0.5, 2), (99, (300, 40, 2000, "wide"), 150.0, 0.3, 3),
+                                                      (7, (1000, 1, 500, "realistic"), 1.5, 0.8, 1)):
+        g = synth.groups(I, K, nmax, prof)
+        orc.seed_libc(777, seed)
+        b_dev = L.sampleb(b_in, g.I, g.shape, g.scale, orc.u32p(g.N), orc.u32p(g.T), apar, None, loops, 0)
+        xs, ys, _ = trace(L)
+        assert 0.01 <= b_dev <= 2000 and len(xs) >= loops
+        # the same run on the host
+        orc.seed_libc(777, seed)
+        Q = 1.0 / g.scale
+        for i in range(g.I):
+            if g.N[i] > 0:
+                Q -= np.log(L.gsl_rng_beta(b_in, float(int(g.N[i]))))
+        hx, hy = [], []
+
+        def post(x, _):
+            y = O.orc_bterms(x, Q, g.shape, g.I, orc.u32p(g.T), apar)
+            hx.append(x)
+            hy.append(y)
+            return y
+
+        b = C.c_double(b_in)
+        bounds = (C.c_double * 3)(0.01, 2000.0, 2000.0)
+        assert L.SliceSimple(C.byref(b), POST(post), bounds, None, loops, None) == 0
+        assert np.array_equal(xs, np.array(hx)), (xs, hx)
+        assert orc.close(ys, np.array(hy), 1e-10), orc.max_err(ys, np.array(hy))
+        assert b_dev == b.value
 
 
 def test_rand_stream_is_not_disturbed_by_the_runtime():
