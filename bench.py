@@ -136,15 +136,15 @@ def dropin_section(N: int, M: int, a: float, probes: int = 1000000):
     res = {"N": N, "M": M, "probes": probes, "table_MB": 8.0 * synth.cells(N, M) / 1e6}
     L = capi.lib()
     outv = np.zeros(probes)
-    for mode in ("ahead", "lazy", "eager", "ahead_huge_pages"):
+    for mode in ("ahead", "lazy", "eager", "ahead_small_pages"):
         old = os.environ.get("STB_MIRROR")
         if mode.startswith("ahead"):
             os.environ.pop("STB_MIRROR", None)
         else:
             os.environ["STB_MIRROR"] = mode
         os.environ.pop("STB_MIRROR_PAGES", None)
-        if mode == "ahead_huge_pages":   # (2 MB pages under the pinned mirror: no difference measured; on request only)
-            os.environ["STB_MIRROR_PAGES"] = "huge"
+        if mode == "ahead_small_pages":   # (hipHostMalloc's memory instead of 2 MB pages: the same on some boxes, 40 % slower look-ups on others)
+            os.environ["STB_MIRROR_PAGES"] = "small"
         try:
             t = capi.Table(N, M, N, M, a, capi.S_STABLE)
             r = {}

@@ -136,14 +136,15 @@ static void unlock(stable_t *sp) {
   if (sp->flags & S_THREADS) pthread_mutex_unlock(&sp->mutex);
 }
 
-/* the mirror's memory: pinned (1: hipHostMalloc), pinned and on 2 MB pages (2: STB_MIRROR_PAGES=huge), or plain (0: copies
- * are then staged by the runtime).  Huge pages are on request only: measured on the MI355X boxes' hosts (transparent huge
- * pages in madvise mode) 10^6 random look-ups over 400 MB take 14.3 ms either way -- the look-ups were never short of
- * TLB reach, they were long in instructions (see S_S). */
+/* the mirror's memory: pinned and on 2 MB pages (2: aligned_alloc + madvise + hipHostRegister; from 8 MB on), pinned (1:
+ * hipHostMalloc; STB_MIRROR_PAGES=small asks for it), or plain (0: copies are then staged by the runtime).  A caller's
+ * look-ups are random reads over the whole slab: 10^6 of them over 400 MB take 14.3 ms on 2 MB pages on every box measured;
+ * on hipHostMalloc's memory 14.3 on one box and 20-22 on another (whether the runtime's allocation happens to sit on huge
+ * pages is the box's state, not ours). */
 static void *host_slab(size_t bytes, int *pinned) {
   const char *pg = getenv("STB_MIRROR_PAGES");
   void *p = NULL;
-  if (bytes >= ((size_t)8 << 20) && pg && strcmp(pg, "huge") == 0) {
+  if (bytes >= ((size_t)8 << 20) && !(pg && strcmp(pg, "small") == 0)) {
     p = stb_host_malloc_huge(bytes);
     *pinned = 2;
   }
