@@ -257,6 +257,9 @@ __host__ __device__ static inline int hb_first_block(int j, int UC, int R) { ret
 #define HB_LEAN 1  // 0: the block top as rounds 3-5 had it (a masked region per step, two waits for LDS; kept for A/B runs: make variant DEFS=-DHB_LEAN=0)
 #endif
 #define HB_EB (HB_LEAN ? HB_EOFF32 : 0u)
+#ifndef HB_LEAN_MASK
+#define HB_LEAN_MASK 0  // 1: the lean top's hand-over and halo touch LDS with their own lanes only (masked regions again, less LDS work): measured, see MEASUREMENTS R6.1
+#endif
 #ifndef HB_ABL
 #define HB_ABL 0  // timing-only builds (results wrong): the spine leaves out 1 the halo read, 2 the ring store, 4 the renormalisation, 8 the record, 16 the progress word
 #endif
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           HB_FINE(1);
           const int so = b & (HB_SLOTS - 1);
           // ---- hand-over to the right: significands and exponent of every lane, then the counters ----
-          {
+          if (!HB_LEAN_MASK || hand) {
             double *dst = &rgv[wv_idx + so * SLOTV];
             if constexpr (C == 1) {
               dst[0] = v[0];
@@ -452,8 +455,12 @@ __global__ __launch_bounds__(64 * ((DOT != 0 && C >= 3) ? HB_NW_DOT4 : HB_NW), (
           int seen = __hip_atomic_load(chk_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
           double hv[C];
-          int he;
-          {
+          int he = 0;
+          if constexpr (HB_LEAN_MASK != 0) {
+#pragma unroll
+            for (int i = 0; i < C; i++) hv[i] = 0.0;
+          }
+          if (!HB_LEAN_MASK || lane < HL) {
             const double *src = &rgv[rv_idx + so * SLOTV];
             if constexpr (C == 1) {
               hv[0] = src[0];
