@@ -28,6 +28,11 @@
 // the last halo lane of strip 0, whose halo needs no neighbour (column 0 is identically zero): strip 0
 // computes it along.  The state before block b is row 1 + b R; row 1 is S^1_1 = 1.
 //
+// Round 6: what lies between two blocks' rows on a spine wave (hand-over, record, halo, renormalisation) was ~125
+// instructions and ~840 cycles beside the rows' ~1500; the block loop below (HB_LEAN) does it in ~60 and ~440 -- nothing
+// masked, one LDS word per lane for all signalling, the halo asked for a record's stores ahead of its use, the
+// renormalisation shift taken four rows before the block's end.  MEASUREMENTS.md section R6.1.
+//
 // A record word is its own flag: 0 means "not written yet" (significands, which are never negative, travel
 // with the sign bit set, exponents carry an offset); records are written with write-through stores and read with L1-bypassing loads.
 // Every wait is bounded; on expiry the waiter records an error in the header and everybody runs to the
